@@ -1,0 +1,162 @@
+"""Pins the CPU oracle against the reference's own golden vectors.
+
+Mirrors /root/reference/test/runtests.jl: test1 (:52-68), test2 (:70-76); test3 (:78-86)
+repeats test1's second case through DCAUtils' non-bit-packed Hamming path, which the
+oracle covers by checking its two Hamming forms against each other.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gdca_oracle as o
+
+from gdca_testutil import CASES, compare_with_golden, parse_golden
+
+
+@pytest.mark.parametrize("golden", list(CASES))
+def test_oracle_reproduces_reference_golden(golden, refdata):
+    c = CASES[golden]
+    R, inter = o.gDCA(os.path.join(refdata, c["fasta"]), return_intermediates=True, **c["kw"])
+    rep = compare_with_golden(R, os.path.join(refdata, golden))
+    # identical key sets (runtests.jl:44-45), every score within 1e-6 relative (7-digit prints)
+    assert rep["keys_equal"]
+    assert rep["max_rel"] <= 1e-6, rep
+    # the restatement reproduces every printed digit; allow isolated 7th-digit boundary flips
+    assert rep["string_mismatches"] <= 2, rep
+    assert rep["order_equal_mod_ties"], rep
+    if not golden.startswith("large"):
+        assert rep["order_equal"], rep
+    with open(os.path.join(os.path.dirname(refdata), "intermediates.json")) as f:
+        want = json.load(f)[golden]
+    assert inter["thresh"] == want["thresh"]
+    assert inter["M"] == want["M"] and inter["N"] == want["N"] and inter["q"] == want["q"]
+    assert inter["theta"] == want["theta"]
+    assert inter["Meff"] == want["Meff"]
+
+
+def test_golden_smoke_kats(refdata):
+    # SURVEY.md 4.3 "Smoke KATs": first and last rows of each reference golden
+    kats = {
+        "small.FNRout.txt": ("11 35 3.649475e+00", "9 46 -6.752293e-01"),
+        "small.DIRout.txt": ("11 35 7.878672e-01", "4 23 -2.242551e-01"),
+        "small.DIRout2.txt": ("11 35 8.057298e-01", "4 23 -2.190418e-01"),
+        "large.DIRout.txt": ("14 21 3.876863e-01", "136 232 -7.159769e-02"),
+    }
+    for name, (first, last) in kats.items():
+        lines = open(os.path.join(refdata, name)).read().split("\n")
+        lines = [ln for ln in lines if ln]
+        assert lines[0] == first and lines[-1] == last
+        d, order = parse_golden(os.path.join(refdata, name))
+        assert len(d) == len(order)
+
+
+def _random_msa(rng, M, N, q=21, gap_runs=True):
+    root = rng.integers(1, q, size=N)
+    Z = np.tile(root, (M, 1))
+    mu = rng.choice([0.02, 0.1, 0.3, 0.6], size=M)
+    mask = rng.random((M, N)) < mu[:, None]
+    Z[mask] = rng.integers(1, q, size=int(mask.sum()))
+    if gap_runs:
+        for k in range(M):
+            a = rng.integers(0, N)
+            Z[k, a:a + rng.integers(0, max(2, N // 8))] = q
+    return np.ascontiguousarray(Z.astype(np.int8))
+
+
+def test_theta_closed_form_equals_all_pairs():
+    rng = np.random.default_rng(7)
+    for (M, N) in [(2, 1), (17, 5), (120, 33), (301, 64)]:
+        Z = _random_msa(rng, M, N)
+        assert o.pair_identity_sum(Z) == o.pair_identity_sum_allpairs(Z)
+
+
+def test_c_accelerators_match_numpy_forms(monkeypatch):
+    if not o.have_c_kernels():
+        pytest.skip("oracle C kernels not built")
+    rng = np.random.default_rng(11)
+    Z = _random_msa(rng, 150, 23)
+    q = 21
+    thresh = 9
+    n_c = o.neighbour_counts(Z, thresh)
+    W, Meff = o.weights_from_counts(n_c)
+    Pi_c, Pij_c = o.compute_frequencies(Z, q, W, Meff)
+    Pi, Pij = o.add_pseudocount(Pi_c, Pij_c, 0.5, q)
+    mJ = o.spd_inverse(o.compute_C(Pi, Pij))
+    FN_c = o.compute_FN(mJ, q)
+    monkeypatch.setattr(o, "_ck", False)
+    n_np = o.neighbour_counts(Z, thresh)
+    assert np.array_equal(n_c, n_np)  # integers: bit exact
+    Pi_np, Pij_np = o.compute_frequencies(Z, q, W, Meff)
+    assert np.allclose(Pi_c, Pi_np, rtol=1e-13, atol=1e-16)
+    assert np.allclose(Pij_c, Pij_np, rtol=1e-13, atol=1e-16)
+    assert np.array_equal(Pij_c, Pij_c.T)
+    FN_np = o.compute_FN(mJ, q)
+    assert np.allclose(FN_c, FN_np, rtol=1e-12, atol=1e-14)
+
+
+def test_weights_rules():
+    rng = np.random.default_rng(3)
+    Z = _random_msa(rng, 60, 53)
+    # theta == 0 -> W = 1, Meff = M (early exit);  thresh == 0 (tiny theta) -> n_k = 1 as well
+    W, Meff, th, thresh = o.compute_weights(Z, 0.0)
+    assert Meff == 60.0 and np.all(W == 1.0) and thresh == 0
+    W, Meff, th, thresh = o.compute_weights(Z, 0.01)
+    assert thresh == 0 and Meff == 60.0
+    # duplicates are neighbours of each other for any thresh >= 1 (strict '<': d = 0 < 1)
+    Zu, _ = o.remove_duplicate_sequences(Z)
+    Mu = Zu.shape[0]
+    Z2 = np.concatenate([Zu, Zu[:5]], axis=0)
+    n = o.neighbour_counts(Z2, 1)
+    assert np.all(n[:5] == 2) and np.all(n[Mu:] == 2) and np.all(n[5:Mu] == 1)
+
+
+def test_pseudocount_and_covariance_rules():
+    rng = np.random.default_rng(5)
+    Z = _random_msa(rng, 40, 7)
+    q, s = 21, 20
+    Pi_t, Pij_t, Meff, W = o.compute_weighted_frequencies(Z, q, 0.3)
+    # diagonal blocks of Pij_true are diagonal with Pi on the diagonal (rule 5)
+    for i in range(7):
+        blk = Pij_t[i * s:(i + 1) * s, i * s:(i + 1) * s]
+        assert np.allclose(np.diag(blk), Pi_t[i * s:(i + 1) * s], rtol=1e-14, atol=0)
+        assert np.count_nonzero(blk - np.diag(np.diag(blk))) == 0
+    Pi, Pij = o.add_pseudocount(Pi_t, Pij_t, 0.8, q)
+    pcq = 0.8 / q
+    assert np.allclose(Pij[0:s, s:2 * s], 0.2 * Pij_t[0:s, s:2 * s] + pcq / q)
+    assert np.allclose(Pij[0:s, 0:s], 0.2 * Pij_t[0:s, 0:s] + pcq * np.eye(s))
+    C = o.compute_C(Pi, Pij)
+    assert np.array_equal(C, C.T)
+    assert np.all(np.linalg.eigvalsh(C) > 0)
+    with pytest.raises(o.NotPositiveDefinite):
+        Pi0, Pij0 = o.add_pseudocount(Pi_t, Pij_t, 0.0, q)
+        o.spd_inverse(o.compute_C(Pi0, Pij0))
+
+
+def test_apc_and_ranking_rules():
+    rng = np.random.default_rng(9)
+    S = rng.random((12, 12))
+    S = S + S.T
+    np.fill_diagonal(S, 0.0)
+    A = o.correct_APC(S)
+    Sa = S.sum() * (1 - 1 / 12)
+    assert np.allclose(A[3, 7], S[3, 7] - S[3].sum() * S[:, 7].sum() / Sa)
+    R = o.compute_ranking(A, 5)
+    assert len(R) == (12 - 5) * (12 - 5 + 1) // 2
+    assert all(j >= i + 5 for i, j, _ in R)
+    assert all(R[t][2] >= R[t + 1][2] for t in range(len(R) - 1))
+    assert o.format_rank([(11, 35, 3.649475)]) == "11 35 3.649475e+00\n"
+    # stable: exact ties keep generation order (i-major, j-minor)
+    T = np.zeros((8, 8))
+    assert [(i, j) for i, j, _ in o.compute_ranking(T, 5)] == [(1, 6), (1, 7), (1, 8), (2, 7), (2, 8), (3, 8)]
+
+
+def test_argument_checks(refdata, tmp_path):
+    f = os.path.join(refdata, "small.fasta.gz")
+    for kw in (dict(pseudocount=1.5), dict(theta=-0.1), dict(theta="bogus"), dict(max_gap_fraction=2),
+               dict(score="plm"), dict(min_separation=0)):
+        with pytest.raises(ValueError):
+            o.gDCA(f, **kw)
+    with pytest.raises(ValueError):
+        o.gDCA(str(tmp_path / "missing.fasta"))
