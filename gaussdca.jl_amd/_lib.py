@@ -1,0 +1,190 @@
+"""ctypes binding of libgdca.so (include/gdca.h).  There is no CPU fallback: if the shared
+library is missing or no HIP device is usable, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgdca.so")
+
+GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM = 0, 1, 2, 3, 4
+SCORE_FROB, SCORE_DI = 0, 1
+
+
+class GdcaError(RuntimeError):
+    pass
+
+
+class ArgumentError(ValueError):
+    """Mirror of Julia's ArgumentError thrown by check_arguments (src/GaussDCA.jl:49-65)."""
+
+
+class PosDefException(ArithmeticError):
+    """Mirror of LinearAlgebra.PosDefException(info) thrown by cholesky (src/GaussDCA.jl:34)."""
+
+    def __init__(self, info: int):
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info={info})")
+        self.info = int(info)
+
+
+class Params(C.Structure):
+    _fields_ = [("pseudocount", C.c_double), ("theta", C.c_double), ("score", C.c_int32), ("apc", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("theta", C.c_double), ("Meff", C.c_double), ("pair_identity_sum", C.c_uint64),
+        ("thresh", C.c_int32), ("info", C.c_int32),
+        ("N", C.c_int32), ("M", C.c_int32), ("q", C.c_int32), ("n", C.c_int32), ("n_pad", C.c_int32),
+        ("update_launches", C.c_int32),
+        ("ms_total", C.c_double), ("ms_theta", C.c_double), ("ms_weights", C.c_double),
+        ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
+        ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/gdca.h declares: name -> (restype, argtypes)
+_i8p, _i32p, _f64p, _u64p = C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+_ctx = C.c_void_p
+SYMBOLS = {
+    "gdca_version": (C.c_int32, []),
+    "gdca_device_count": (C.c_int32, []),
+    "gdca_ctx_create": (C.c_int, [C.c_int32, C.POINTER(_ctx)]),
+    "gdca_ctx_create_on_stream": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(_ctx)]),
+    "gdca_ctx_destroy": (C.c_int, [_ctx]),
+    "gdca_ctx_synchronize": (C.c_int, [_ctx]),
+    "gdca_last_error": (C.c_char_p, [_ctx]),
+    "gdca_ctx_set_timing": (C.c_int, [_ctx, C.c_int32]),
+    "gdca_run": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
+                           C.POINTER(Stats)]),
+    "gdca_run_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
+                               C.POINTER(Stats)]),
+    "gdca_pair_identity_sum": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _u64p]),
+    "gdca_compute_theta": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "gdca_neighbour_counts": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_compute_weights": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, _f64p, _f64p,
+                                       _i32p]),
+    "gdca_frequencies": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                   C.c_void_p, C.c_void_p]),
+    "gdca_add_pseudocount": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
+                                       C.c_void_p]),
+    "gdca_covariance": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gdca_spd_inverse": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _i32p]),
+    "gdca_fn": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_di": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_apc": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
+    "gdca_probe_mfma_f64": (C.c_int, [_ctx, C.c_int32, _f64p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libgdca.so and bind every declared symbol.  Raises GdcaError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdcaError(
+            f"{LIB_PATH} not found: the HIP library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _p(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One gdca_ctx = one HIP device + one stream + its workspace."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load()
+        h = _ctx()
+        if stream is None:
+            st = self.lib.gdca_ctx_create(int(device), C.byref(h))
+        else:
+            st = self.lib.gdca_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h))
+        if st != GDCA_OK:
+            raise GdcaError(f"gdca_ctx_create(device={device}) failed with status {st}: no usable HIP device "
+                            "(the gDCA hot path has no CPU fallback)")
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gdca_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st: int, info: int = 0):
+        if st == GDCA_OK:
+            return
+        msg = self.lib.gdca_last_error(self.h)
+        msg = msg.decode() if msg else ""
+        if st == GDCA_EINVAL:
+            raise ArgumentError(msg or "invalid argument")
+        if st == GDCA_ENOTPD:
+            raise PosDefException(info)
+        if st == GDCA_ENOMEM:
+            raise MemoryError(msg)
+        raise GdcaError(f"HIP error: {msg}")
+
+    def synchronize(self):
+        self.check(self.lib.gdca_ctx_synchronize(self.h))
+
+    def set_timing(self, on: bool):
+        self.check(self.lib.gdca_ctx_set_timing(self.h, 1 if on else 0))
+
+    # ---- fused path ----
+    def run(self, Zf: np.ndarray, q: int, pseudocount: float, theta: float, score: int, apc: bool = True):
+        """Zf: int8, shape (N, M), Fortran-contiguous.  Returns (S[N,N], stats dict)."""
+        N, M = Zf.shape
+        S = np.empty((N, N), dtype=np.float64)
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        st = Stats()
+        rc = self.lib.gdca_run(self.h, _p(Zf), N, M, int(q), C.byref(prm), _p(S), C.byref(st))
+        self.check(rc, st.info)
+        return S, st.as_dict()
+
+    def run_dev(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int,
+                S_ptr: int, apc: bool = True):
+        """Device-pointer form (Z and S resident in HBM).  Returns the stats dict."""
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        st = Stats()
+        rc = self.lib.gdca_run_dev(self.h, C.c_void_p(Z_ptr), N, M, int(q), C.byref(prm), C.c_void_p(S_ptr),
+                                   C.byref(st))
+        self.check(rc, st.info)
+        return st.as_dict()
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    """Process-wide context on the device named by LOCAL_RANK (one process per GPU), else 0."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("GDCA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        ndev = load().gdca_device_count()
+        if ndev <= 0:
+            raise GdcaError("no HIP device visible: the gDCA hot path has no CPU fallback")
+        _default_ctx = Context(dev % ndev)
+    return _default_ctx

@@ -1,0 +1,658 @@
+// C-ABI of libgdca.so (see include/gdca.h): context, workspace, the fused device pipeline and
+// the operator-level entry points.  Host-side orchestration only; all arithmetic is in the
+// k_*.hip kernels.  No CPU fallback exists: every entry point needs a HIP device.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gdca_internal.h"
+
+#define MAX_EV 1024
+#define N_SCRATCH 10
+
+struct gdca_buf {
+    void *p;
+    size_t cap;
+};
+
+struct gdca_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    bool timing;
+    char err[512];
+    // named device buffers (grow-only)
+    gdca_buf Zt, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Dblk, Ld, colsum, sc;
+    gdca_buf scratch[N_SCRATCH];
+    gdca_dev_scalars *sc_host;  // pinned
+    hipEvent_t ev[MAX_EV];
+    int n_ev;
+};
+
+static gdca_status fail(gdca_ctx *ctx, gdca_status st, const char *fmt, const char *a, const char *b)
+{
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), fmt, a, b);
+    return st;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail(ctx, GDCA_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define CHK(expr)                         \
+    do {                                  \
+        gdca_status s_ = (expr);          \
+        if (s_ != GDCA_OK) return s_;     \
+    } while (0)
+
+static gdca_status ensure(gdca_ctx *ctx, gdca_buf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return GDCA_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, GDCA_ENOMEM, "hipMalloc failed: %s%s", hipGetErrorString(e), "");
+    }
+    b.cap = want;
+    return GDCA_OK;
+}
+
+static gdca_status check_launch(gdca_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, GDCA_EHIP, "launch %s: %s", what, hipGetErrorString(e));
+    return GDCA_OK;
+}
+
+extern "C" {
+
+int32_t gdca_version(void)
+{
+    return GDCA_VERSION_MAJOR * 1000 + GDCA_VERSION_MINOR;
+}
+
+int32_t gdca_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_ctx **out)
+{
+    if (!out) return GDCA_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GDCA_EHIP;
+    if (device_id < 0 || device_id >= ndev) return GDCA_EINVAL;
+    gdca_ctx *ctx = (gdca_ctx *)calloc(1, sizeof(gdca_ctx));
+    if (!ctx) return GDCA_ENOMEM;
+    ctx->device = device_id;
+    ctx->timing = true;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        free(ctx);
+        return GDCA_EHIP;
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    if (hipHostMalloc((void **)&ctx->sc_host, sizeof(gdca_dev_scalars), hipHostMallocDefault) != hipSuccess) {
+        free(ctx);
+        return GDCA_ENOMEM;
+    }
+    *out = ctx;
+    return GDCA_OK;
+}
+
+gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
+{
+    gdca_status st = gdca_ctx_create_on_stream(device_id, nullptr, out);
+    if (st != GDCA_OK) return st;
+    gdca_ctx *ctx = *out;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        gdca_ctx_destroy(ctx);
+        *out = nullptr;
+        return GDCA_EHIP;
+    }
+    ctx->own_stream = true;
+    return GDCA_OK;
+}
+
+gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
+{
+    if (!ctx) return GDCA_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    gdca_buf *bufs[] = {&ctx->Zt, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
+                        &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Dblk, &ctx->Ld, &ctx->colsum, &ctx->sc};
+    for (gdca_buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < N_SCRATCH; ++i)
+        if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
+    for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->sc_host) (void)hipHostFree(ctx->sc_host);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return GDCA_OK;
+}
+
+gdca_status gdca_ctx_synchronize(gdca_ctx *ctx)
+{
+    if (!ctx) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+const char *gdca_last_error(gdca_ctx *ctx)
+{
+    return ctx ? ctx->err : "null context";
+}
+
+gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled)
+{
+    if (!ctx) return GDCA_EINVAL;
+    ctx->timing = enabled != 0;
+    return GDCA_OK;
+}
+
+}  // extern "C"
+
+static gdca_status need_events(gdca_ctx *ctx, int n)
+{
+    if (n > MAX_EV) n = MAX_EV;
+    while (ctx->n_ev < n) {
+        HIPCHK(hipEventCreate(&ctx->ev[ctx->n_ev]));
+        ++ctx->n_ev;
+    }
+    return GDCA_OK;
+}
+
+static double inverse_flops_model(double n)
+{
+    return (n * n * n / 3.0 + n * n / 2.0 + n / 6.0) + (2.0 * n * n * n / 3.0 + n * n / 2.0 + 5.0 * n / 6.0);
+}
+
+static int round_up(int x, int m)
+{
+    return (x + m - 1) / m * m;
+}
+
+// stage 1+2: theta, threshold, neighbour counts, W, Wfix, Meff  (all on device)
+static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, double theta_in, int fixed_thresh,
+                                 bool want_theta_only, hipEvent_t ev_after_theta)
+{
+    hipStream_t s = ctx->stream;
+    gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+    CHK(ensure(ctx, ctx->hist, (size_t)N * 32 * sizeof(uint32_t)));
+    if (fixed_thresh >= 0) {
+        gdca_launch_set_thresh(s, sc, fixed_thresh);
+    } else {
+        if (theta_in < 0.0) {
+            HIPCHK(hipMemsetAsync(ctx->hist.p, 0, (size_t)N * 32 * sizeof(uint32_t), s));
+            gdca_launch_column_hist(s, Zd, (uint32_t *)ctx->hist.p, N, M);
+        }
+        gdca_launch_theta_finalize(s, (const uint32_t *)ctx->hist.p, N, M, theta_in, sc);
+    }
+    CHK(check_launch(ctx, "theta"));
+    if (ev_after_theta) HIPCHK(hipEventRecord(ev_after_theta, s));
+    if (want_theta_only) return GDCA_OK;
+
+    const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE;
+    CHK(ensure(ctx, ctx->Zb, gdca_bitplane_bytes(N, M)));
+    CHK(ensure(ctx, ctx->hcnt, (size_t)Mt * GDCA_HTILE * sizeof(int32_t)));
+    CHK(ensure(ctx, ctx->nk, (size_t)M * sizeof(int32_t)));
+    CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
+    CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t), s));
+    gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M);
+    gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
+    gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
+                        (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
+    gdca_launch_meff(s, (const double *)ctx->W.p, M, sc);
+    return check_launch(ctx, "weights");
+}
+
+// stage 3: Pi, pair tallies.  mode 0 -> Pij_true (ld) ; mode 1 -> covariance (ld)
+static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, int q, const double *Meff_dev, double pc,
+                               int mode, double *Pi_true_out, double *out, size_t ld)
+{
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim;
+    const int shift = gdca_fix_shift(M);
+    CHK(ensure(ctx, ctx->Zt, (size_t)N * M));
+    CHK(ensure(ctx, ctx->Pifix, (size_t)N * 32 * sizeof(unsigned long long)));
+    CHK(ensure(ctx, ctx->Pipc, (size_t)n * sizeof(double)));
+    gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
+    HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
+    gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M);
+    gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
+                            (double *)ctx->Pipc.p);
+    gdca_launch_pair_tally(s, Zd, (const int8_t *)ctx->Zt.p, (const unsigned long long *)ctx->Wfix.p, N, M, q, shift,
+                           Meff_dev, pc, (const double *)ctx->Pipc.p, mode, out, ld);
+    return check_launch(ctx, "tally");
+}
+
+static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, int *n_upd)
+{
+    hipStream_t s = ctx->stream;
+    CHK(ensure(ctx, ctx->G, (size_t)n_pad * GDCA_TILE * sizeof(double)));
+    CHK(ensure(ctx, ctx->H, (size_t)n_pad * GDCA_TILE * sizeof(double)));
+    CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
+    gdca_inverse_ws ws;
+    ws.G = (double *)ctx->G.p;
+    ws.H = (double *)ctx->H.p;
+    ws.P = (double *)ctx->P.p;
+    const int nblk = n_pad / GDCA_TILE;
+    hipEvent_t *uev = nullptr;
+    int max_ev = 0;
+    if (timed) {
+        CHK(need_events(ctx, 16 + 2 * nblk));
+        uev = ctx->ev + 16;
+        max_ev = ctx->n_ev - 16;
+    }
+    gdca_launch_spd_inverse(s, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n, uev, max_ev, n_upd);
+    return check_launch(ctx, "spd_inverse");
+}
+
+static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int score, int apc, double *S_dev)
+{
+    hipStream_t s = ctx->stream;
+    if (score == GDCA_SCORE_DI) {
+        gdca_launch_di(s, (const double *)ctx->A.p, (size_t)n_pad, (const double *)ctx->Ld.p, N, sdim, S_dev);
+    } else {
+        gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev);
+    }
+    if (apc) {
+        CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
+        gdca_launch_apc(s, S_dev, N, (double *)ctx->colsum.p);
+    }
+    return check_launch(ctx, "score");
+}
+
+static gdca_status validate(gdca_ctx *ctx, int N, int M, int q)
+{
+    if (!ctx) return GDCA_EINVAL;
+    if (N < 1 || M < 1) return fail(ctx, GDCA_EINVAL, "invalid alignment size%s%s", "", "");
+    if (q < 2 || q > GDCA_MAXQ) return fail(ctx, GDCA_EINVAL, "parameter q is too big (max 31 is allowed)%s%s", "", "");
+    if ((long long)N * (q - 1) > 60000) return fail(ctx, GDCA_EINVAL, "N*(q-1) too large%s%s", "", "");
+    return GDCA_OK;
+}
+
+static gdca_status fetch_scalars(gdca_ctx *ctx)
+{
+    HIPCHK(hipMemcpyAsync(ctx->sc_host, ctx->sc.p, sizeof(gdca_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+static gdca_status begin(gdca_ctx *ctx)
+{
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->sc, sizeof(gdca_dev_scalars)));
+    HIPCHK(hipMemsetAsync(ctx->sc.p, 0, sizeof(gdca_dev_scalars), ctx->stream));
+    return GDCA_OK;
+}
+
+extern "C" {
+
+gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                         double *S_dev, gdca_stats *st)
+{
+    CHK(validate(ctx, N, M, q));
+    if (!Z_dev || !S_dev || !p) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
+    if (!(p->pseudocount >= 0.0 && p->pseudocount <= 1.0))
+        return fail(ctx, GDCA_EINVAL, "invalid pseudocount value (must be between 0 and 1)%s%s", "", "");
+    if (!(p->theta <= 1.0)) return fail(ctx, GDCA_EINVAL, "invalid theta value%s%s", "", "");
+    if (p->score != GDCA_SCORE_FROB && p->score != GDCA_SCORE_DI)
+        return fail(ctx, GDCA_EINVAL, "invalid score value%s%s", "", "");
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
+    const bool timed = ctx->timing;
+    if (timed) CHK(need_events(ctx, 16));
+    hipEvent_t *ev = ctx->ev;
+    gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+
+    if (timed) HIPCHK(hipEventRecord(ev[0], s));
+    CHK(weights_stage(ctx, Z_dev, N, M, p->theta, -1, false, timed ? ev[1] : nullptr));
+    if (timed) HIPCHK(hipEventRecord(ev[2], s));
+
+    CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
+    CHK(tally_stage(ctx, Z_dev, N, M, q, &sc->Meff, p->pseudocount, 1, nullptr, (double *)ctx->A.p, (size_t)n_pad));
+    gdca_launch_pad_identity(s, (double *)ctx->A.p, n, n_pad);
+    if (p->score == GDCA_SCORE_DI) {
+        CHK(ensure(ctx, ctx->Dblk, (size_t)N * sdim * sdim * sizeof(double)));
+        CHK(ensure(ctx, ctx->Ld, (size_t)N * sdim * sdim * sizeof(double)));
+        gdca_launch_save_diag_blocks(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, (double *)ctx->Dblk.p);
+        gdca_launch_diag_chol(s, (const double *)ctx->Dblk.p, N, sdim, (double *)ctx->Ld.p);
+    }
+    CHK(check_launch(ctx, "covariance"));
+    if (timed) HIPCHK(hipEventRecord(ev[3], s));
+
+    int n_upd = 0;
+    CHK(inverse_stage(ctx, n, n_pad, timed, &n_upd));
+    if (timed) HIPCHK(hipEventRecord(ev[4], s));
+
+    CHK(score_stage(ctx, N, sdim, n_pad, p->score, p->apc, S_dev));
+    if (timed) HIPCHK(hipEventRecord(ev[5], s));
+
+    CHK(fetch_scalars(ctx));
+    const gdca_dev_scalars &h = *ctx->sc_host;
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->theta = h.theta;
+        st->Meff = h.Meff;
+        st->pair_identity_sum = h.pair_sum;
+        st->thresh = h.thresh;
+        st->info = h.info;
+        st->N = N;
+        st->M = M;
+        st->q = q;
+        st->n = n;
+        st->n_pad = n_pad;
+        st->update_launches = n_upd;
+        st->inverse_flops = inverse_flops_model((double)n);
+        const int m = n_pad / GDCA_TILE - 1;
+        st->update_flops = (double)n_upd * ((double)m * (m + 1) / 2.0) * 2.0 * GDCA_TILE * GDCA_TILE * GDCA_TILE;
+        if (timed) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
+            st->ms_total = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            st->ms_theta = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
+            st->ms_weights = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3]));
+            st->ms_covariance = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[3], ev[4]));
+            st->ms_inverse = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+            st->ms_score = ms;
+            double upd = 0.0;
+            for (int k = 0; k < n_upd && 16 + 2 * k + 1 < ctx->n_ev; ++k) {
+                HIPCHK(hipEventElapsedTime(&ms, ev[16 + 2 * k], ev[16 + 2 * k + 1]));
+                upd += ms;
+            }
+            st->ms_inverse_update = upd;
+        }
+    }
+    if (h.info != 0) return fail(ctx, GDCA_ENOTPD, "covariance matrix is not positive definite%s%s", "", "");
+    return GDCA_OK;
+}
+
+gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                     double *S_host, gdca_stats *st)
+{
+    CHK(validate(ctx, N, M, q));
+    if (!Z_host || !S_host) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->scratch[0], (size_t)N * M));
+    CHK(ensure(ctx, ctx->scratch[1], (size_t)N * N * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z_host, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
+    gdca_status rs = gdca_run_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, q, p, (double *)ctx->scratch[1].p, st);
+    if (rs != GDCA_OK) return rs;
+    HIPCHK(hipMemcpyAsync(S_host, ctx->scratch[1].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+// ---- operator level ---------------------------------------------------------------------------------
+
+static gdca_status upload_Z(gdca_ctx *ctx, const int8_t *Z, int N, int M, const int8_t **Zd)
+{
+    CHK(ensure(ctx, ctx->scratch[0], (size_t)N * M));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
+    *Zd = (const int8_t *)ctx->scratch[0].p;
+    return GDCA_OK;
+}
+
+gdca_status gdca_pair_identity_sum(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, uint64_t *out)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !out) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    const int8_t *Zd;
+    CHK(upload_Z(ctx, Z, N, M, &Zd));
+    CHK(weights_stage(ctx, Zd, N, M, -1.0, -1, true, nullptr));
+    CHK(fetch_scalars(ctx));
+    *out = ctx->sc_host->pair_sum;
+    return GDCA_OK;
+}
+
+gdca_status gdca_compute_theta(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double *theta)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !theta) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    const int8_t *Zd;
+    CHK(upload_Z(ctx, Z, N, M, &Zd));
+    CHK(weights_stage(ctx, Zd, N, M, -1.0, -1, true, nullptr));
+    CHK(fetch_scalars(ctx));
+    *theta = ctx->sc_host->theta;
+    return GDCA_OK;
+}
+
+gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t thresh,
+                                  int32_t *n_out)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !n_out || thresh < 0) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    const int8_t *Zd;
+    CHK(upload_Z(ctx, Z, N, M, &Zd));
+    CHK(weights_stage(ctx, Zd, N, M, 0.0, thresh, false, nullptr));
+    HIPCHK(hipMemcpyAsync(n_out, ctx->nk.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta, double *W,
+                                 double *Meff, double *theta_used, int32_t *thresh)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !W || !Meff || !(theta <= 1.0)) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    const int8_t *Zd;
+    CHK(upload_Z(ctx, Z, N, M, &Zd));
+    CHK(weights_stage(ctx, Zd, N, M, theta, -1, false, nullptr));
+    HIPCHK(hipMemcpyAsync(W, ctx->W.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(fetch_scalars(ctx));
+    *Meff = ctx->sc_host->Meff;
+    if (theta_used) *theta_used = ctx->sc_host->theta;
+    if (thresh) *thresh = ctx->sc_host->thresh;
+    return GDCA_OK;
+}
+
+gdca_status gdca_frequencies(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const double *W,
+                             double Meff, double *Pi, double *Pij)
+{
+    CHK(validate(ctx, N, M, q));
+    if (!Z || !W || !Pi || !Pij || !(Meff > 0.0)) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim;
+    const int8_t *Zd;
+    CHK(upload_Z(ctx, Z, N, M, &Zd));
+    CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
+    CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
+    CHK(ensure(ctx, ctx->scratch[1], (size_t)n * n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[3], sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->W.p, W, (size_t)M * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, &Meff, sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_fix_weights(s, (const double *)ctx->W.p, M, gdca_fix_shift(M), (unsigned long long *)ctx->Wfix.p);
+    CHK(tally_stage(ctx, Zd, N, M, q, (const double *)ctx->scratch[3].p, 0.0, 0, (double *)ctx->scratch[2].p,
+                    (double *)ctx->scratch[1].p, (size_t)n));
+    HIPCHK(hipMemcpyAsync(Pi, ctx->scratch[2].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Pij, ctx->scratch[1].p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_add_pseudocount(gdca_ctx *ctx, const double *Pi_true, const double *Pij_true, int32_t N, int32_t q,
+                                 double pc, double *Pi, double *Pij)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!Pi_true || !Pij_true || !Pi || !Pij || !(pc >= 0.0 && pc <= 1.0)) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const size_t n = (size_t)N * (q - 1);
+    CHK(ensure(ctx, ctx->scratch[1], n * n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[2], n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[4], n * n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[5], n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, Pij_true, n * n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, Pi_true, n * sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_add_pseudocount(s, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, N, q, pc,
+                                (double *)ctx->scratch[5].p, (double *)ctx->scratch[4].p);
+    CHK(check_launch(ctx, "add_pseudocount"));
+    HIPCHK(hipMemcpyAsync(Pi, ctx->scratch[5].p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(Pij, ctx->scratch[4].p, n * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, int32_t n, double *C)
+{
+    if (!ctx || !Pi || !Pij || !C || n < 1 || n > 60000) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const size_t nn = (size_t)n;
+    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[2], nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[4], nn * nn * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, Pij, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, Pi, nn * sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_covariance(s, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, n,
+                           (double *)ctx->scratch[4].p);
+    CHK(check_launch(ctx, "covariance"));
+    HIPCHK(hipMemcpyAsync(C, ctx->scratch[4].p, nn * nn * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
+{
+    if (!ctx || !A || n < 1 || n > 60000) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int n_pad = round_up(n, GDCA_TILE);
+    const size_t nn = (size_t)n;
+    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, A, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_copy_in(s, (const double *)ctx->scratch[1].p, n, (double *)ctx->A.p, n_pad);
+    int n_upd = 0;
+    CHK(inverse_stage(ctx, n, n_pad, false, &n_upd));
+    gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, (double *)ctx->scratch[1].p, n);
+    CHK(check_launch(ctx, "copy_out"));
+    HIPCHK(hipMemcpyAsync(A, ctx->scratch[1].p, nn * nn * sizeof(double), hipMemcpyDeviceToHost, s));
+    CHK(fetch_scalars(ctx));
+    if (info) *info = ctx->sc_host->info;
+    if (ctx->sc_host->info != 0)
+        return fail(ctx, GDCA_ENOTPD, "matrix is not positive definite; Cholesky factorization failed%s%s", "", "");
+    return GDCA_OK;
+}
+
+// mJ (host, n x n full) -> ctx->A as "-mJ" with ld = n_pad (lower triangle is what the score kernels read)
+static gdca_status upload_neg_mJ(gdca_ctx *ctx, const double *mJ, int n, int n_pad)
+{
+    hipStream_t s = ctx->stream;
+    const size_t nn = (size_t)n;
+    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[4], nn * nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, mJ, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
+    // negate via the symmetric copy-out helper (ld n -> n), then pad
+    gdca_launch_copy_out_neg_sym(s, (const double *)ctx->scratch[1].p, n, (double *)ctx->scratch[4].p, n);
+    gdca_launch_copy_in(s, (const double *)ctx->scratch[4].p, n, (double *)ctx->A.p, n_pad);
+    return check_launch(ctx, "upload_mJ");
+}
+
+gdca_status gdca_fn(gdca_ctx *ctx, const double *mJ, int32_t N, int32_t q, double *S)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!mJ || !S) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
+    CHK(upload_neg_mJ(ctx, mJ, n, n_pad));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
+    CHK(score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_FROB, 0, (double *)ctx->scratch[2].p));
+    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_di(gdca_ctx *ctx, const double *mJ, const double *C, int32_t N, int32_t q, double *S)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!mJ || !C || !S) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
+    const size_t nn = (size_t)n;
+    // diagonal blocks of C -> Cholesky factors
+    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
+    CHK(ensure(ctx, ctx->Dblk, (size_t)N * sdim * sdim * sizeof(double)));
+    CHK(ensure(ctx, ctx->Ld, (size_t)N * sdim * sdim * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, C, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_save_diag_blocks(s, (const double *)ctx->scratch[1].p, nn, N, sdim, (double *)ctx->Dblk.p);
+    gdca_launch_diag_chol(s, (const double *)ctx->Dblk.p, N, sdim, (double *)ctx->Ld.p);
+    CHK(upload_neg_mJ(ctx, mJ, n, n_pad));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
+    CHK(score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_DI, 0, (double *)ctx->scratch[2].p));
+    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_apc(gdca_ctx *ctx, double *S, int32_t N)
+{
+    if (!ctx || !S || N < 1) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
+    CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, S, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
+    gdca_launch_apc(s, (double *)ctx->scratch[2].p, N, (double *)ctx->colsum.p);
+    CHK(check_launch(ctx, "apc"));
+    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops)
+{
+    if (!ctx || !tflops || iters < 1) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int blocks = 256 * 4;  // 4 waves per SIMD
+    CHK(ensure(ctx, ctx->scratch[6], (size_t)blocks * 256 * sizeof(double)));
+    CHK(need_events(ctx, 2));
+    gdca_launch_probe_mfma_f64(s, (double *)ctx->scratch[6].p, 16, blocks);  // warm-up
+    HIPCHK(hipEventRecord(ctx->ev[0], s));
+    gdca_launch_probe_mfma_f64(s, (double *)ctx->scratch[6].p, iters, blocks);
+    HIPCHK(hipEventRecord(ctx->ev[1], s));
+    CHK(check_launch(ctx, "probe"));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    *tflops = flops / ((double)ms * 1e-3) / 1e12;
+    return GDCA_OK;
+}
+
+}  // extern "C"

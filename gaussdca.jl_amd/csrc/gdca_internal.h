@@ -1,0 +1,94 @@
+// Internal declarations shared by the HIP translation units of libgdca.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gdca.h"
+
+#define GDCA_TILE 128     // tile edge of the SPD-inverse kernels (f64 elements)
+#define GDCA_HTILE 128    // sequences per side of a Hamming tile
+#define GDCA_MAXQ 31
+
+// Scalars that live in HBM so the whole pipeline can be enqueued without a host round trip.
+struct gdca_dev_scalars {
+    double theta;
+    double Meff;
+    unsigned long long pair_sum;
+    int thresh;
+    int info;
+};
+
+// ---- k_theta.hip -------------------------------------------------------------------------
+void gdca_launch_transpose_i8(hipStream_t s, const int8_t *Z, int8_t *Zt, int N, int M);
+// cnt: uint32 [N][32], zeroed by the caller
+void gdca_launch_column_hist(hipStream_t s, const int8_t *Z, uint32_t *cnt, int N, int M);
+// theta_in < 0: theta = :auto from cnt; else theta = theta_in.  Writes theta, thresh, pair_sum.
+void gdca_launch_theta_finalize(hipStream_t s, const uint32_t *cnt, int N, int M, double theta_in,
+                                gdca_dev_scalars *sc);
+// sets sc->thresh directly (operator-level neighbour counts with a caller-given threshold)
+void gdca_launch_set_thresh(hipStream_t s, gdca_dev_scalars *sc, int thresh);
+
+// ---- k_hamming.hip -----------------------------------------------------------------------
+// bit-plane image: uint32 [Mt][5][NW][128], Mt = ceil(M/128), NW = ceil(N/32)
+size_t gdca_bitplane_bytes(int N, int M);
+void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M);
+// cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
+                         const gdca_dev_scalars *sc);
+// n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)
+void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W,
+                         unsigned long long *Wfix);
+// Meff = W[0] + W[1] + ... strictly left to right (one wave)
+void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc);
+// Wfix from caller-given W (operator-level gdca_frequencies)
+void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix);
+int gdca_fix_shift(int M);
+
+// ---- k_tally.hip -------------------------------------------------------------------------
+// Pifix: u64 [N][32] zeroed by the caller; adds sum_k Wfix[k] [Z[i,k]==a] at [i][a-1]
+void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const unsigned long long *Wfix,
+                          unsigned long long *Pifix, int N, int M);
+// Pi_true[i*s+a] = Pifix * 2^-shift / Meff;  Pi_pc = (1-pc) Pi_true + pc/q
+void gdca_launch_pi_finalize(hipStream_t s, const unsigned long long *Pifix, int N, int q, int fix_shift,
+                             const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc);
+// Pair tallies.  mode 0: out = Pij_true (full symmetric, ld);  mode 1: out = C =
+// add_pseudocount + compute_C fused (full symmetric, ld).  Pi_pc used by mode 1 only.
+void gdca_launch_pair_tally(hipStream_t s, const int8_t *Z, const int8_t *Zt, const unsigned long long *Wfix,
+                            int N, int M, int q, int fix_shift, const double *Meff_dev, double pc,
+                            const double *Pi_pc, int mode, double *out, size_t ld);
+
+// ---- k_elementwise.hip ---------------------------------------------------------------------
+void gdca_launch_add_pseudocount(hipStream_t s, const double *Pi_true, const double *Pij_true, int N, int q,
+                                 double pc, double *Pi, double *Pij);
+void gdca_launch_covariance(hipStream_t s, const double *Pi, const double *Pij, int n, double *C);
+// A[n_pad x n_pad] (ld = n_pad): rows/cols >= n become identity
+void gdca_launch_pad_identity(hipStream_t s, double *A, int n, int n_pad);
+// copy a dense n x n (ld_src) into the padded buffer (ld_dst) / back, with optional negate+mirror
+void gdca_launch_copy_in(hipStream_t s, const double *src, int n, double *dst, int n_pad);
+// dst (n x n, ld n) = full symmetric  -lower(A)  (A holds -inverse in its lower triangle)
+void gdca_launch_copy_out_neg_sym(hipStream_t s, const double *A, int n_pad, double *dst, int n);
+// D[i] (s x s, packed) = diagonal block i of C (ld)
+void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int N, int sdim, double *D);
+
+// ---- k_inverse.hip -------------------------------------------------------------------------
+struct gdca_inverse_ws {
+    double *G;   // n_pad x 128 panel (column k of the swept matrix)
+    double *H;   // n_pad x 128 panel, -G * P
+    double *P;   // 128 x 128 inverse of the pivot block
+};
+// In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles
+// authoritative): A <- -inverse(A) by the block symmetric sweep.  info (device) gets the
+// 1-based index of the first non-positive pivot, if any.
+void gdca_launch_spd_inverse(hipStream_t s, double *A, int n_pad, const gdca_inverse_ws &ws,
+                             gdca_dev_scalars *sc, int n_real, hipEvent_t *upd_ev, int max_ev,
+                             int *n_upd_launch);
+void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
+
+// ---- k_score.hip ---------------------------------------------------------------------------
+// S (N x N) from the lower triangle of A = -mJ (ld).  Diagonal 0.
+void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S);
+// Ld[i] = chol(D[i]) lower, packed s x s
+void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, double *Ld);
+void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S);
+void gdca_launch_apc(hipStream_t s, double *S, int N, double *rowsum_ws);

@@ -1,0 +1,131 @@
+// HBM-bound elementwise kernels: the operator-level add_pseudocount (DCAUtils; reference call
+// site src/GaussDCA.jl:30) and compute_C (src/GaussDCA.jl:76), plus layout helpers around the
+// SPD inverse.  One pass each, 8-byte accesses contiguous along columns (column-major).
+// In the fused pipeline add_pseudocount and compute_C never run as kernels of their own: the
+// pair-tally epilogue (k_tally.hip) applies both while writing C.
+#include "gdca_internal.h"
+
+// Pij' = (1-pc) Pij + pc/q^2 off the diagonal blocks; diagonal blocks (1-pc) Pij + (pc/q) I
+__global__ __launch_bounds__(256) void k_add_pseudocount(const double *__restrict__ Pi_true,
+                                                          const double *__restrict__ Pij_true, int n, int sdim, int q,
+                                                          double pc, double *__restrict__ Pi, double *__restrict__ Pij)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n) return;
+    const double pcq = pc / (double)q;
+    const size_t e = (size_t)r + (size_t)c * n;
+    const double x = (1.0 - pc) * Pij_true[e];
+    double v;
+    if (r / sdim == c / sdim)
+        v = (r == c) ? (x + pcq) : x;
+    else
+        v = x + pcq / (double)q;
+    Pij[e] = v;
+    if (c == 0) Pi[r] = (1.0 - pc) * Pi_true[r] + pcq;
+}
+
+void gdca_launch_add_pseudocount(hipStream_t s, const double *Pi_true, const double *Pij_true, int N, int q, double pc,
+                                 double *Pi, double *Pij)
+{
+    const int sdim = q - 1, n = N * sdim;
+    hipLaunchKernelGGL(k_add_pseudocount, dim3((n + 255) / 256, n), dim3(256), 0, s, Pi_true, Pij_true, n, sdim, q, pc,
+                       Pi, Pij);
+}
+
+__global__ __launch_bounds__(256) void k_covariance(const double *__restrict__ Pi, const double *__restrict__ Pij,
+                                                     int n, double *__restrict__ C)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n) return;
+    const size_t e = (size_t)r + (size_t)c * n;
+    C[e] = Pij[e] - Pi[r] * Pi[c];
+}
+
+void gdca_launch_covariance(hipStream_t s, const double *Pi, const double *Pij, int n, double *C)
+{
+    hipLaunchKernelGGL(k_covariance, dim3((n + 255) / 256, n), dim3(256), 0, s, Pi, Pij, n, C);
+}
+
+// rows / columns >= n of the padded matrix become identity (SPD, decoupled from the real block)
+__global__ __launch_bounds__(256) void k_pad_identity(double *__restrict__ A, int n, int n_pad)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n_pad) return;
+    if (r < n && c < n) return;
+    A[(size_t)r + (size_t)c * n_pad] = (r == c) ? 1.0 : 0.0;
+}
+
+void gdca_launch_pad_identity(hipStream_t s, double *A, int n, int n_pad)
+{
+    if (n_pad == n) return;
+    hipLaunchKernelGGL(k_pad_identity, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, A, n, n_pad);
+}
+
+__global__ __launch_bounds__(256) void k_copy_in(const double *__restrict__ src, int n, double *__restrict__ dst,
+                                                  int n_pad)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (r >= n_pad) return;
+    double v;
+    if (r < n && c < n)
+        v = src[(size_t)r + (size_t)c * n];
+    else
+        v = (r == c) ? 1.0 : 0.0;
+    dst[(size_t)r + (size_t)c * n_pad] = v;
+}
+
+void gdca_launch_copy_in(hipStream_t s, const double *src, int n, double *dst, int n_pad)
+{
+    hipLaunchKernelGGL(k_copy_in, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, src, n, dst, n_pad);
+}
+
+// dst[r][c] = dst[c][r] = -A[max(r,c)][min(r,c)]  through a 32 x 32 LDS tile so that both the
+// read of the lower triangle and the two writes stay contiguous along columns
+__global__ __launch_bounds__(256) void k_copy_out_neg_sym(const double *__restrict__ A, int n_pad,
+                                                           double *__restrict__ dst, int n)
+{
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;  // tile (bi, bj) of the lower triangle: bi >= bj
+    if (bi < bj) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int r = bi * 32 + tx, c = bj * 32 + cc;
+        double v = 0.0;
+        if (r < n && c < n) {
+            v = -A[(size_t)r + (size_t)c * n_pad];
+            if (r >= c) dst[(size_t)r + (size_t)c * n] = v;
+        }
+        tile[cc][tx] = v;
+    }
+    __syncthreads();
+    // mirror: element (c, r) of dst for r > c, written contiguous along c
+    for (int rr = ty; rr < 32; rr += 8) {
+        const int c = bj * 32 + tx, r = bi * 32 + rr;
+        if (r < n && c < n && r > c) dst[(size_t)c + (size_t)r * n] = tile[tx][rr];
+    }
+}
+
+void gdca_launch_copy_out_neg_sym(hipStream_t s, const double *A, int n_pad, double *dst, int n)
+{
+    const int nt = (n + 31) / 32;
+    hipLaunchKernelGGL(k_copy_out_neg_sym, dim3(nt, nt), dim3(256), 0, s, A, n_pad, dst, n);
+}
+
+__global__ __launch_bounds__(256) void k_save_diag_blocks(const double *__restrict__ C, size_t ld, int N, int sdim,
+                                                           double *__restrict__ D)
+{
+    const int i = blockIdx.x;
+    for (int e = threadIdx.x; e < sdim * sdim; e += 256) {
+        const int r = e % sdim, c = e / sdim;
+        D[(size_t)i * sdim * sdim + e] = C[(size_t)(i * sdim + r) + (size_t)(i * sdim + c) * ld];
+    }
+}
+
+void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int N, int sdim, double *D)
+{
+    hipLaunchKernelGGL(k_save_diag_blocks, dim3(N), dim3(256), 0, s, C, ld, N, sdim, D);
+}

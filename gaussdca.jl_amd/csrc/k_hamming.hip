@@ -1,0 +1,258 @@
+// All-pairs Hamming reweighting  (DCAUtils compute_weights; reference call site
+// src/GaussDCA.jl:28):  n_k = 1 + #{l != k : Hamming(Z[:,k], Z[:,l]) < floor(theta N)},
+// W_k = 1/n_k, Meff = sum_k W_k.
+//
+// MI355X design.  The reference packs 5-bit symbols into UInt64 words and XOR/popcounts them.
+// Here the alignment is BIT-SLICED instead: for every sequence, plane p (p = 0..4) holds bit p
+// of 32 consecutive positions in one dword.  Two sequences differ at a position iff any plane
+// differs, so 32 symbol compares cost  5 x (xor|or as one v_bitop3) + 1 x v_bcnt(+acc)  = 6
+// VALU ops -- 0.19 op per compare against >= 0.75 for byte-wise compares.  Everything is
+// integer and exact; the result does not depend on any summation order.
+//
+// Tiling: a workgroup owns a 128 x 128 block of sequence pairs (upper-triangular tile
+// schedule, symmetric pairs visited once), stages both sides' planes through LDS in chunks
+// of 8 dwords (256 positions) with 16-byte coalesced loads, and every thread keeps an 8 x 8
+// pair micro-tile of distances in registers.  Neighbour counts leave the workgroup as one
+// integer atomic per sequence and tile (wave-contiguous addresses).
+//
+// Not HBM-bound: the bit-plane image (N*M*5/8 bytes, 16 MB at N=500, M=50k) stays in L2 /
+// Infinity Cache and every tile is re-read M/128 times; the bound is VALU issue.
+#include "gdca_internal.h"
+
+#define NPLANES 5
+#define WCHUNK 8
+
+size_t gdca_bitplane_bytes(int N, int M)
+{
+    const size_t Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
+    return Mt * NPLANES * NW * GDCA_HTILE * sizeof(uint32_t);
+}
+
+// ---- Z [M][N] bytes -> bit planes [Mt][5][NW][128] -------------------------------------------
+// thread <-> sequence, blockIdx.y <-> dword of 32 positions: 128 contiguous dwords per store.
+__global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict__ Z, uint32_t *__restrict__ Zb,
+                                                        int N, int M, int NW)
+{
+    const int tile = blockIdx.x, w = blockIdx.y, kl = threadIdx.x;
+    const int k = tile * GDCA_HTILE + kl;
+    uint32_t pl[NPLANES];
+#pragma unroll
+    for (int p = 0; p < NPLANES; ++p) pl[p] = 0;
+    if (k < M) {
+        const int8_t *src = Z + (size_t)k * N + (size_t)w * 32;
+        const int nb = min(32, N - w * 32);
+        for (int b = 0; b < nb; ++b) {
+            const uint32_t z = (uint32_t)src[b] & 31u;
+#pragma unroll
+            for (int p = 0; p < NPLANES; ++p) pl[p] |= ((z >> p) & 1u) << b;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NPLANES; ++p)
+        Zb[(((size_t)tile * NPLANES + p) * NW + w) * GDCA_HTILE + kl] = pl[p];
+}
+
+void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M)
+{
+    const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
+    hipLaunchKernelGGL(k_bitplane_pack, dim3(Mt, NW), dim3(128), 0, s, Z, Zb, N, M, NW);
+}
+
+// ---- all-pairs distances, thresholded neighbour counts ----------------------------------------
+__device__ __forceinline__ void tri_decode(int t, int Mt, int &I, int &J)
+{
+    // t in [0, Mt(Mt+1)/2) -> (I, J), I <= J, row-major over the upper triangle
+    const double b = 2.0 * Mt + 1.0;
+    int i = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > Mt - 1) i = Mt - 1;
+    auto start = [Mt](int r) { return (long long)r * Mt - (long long)r * (r - 1) / 2; };
+    while (i > 0 && start(i) > t) --i;
+    while (i < Mt - 1 && start(i + 1) <= t) ++i;
+    I = i;
+    J = i + (int)(t - start(i));
+}
+
+__global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
+                                                  int NW, int M, int Mt, const gdca_dev_scalars *__restrict__ sc)
+{
+    const int thresh = sc->thresh;
+    if (thresh <= 0) return;  // theta == 0 (or floor(theta N) == 0): every n_k = 1
+
+    __shared__ __attribute__((aligned(16))) uint32_t As[NPLANES][WCHUNK][GDCA_HTILE];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[NPLANES][WCHUNK][GDCA_HTILE];
+    __shared__ int rc[GDCA_HTILE], cc[GDCA_HTILE];
+
+    int I, J;
+    tri_decode(blockIdx.x, Mt, I, J);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    if (tid < GDCA_HTILE) {
+        rc[tid] = 0;
+        cc[tid] = 0;
+    }
+
+    uint32_t acc[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+
+    const uint32_t *Ag = Zb + (size_t)I * NPLANES * NW * GDCA_HTILE;
+    const uint32_t *Bg = Zb + (size_t)J * NPLANES * NW * GDCA_HTILE;
+
+    for (int w0 = 0; w0 < NW; w0 += WCHUNK) {
+        __syncthreads();
+        // stage: per plane a contiguous run of WCHUNK*128 dwords = 4 KB = 256 threads x 16 B
+#pragma unroll
+        for (int p = 0; p < NPLANES; ++p) {
+            const int wl = tid >> 5;  // dword row inside the chunk (32 threads x 16 B = 128 dwords)
+            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+            if (w0 + wl < NW) {
+                const size_t off = ((size_t)p * NW + w0 + wl) * GDCA_HTILE + (size_t)(tid & 31) * 4;
+                va = *reinterpret_cast<const uint4 *>(Ag + off);
+                vb = *reinterpret_cast<const uint4 *>(Bg + off);
+            }
+            *reinterpret_cast<uint4 *>(&As[p][wl][(tid & 31) * 4]) = va;
+            *reinterpret_cast<uint4 *>(&Bs[p][wl][(tid & 31) * 4]) = vb;
+        }
+        __syncthreads();
+        const int wn = min(WCHUNK, NW - w0);
+        for (int w = 0; w < wn; ++w) {
+            uint32_t a[NPLANES][8], b[NPLANES][8];
+#pragma unroll
+            for (int p = 0; p < NPLANES; ++p) {
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(&As[p][w][ty * 8]);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(&As[p][w][ty * 8 + 4]);
+                const uint4 b0 = *reinterpret_cast<const uint4 *>(&Bs[p][w][tx * 4]);
+                const uint4 b1 = *reinterpret_cast<const uint4 *>(&Bs[p][w][64 + tx * 4]);
+                a[p][0] = a0.x; a[p][1] = a0.y; a[p][2] = a0.z; a[p][3] = a0.w;
+                a[p][4] = a1.x; a[p][5] = a1.y; a[p][6] = a1.z; a[p][7] = a1.w;
+                b[p][0] = b0.x; b[p][1] = b0.y; b[p][2] = b0.z; b[p][3] = b0.w;
+                b[p][4] = b1.x; b[p][5] = b1.y; b[p][6] = b1.z; b[p][7] = b1.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t x = a[0][r] ^ b[0][c];
+#pragma unroll
+                    for (int p = 1; p < NPLANES; ++p)  // x |= a ^ b as one v_bitop3_b32 (table 0xBE)
+                        x = __builtin_amdgcn_bitop3_b32(a[p][r], b[p][c], x, 0xBE);
+                    acc[r][c] += __builtin_popcount(x);
+                }
+        }
+    }
+
+    // threshold, count (strict '<'), reduce over the workgroup
+    int rowc[8], colc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rowc[r] = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) colc[c] = 0;
+    const bool diag = (I == J);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int gr = I * GDCA_HTILE + ty * 8 + r;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+            const int gc = J * GDCA_HTILE + lc;
+            const bool ok = (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh);
+            rowc[r] += ok ? 1 : 0;
+            colc[c] += ok ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (rowc[r]) atomicAdd(&rc[ty * 8 + r], rowc[r]);
+    if (!diag) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+            if (colc[c]) atomicAdd(&cc[lc], colc[c]);
+        }
+    }
+    __syncthreads();
+    if (tid < GDCA_HTILE) {
+        const int v = rc[tid];
+        if (v) atomicAdd(&cnt[I * GDCA_HTILE + tid], v);
+    } else if (!diag) {
+        const int v = cc[tid - GDCA_HTILE];
+        if (v) atomicAdd(&cnt[J * GDCA_HTILE + tid - GDCA_HTILE], v);
+    }
+}
+
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
+                         const gdca_dev_scalars *sc)
+{
+    const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
+    const long long ntile = (long long)Mt * (Mt + 1) / 2;
+    hipLaunchKernelGGL(k_hamming, dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+}
+
+// ---- weights ------------------------------------------------------------------------------------
+int gdca_fix_shift(int M)
+{
+    // fixed-point scale 2^shift for the weighted tallies: M * 2^shift <= 2^63
+    int lg = 0;
+    while ((1ll << lg) < (long long)M) ++lg;
+    return 63 - lg;
+}
+
+__global__ __launch_bounds__(256) void k_weights(const int32_t *__restrict__ cnt, int M, int fix_shift,
+                                                  int32_t *__restrict__ n_out, double *__restrict__ W,
+                                                  unsigned long long *__restrict__ Wfix)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= M) return;
+    const int n = 1 + cnt[k];
+    if (n_out) n_out[k] = n;
+    const double w = 1.0 / (double)n;  // IEEE division, correctly rounded
+    W[k] = w;
+    if (Wfix) Wfix[k] = (unsigned long long)rint(ldexp(w, fix_shift));
+}
+
+void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W,
+                         unsigned long long *Wfix)
+{
+    hipLaunchKernelGGL(k_weights, dim3((M + 255) / 256), dim3(256), 0, s, cnt, M, fix_shift, n_out, W, Wfix);
+}
+
+__global__ __launch_bounds__(256) void k_fix_weights(const double *__restrict__ W, int M, int fix_shift,
+                                                      unsigned long long *__restrict__ Wfix)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < M) Wfix[k] = (unsigned long long)rint(ldexp(W[k], fix_shift));
+}
+
+void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix)
+{
+    hipLaunchKernelGGL(k_fix_weights, dim3((M + 255) / 256), dim3(256), 0, s, W, M, fix_shift, Wfix);
+}
+
+// Meff = ((W[0] + W[1]) + W[2]) + ...  -- the strictly sequential f64 sum the oracle uses, so the
+// value is bit-identical to it.  One wave: 64 coalesced loads, then 64 dependent adds fed by
+// v_readlane.  O(M) dependent adds (~0.2 ms at M = 50k); nothing else in the pipeline waits on
+// a shorter chain.
+__global__ __launch_bounds__(64) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
+{
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int base = 0; base < M; base += 64) {
+        const int k = base + lane;
+        const double w = (k < M) ? W[k] : 0.0;
+        const int cntv = min(64, M - base);
+        if (cntv == 64) {
+#pragma unroll
+            for (int t = 0; t < 64; ++t) acc += __shfl(w, t, 64);
+        } else {
+            for (int t = 0; t < cntv; ++t) acc += __shfl(w, t, 64);
+        }
+    }
+    if (lane == 0) sc->Meff = acc;
+}
+
+void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc)
+{
+    hipLaunchKernelGGL(k_meff, dim3(1), dim3(64), 0, s, W, M, sc);
+}

@@ -1,0 +1,148 @@
+/* gdca.h -- C-ABI of libgdca.so: the MI355X (gfx950) Gaussian-DCA hot path.
+ *
+ * This is the drop-in boundary for the one path of carlobaldassi/GaussDCA.jl that this
+ * project accelerates: everything between src/GaussDCA.jl:28 and :42 of the reference
+ *
+ *     Pi_true, Pij_true, Meff, _ = compute_weighted_frequencies(Z, q, theta)   (:28)
+ *     Pi, Pij = add_pseudocount(Pi_true, Pij_true, Float64(pseudocount), q)     (:30)
+ *     C  = compute_C(Pi, Pij)                                                   (:32, :76)
+ *     mJ = inv(cholesky(C))                                                     (:34)
+ *     S  = score == :DI ? compute_DI_gauss(mJ, C, q) : compute_FN(mJ, q)        (:36-40)
+ *     S  = correct_APC(S)                                                       (:42, :78-86)
+ *
+ * The reference is Julia; it would bind these entry points with `ccall((:sym, libgdca), ...)`
+ * (the stub a maintainer would add is in INTEGRATION.md).  Plain pointers and sizes only: no
+ * C++ types, no exceptions, no Julia/Python/torch types cross this ABI.
+ *
+ * Conventions
+ *   - Matrices are COLUMN-MAJOR (Julia native), so Julia arrays are passed without copies.
+ *   - Z is the reference's `Z::Matrix{Int8}`, N x M column-major: sequence k is the N
+ *     contiguous bytes Z[k*N .. k*N+N-1], symbols 1..q, q <= 31 (src/GaussDCA.jl:24-26).
+ *   - s = q - 1 (state q, the gap, has no row/column); n = N * s.
+ *   - "host" pointers are ordinary host memory owned by the caller; "_dev" entry points take
+ *     device (HBM) pointers owned by the caller.  The library never returns memory it
+ *     allocated except the opaque gdca_ctx.
+ *   - Every function returns a gdca_status; it never aborts and never throws.
+ *   - A gdca_ctx owns one HIP device, one stream and a grow-only device workspace.  A ctx is
+ *     used by one host thread at a time; different ctxs are independent (this is the
+ *     multi-GPU model: one ctx per GPU, no collectives).
+ *   - There is NO CPU fallback: without a usable HIP device gdca_ctx_create fails with
+ *     GDCA_EHIP and nothing else can be called.
+ */
+#ifndef GDCA_H
+#define GDCA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDCA_VERSION_MAJOR 0
+#define GDCA_VERSION_MINOR 1
+
+typedef enum gdca_status {
+    GDCA_OK = 0,
+    GDCA_EINVAL = 1, /* bad argument: mirrors ArgumentError (src/GaussDCA.jl:50-62) and q >= 32 (:26) */
+    GDCA_ENOTPD = 2, /* covariance not positive definite: mirrors PosDefException(info) from :34 */
+    GDCA_EHIP = 3,   /* HIP runtime error; see gdca_last_error() */
+    GDCA_ENOMEM = 4  /* device or host allocation failed */
+} gdca_status;
+
+enum { GDCA_SCORE_FROB = 0, GDCA_SCORE_DI = 1 }; /* score = :frob | :DI (src/GaussDCA.jl:14) */
+
+typedef struct gdca_ctx gdca_ctx;
+
+/* Keyword arguments of gDCA() that reach the hot path (src/GaussDCA.jl:10-15). */
+typedef struct gdca_params {
+    double pseudocount; /* 0 <= pc <= 1            (default 0.8, :11)                       */
+    double theta;       /* 0 <= theta <= 1, or any negative value for theta = :auto (:12)   */
+    int32_t score;      /* GDCA_SCORE_FROB | GDCA_SCORE_DI (:14)                            */
+    int32_t apc;        /* 1: apply correct_APC (what gDCA does, :42); 0: raw scores        */
+} gdca_params;
+
+/* What DCAUtils prints (theta, threshold, Meff) plus device timings of the last run. */
+typedef struct gdca_stats {
+    double theta;               /* theta used (the estimate when theta = :auto)             */
+    double Meff;                /* effective number of sequences                            */
+    uint64_t pair_identity_sum; /* sum_{k<l} #{i: Z[i,k]==Z[i,l]} (0 unless theta = :auto)  */
+    int32_t thresh;             /* floor(theta * N)                                         */
+    int32_t info;               /* 0, or k>0: leading minor k of C not positive definite    */
+    int32_t N, M, q, n, n_pad;  /* n = N(q-1); n_pad = n rounded up to the tile size        */
+    int32_t update_launches;    /* launches of the dominant kernel (trailing sweep update)  */
+    /* device time (HIP events on the ctx stream), milliseconds */
+    double ms_total;            /* Z in HBM -> S in HBM                                     */
+    double ms_theta;            /* column histograms + theta                                */
+    double ms_weights;          /* bit-plane pack + all-pairs Hamming + W, Meff             */
+    double ms_covariance;       /* Pi + pair tallies + pseudocount + covariance build       */
+    double ms_inverse;          /* SPD inverse, whole stage                                 */
+    double ms_inverse_update;   /* sum over launches of the dominant kernel                 */
+    double ms_score;            /* FN or DI, + APC                                          */
+    double inverse_flops;       /* n^3/3+n^2/2+n/6 + 2n^3/3+n^2/2+5n/6 (dpotrf+dpotri)      */
+    double update_flops;        /* flops executed by all launches of the dominant kernel    */
+} gdca_stats;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int32_t gdca_version(void); /* major*1000 + minor */
+int32_t gdca_device_count(void);
+
+gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out);
+/* same, but enqueue on an existing hipStream_t (passed as void*); NULL = the null stream */
+gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_ctx **out);
+gdca_status gdca_ctx_destroy(gdca_ctx *ctx);
+gdca_status gdca_ctx_synchronize(gdca_ctx *ctx);
+const char *gdca_last_error(gdca_ctx *ctx); /* valid until the next call on ctx */
+/* per-stage device timing (HIP events + one stream sync per run); default on */
+gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
+
+/* ---- fused hot path: replaces src/GaussDCA.jl:28-42 in one call ------------------------ */
+/* Z_host: N x M int8 (host).  S_host: N x N f64 column-major (host), caller-owned.
+ * Only Z goes in and S + stats come out over PCIe. */
+gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q,
+                     const gdca_params *p, double *S_host, gdca_stats *st);
+/* Same with Z and S resident in HBM (device pointers). Synchronises the ctx stream before
+ * returning so that *st is complete. */
+gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                         const gdca_params *p, double *S_dev, gdca_stats *st);
+
+/* ---- operator level (host pointers): what the DCAUtils-named wrappers bind -------------- */
+/* compute_theta's all-pairs identity sum (inside compute_weighted_frequencies, :28) */
+gdca_status gdca_pair_identity_sum(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, uint64_t *out);
+/* theta = min(0.5, 0.38*0.32 / mean pair identity) */
+gdca_status gdca_compute_theta(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double *theta);
+/* n_out[k] = 1 + #{l != k : Hamming(k,l) < thresh}  (compute_weights, :28) */
+gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t thresh,
+                                  int32_t *n_out);
+/* compute_weights(Z, q, theta): W[M] = 1/n_k, Meff = W[0]+W[1]+... left to right.
+ * theta < 0 selects :auto.  theta_used / thresh may be NULL. */
+gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta,
+                                 double *W, double *Meff, double *theta_used, int32_t *thresh);
+/* weighted one-/two-site frequencies (compute_weighted_frequencies' accumulation, :28):
+ * Pi[n], Pij[n x n] full symmetric */
+gdca_status gdca_frequencies(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q,
+                             const double *W, double Meff, double *Pi, double *Pij);
+/* add_pseudocount(Pi_true, Pij_true, pc, q) (:30) */
+gdca_status gdca_add_pseudocount(gdca_ctx *ctx, const double *Pi_true, const double *Pij_true, int32_t N,
+                                 int32_t q, double pc, double *Pi, double *Pij);
+/* compute_C(Pi, Pij) = Pij - Pi*Pi' (:32, :76) */
+gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, int32_t n, double *C);
+/* inv(cholesky(C)) (:34): A (n x n, full symmetric) is replaced by its inverse (full
+ * symmetric).  *info = 0, or k > 0 when the leading minor of order k is not positive
+ * definite (then GDCA_ENOTPD is returned and A is unspecified). */
+gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info);
+/* compute_FN(mJ, q) (:39): S[N x N], diagonal 0 */
+gdca_status gdca_fn(gdca_ctx *ctx, const double *mJ, int32_t N, int32_t q, double *S);
+/* compute_DI_gauss(mJ, C, q) (:37) */
+gdca_status gdca_di(gdca_ctx *ctx, const double *mJ, const double *C, int32_t N, int32_t q, double *S);
+/* correct_APC(S) (:42, :78-86), in place */
+gdca_status gdca_apc(gdca_ctx *ctx, double *S, int32_t N);
+
+/* ---- measurement helpers (bench.py / profiles; not part of the reference surface) ------- */
+/* Dense f64 MFMA issue-rate probe: returns achieved TFLOP/s of a register-resident
+ * v_mfma_f64_16x16x4_f64 loop on every CU. */
+gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDCA_H */
