@@ -1,0 +1,216 @@
+"""bench.py -- the gDCA hot path on MI355X, BASELINE.json's headline configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--score frob|DI] [--N 500 --M 50000]
+
+One "step" = one pass of the hot path (src/GaussDCA.jl:28-42 of the reference: reweighting ->
+Pi/Pij -> covariance -> SPD inverse -> FN/DI -> APC) over one synthetic protein family whose
+int8 alignment is already resident in HBM; the N x N score matrix is left in HBM.  With N > 1
+GPUs every rank processes its own independent family per step (weak scaling, no collective on
+the data path; torch.distributed is used only for the timing barrier).
+
+Prints ONE JSON line (rank 0).  `value` = families per second over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
+PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
+
+
+def synth_family(N, M, q, seed):
+    """Deterministic 'Pfam-like' synthetic MSA (SURVEY.md 8d model), returned as (M, N) int8."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    root = rng.integers(1, q, size=N)
+    K = max(1, -(-M // 25))
+    centres = np.tile(root, (K, 1))
+    cm = rng.random((K, N)) < 0.25
+    centres[cm] = rng.integers(1, q, size=int(cm.sum()))
+    Z = centres[rng.integers(0, K, size=M)]
+    mu = rng.choice([0.02, 0.05, 0.1, 0.2, 0.3, 0.5], size=M)
+    mask = rng.random((M, N)) < mu[:, None]
+    Z[mask] = rng.integers(1, q, size=int(mask.sum()))
+    nruns = rng.integers(0, 4, size=M)
+    maxlen = max(2, N // 10)
+    for r in range(3):
+        sel = np.nonzero(nruns > r)[0]
+        start = rng.integers(0, N, size=sel.size)
+        length = rng.integers(1, maxlen + 1, size=sel.size)
+        for k, a, ln in zip(sel, start, length):
+            Z[k, a:a + ln] = q
+    return np.ascontiguousarray(Z.astype(np.int8))
+
+
+def cpu_baseline(N, M, q, pc, budget_s=20.0):
+    """The oracle ("port": numpy + OpenMP C loops + OpenBLAS dpotrf/dpotri) timed on the host cores
+    on a bounded sample of the same workload: the Hamming pass on a sequence subsample (cost
+    scaled by pairs), the tallies on a sequence subsample (cost linear in M), the SPD inverse at
+    reduced n (cost scaled by n^3) and FN in full.  Returns an estimate of seconds per family."""
+    import numpy as np
+
+    from oracle import gdca_oracle as o
+
+    cores = os.cpu_count() or 1
+    o.set_threads(cores)
+    s = q - 1
+    t_all = time.time()
+    Ms = min(M, 6000)
+    Zs = synth_family(N, Ms, q, 0xC500)
+    t = time.time()
+    thr = o.hamming_threshold(o.compute_theta(Zs), N)
+    n = o.neighbour_counts(Zs, thr)
+    t_ham = (time.time() - t) * (M * (M - 1.0)) / (Ms * (Ms - 1.0))
+    W, Meff = o.weights_from_counts(n)
+    Mt = min(Ms, 2000)
+    t = time.time()
+    Pi, Pij = o.compute_frequencies(Zs[:Mt], q, W[:Mt], float(W[:Mt].sum()))
+    t_freq = (time.time() - t) * (M / Mt)
+    t = time.time()
+    Pi2, Pij2 = o.add_pseudocount(Pi, Pij, pc, q)
+    C = o.compute_C(Pi2, Pij2)
+    t_cov = time.time() - t
+    ns = min(N * s, 4000)
+    Cs = np.ascontiguousarray(C[:ns, :ns])
+    t = time.time()
+    o.spd_inverse(Cs)
+    t_inv = (time.time() - t) * (N * s / ns) ** 3
+    mJ = o.spd_inverse(C) if N * s <= 4000 else C  # FN cost does not depend on the values
+    t = time.time()
+    o.correct_APC(o.compute_FN(mJ, q))
+    t_fn = time.time() - t
+    est = t_ham + t_freq + t_cov + t_inv + t_fn
+    return dict(value=1.0 / est, unit="families/s", cores=cores, kind="port",
+                sec_per_family_est=est,
+                sample=("oracle (numpy + OpenMP C + OpenBLAS potrf/potri) on %d host threads: Hamming on %d of %d "
+                        "sequences (x pairs ratio), tallies on %d sequences (x M ratio), potrf+potri at n=%d "
+                        "(x n^3 ratio), pseudocount/covariance/FN/APC in full; stage seconds "
+                        "ham=%.2f freq=%.2f cov=%.2f inv=%.2f fn=%.2f; sample wall %.1fs"
+                        % (cores, Ms, M, Mt, ns, t_ham, t_freq, t_cov, t_inv, t_fn, time.time() - t_all)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--score", default="frob")
+    ap.add_argument("--N", type=int, default=500)
+    ap.add_argument("--M", type=int, default=50000)
+    ap.add_argument("--q", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import gaussdca.jl_amd as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the gDCA hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    N, M, q = args.N, args.M, args.q
+    score = 1 if args.score == "DI" else 0
+    pc = 0.2 if score == 1 else 0.8
+    Zh = synth_family(N, M, q, 0xC500 + rank)                 # (M, N) == Julia's N x M column-major bytes
+    Zd = torch.from_numpy(Zh).to(dev)                          # resident in HBM before the timed region
+    Sd = torch.empty((N, N), dtype=torch.float64, device=dev)  # stays in HBM
+    ctx = g.Context(local)
+
+    def step():
+        return ctx.run_dev(Zd.data_ptr(), N, M, q, pc, -1.0, score, Sd.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        ms_step = dt / K * 1e3
+        upd_ms = float(np.mean([s["ms_inverse_update"] for s in stats]))
+        upd_launch = stats[-1]["update_launches"]
+        upd_flops = stats[-1]["update_flops"]
+        inv_ms = float(np.mean([s["ms_inverse"] for s in stats]))
+        achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        out = {
+            "metric": METRIC,
+            "value": world * K / dt,
+            "unit": "families/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic Pfam-like MSA N=%d M=%d q=%d, score=:%s, theta=:auto, pseudocount=%.1f "
+                                   "(BASELINE.json configs[2])" % (N, M, q, args.score, pc),
+                       "N": N, "M": M, "q": q, "n": N * (q - 1), "families_per_step_per_gpu": 1},
+            "sec_per_family": ms_step * 1e-3,
+            "spd_inverse_tflops": stats[-1]["inverse_flops"] / (inv_ms * 1e-3) / 1e12,
+            "stage_ms": {k: float(np.mean([s[k] for s in stats])) for k in
+                         ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
+                          "ms_score")},
+            "theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"],
+            "roofline": {
+                "kernel": "k_sweep_update (f64 MFMA 128x128x128 tile products of the SPD inverse)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F64_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F64_MFMA_TFLOPS,
+                "traffic": None,
+                "launches_per_step": upd_launch,
+                "flops_per_launch": upd_flops / max(1, upd_launch),
+                "avg_launch_ms": upd_ms / max(1, upd_launch),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, M, q, pc)
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
