@@ -23,7 +23,11 @@ struct gdca_ctx {
     bool timing;
     char err[512];
     // named device buffers (grow-only)
-    gdca_buf Zt, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Dblk, Ld, colsum, sc;
+    gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, G2, H2, P, Dblk, Ld, colsum, sc;
+    hipStream_t side;          // look-ahead stream of the SPD inverse
+    bool lookahead;
+    hipEvent_t sev[MAX_EV];    // cross-stream ordering events
+    int n_sev;
     gdca_buf scratch[N_SCRATCH];
     gdca_dev_scalars *sc_host;  // pinned
     hipEvent_t ev[MAX_EV];
@@ -106,6 +110,11 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     }
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    ctx->lookahead = getenv("GDCA_NO_LOOKAHEAD") == nullptr;
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
+        free(ctx);
+        return GDCA_EHIP;
+    }
     if (hipHostMalloc((void **)&ctx->sc_host, sizeof(gdca_dev_scalars), hipHostMallocDefault) != hipSuccess) {
         free(ctx);
         return GDCA_ENOMEM;
@@ -119,7 +128,11 @@ gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
     gdca_status st = gdca_ctx_create_on_stream(device_id, nullptr, out);
     if (st != GDCA_OK) return st;
     gdca_ctx *ctx = *out;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    // the main stream carries the pivot/panel chain of the SPD inverse (the critical path of the
+    // look-ahead schedule): give it the highest priority the device offers
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         gdca_ctx_destroy(ctx);
         *out = nullptr;
         return GDCA_EHIP;
@@ -133,13 +146,19 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (!ctx) return GDCA_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    gdca_buf *bufs[] = {&ctx->Zt, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
-                        &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Dblk, &ctx->Ld, &ctx->colsum, &ctx->sc};
+    gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
+                        &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->G2, &ctx->H2, &ctx->P, &ctx->Dblk, &ctx->Ld,
+                        &ctx->colsum, &ctx->sc};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
         if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < ctx->n_sev; ++i) (void)hipEventDestroy(ctx->sev[i]);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
     if (ctx->sc_host) (void)hipHostFree(ctx->sc_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
@@ -174,6 +193,16 @@ static gdca_status need_events(gdca_ctx *ctx, int n)
     while (ctx->n_ev < n) {
         HIPCHK(hipEventCreate(&ctx->ev[ctx->n_ev]));
         ++ctx->n_ev;
+    }
+    return GDCA_OK;
+}
+
+static gdca_status need_sync_events(gdca_ctx *ctx, int n)
+{
+    if (n > MAX_EV) return fail(ctx, GDCA_EINVAL, "matrix too large for the event pool%s%s", "", "");
+    while (ctx->n_sev < n) {
+        HIPCHK(hipEventCreateWithFlags(&ctx->sev[ctx->n_sev], hipEventDisableTiming));
+        ++ctx->n_sev;
     }
     return GDCA_OK;
 }
@@ -230,30 +259,43 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim;
     const int shift = gdca_fix_shift(M);
+    const int TJ = gdca_tally_tj(q);
     CHK(ensure(ctx, ctx->Zt, (size_t)N * M));
+    CHK(ensure(ctx, ctx->Zp, (size_t)round_up(N, 64) * M + 64));
     CHK(ensure(ctx, ctx->Pifix, (size_t)N * 32 * sizeof(unsigned long long)));
     CHK(ensure(ctx, ctx->Pipc, (size_t)n * sizeof(double)));
     gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
+    gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
     gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M);
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
                             (double *)ctx->Pipc.p);
-    gdca_launch_pair_tally(s, Zd, (const int8_t *)ctx->Zt.p, (const unsigned long long *)ctx->Wfix.p, N, M, q, shift,
-                           Meff_dev, pc, (const double *)ctx->Pipc.p, mode, out, ld);
+    gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
+                           (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
+                           (const double *)ctx->Pipc.p, mode, out, ld);
     return check_launch(ctx, "tally");
 }
 
-static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, int *n_upd)
+static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, int *n_upd, double *upd_flops)
 {
     hipStream_t s = ctx->stream;
-    CHK(ensure(ctx, ctx->G, (size_t)n_pad * GDCA_TILE * sizeof(double)));
-    CHK(ensure(ctx, ctx->H, (size_t)n_pad * GDCA_TILE * sizeof(double)));
+    const size_t pbytes = (size_t)n_pad * GDCA_TILE * sizeof(double);
+    CHK(ensure(ctx, ctx->G, pbytes));
+    CHK(ensure(ctx, ctx->H, pbytes));
     CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
-    gdca_inverse_ws ws;
-    ws.G = (double *)ctx->G.p;
-    ws.H = (double *)ctx->H.p;
-    ws.P = (double *)ctx->P.p;
     const int nblk = n_pad / GDCA_TILE;
+    const bool la = ctx->lookahead && nblk >= 3;
+    gdca_inverse_ws ws;
+    ws.G[0] = ws.G[1] = (double *)ctx->G.p;
+    ws.H[0] = ws.H[1] = (double *)ctx->H.p;
+    ws.P = (double *)ctx->P.p;
+    if (la) {
+        CHK(ensure(ctx, ctx->G2, pbytes));
+        CHK(ensure(ctx, ctx->H2, pbytes));
+        ws.G[1] = (double *)ctx->G2.p;
+        ws.H[1] = (double *)ctx->H2.p;
+        CHK(need_sync_events(ctx, 2 * nblk));
+    }
     hipEvent_t *uev = nullptr;
     int max_ev = 0;
     if (timed) {
@@ -261,7 +303,8 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
         uev = ctx->ev + 16;
         max_ev = ctx->n_ev - 16;
     }
-    gdca_launch_spd_inverse(s, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n, uev, max_ev, n_upd);
+    gdca_launch_spd_inverse(s, la ? ctx->side : nullptr, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n,
+                            ctx->sev, uev, max_ev, n_upd, upd_flops);
     return check_launch(ctx, "spd_inverse");
 }
 
@@ -341,7 +384,8 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
     if (timed) HIPCHK(hipEventRecord(ev[3], s));
 
     int n_upd = 0;
-    CHK(inverse_stage(ctx, n, n_pad, timed, &n_upd));
+    double upd_flops = 0.0;
+    CHK(inverse_stage(ctx, n, n_pad, timed, &n_upd, &upd_flops));
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
 
     CHK(score_stage(ctx, N, sdim, n_pad, p->score, p->apc, S_dev));
@@ -363,8 +407,7 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
         st->n_pad = n_pad;
         st->update_launches = n_upd;
         st->inverse_flops = inverse_flops_model((double)n);
-        const int m = n_pad / GDCA_TILE - 1;
-        st->update_flops = (double)n_upd * ((double)m * (m + 1) / 2.0) * 2.0 * GDCA_TILE * GDCA_TILE * GDCA_TILE;
+        st->update_flops = upd_flops;
         if (timed) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
@@ -555,7 +598,7 @@ gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
     HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, A, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
     gdca_launch_copy_in(s, (const double *)ctx->scratch[1].p, n, (double *)ctx->A.p, n_pad);
     int n_upd = 0;
-    CHK(inverse_stage(ctx, n, n_pad, false, &n_upd));
+    CHK(inverse_stage(ctx, n, n_pad, false, &n_upd, nullptr));
     gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, (double *)ctx->scratch[1].p, n);
     CHK(check_launch(ctx, "copy_out"));
     HIPCHK(hipMemcpyAsync(A, ctx->scratch[1].p, nn * nn * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -54,7 +54,10 @@ void gdca_launch_pi_finalize(hipStream_t s, const unsigned long long *Pifix, int
                              const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc);
 // Pair tallies.  mode 0: out = Pij_true (full symmetric, ld);  mode 1: out = C =
 // add_pseudocount + compute_C fused (full symmetric, ld).  Pi_pc used by mode 1 only.
-void gdca_launch_pair_tally(hipStream_t s, const int8_t *Z, const int8_t *Zt, const unsigned long long *Wfix,
+// Zc: the alignment regrouped as [ceil(N/TJ)][M][TJ] (gdca_launch_colblock), TJ = gdca_tally_tj(q).
+int gdca_tally_tj(int q);
+void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ);
+void gdca_launch_pair_tally(hipStream_t s, const int8_t *Zc, const int8_t *Zt, const unsigned long long *Wfix,
                             int N, int M, int q, int fix_shift, const double *Meff_dev, double pc,
                             const double *Pi_pc, int mode, double *out, size_t ld);
 
@@ -73,16 +76,19 @@ void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int
 
 // ---- k_inverse.hip -------------------------------------------------------------------------
 struct gdca_inverse_ws {
-    double *G;   // n_pad x 128 panel (column k of the swept matrix)
-    double *H;   // n_pad x 128 panel, -G * P
-    double *P;   // 128 x 128 inverse of the pivot block
+    double *G[2];  // n_pad x 128 panels (column k of the swept matrix), double-buffered by step parity
+    double *H[2];  // n_pad x 128 panels, -G * P
+    double *P;     // 128 x 128 inverse of the pivot block
 };
 // In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles
 // authoritative): A <- -inverse(A) by the block symmetric sweep.  info (device) gets the
 // 1-based index of the first non-positive pivot, if any.
-void gdca_launch_spd_inverse(hipStream_t s, double *A, int n_pad, const gdca_inverse_ws &ws,
-                             gdca_dev_scalars *sc, int n_real, hipEvent_t *upd_ev, int max_ev,
-                             int *n_upd_launch);
+// s1 == nullptr: serial schedule on s0.  Otherwise look-ahead over two streams; sync_ev must hold
+// 2 * (n_pad / 128) events.  upd_ev (optional, 2 per big update launch) are recorded on the stream
+// the launch runs on.
+void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
+                             gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev,
+                             int max_upd_ev, int *n_upd_launch, double *upd_flops);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
 
 // ---- k_score.hip ---------------------------------------------------------------------------

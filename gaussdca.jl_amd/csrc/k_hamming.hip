@@ -141,6 +141,17 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
                     acc[r][c] += __builtin_popcount(x);
                 }
         }
+        // early exit: distances only grow, so once every pair of the tile is at or beyond the
+        // threshold no later position can make it a neighbour (unrelated sequences differ at
+        // ~2/3 of the positions: most tiles stop after ~60 % of the alignment)
+        if (w0 + WCHUNK < NW) {
+            uint32_t mn = acc[0][0];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
+            if (__syncthreads_or((int)mn < thresh) == 0) break;
+        }
     }
 
     // threshold, count (strict '<'), reduce over the workgroup
@@ -193,10 +204,12 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N,
 // ---- weights ------------------------------------------------------------------------------------
 int gdca_fix_shift(int M)
 {
-    // fixed-point scale 2^shift for the weighted tallies: M * 2^shift <= 2^63
+    // fixed-point scale 2^shift for the weighted tallies: M * 2^shift <= 2^63, and every weight
+    // (<= 2^shift) must fit the 59-bit field of the tally kernel's packed {symbol, weight} word
     int lg = 0;
     while ((1ll << lg) < (long long)M) ++lg;
-    return 63 - lg;
+    const int sh = 63 - lg;
+    return sh < 58 ? sh : 58;
 }
 
 __global__ __launch_bounds__(256) void k_weights(const int32_t *__restrict__ cnt, int M, int fix_shift,
@@ -231,28 +244,51 @@ void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shif
 }
 
 // Meff = ((W[0] + W[1]) + W[2]) + ...  -- the strictly sequential f64 sum the oracle uses, so the
-// value is bit-identical to it.  One wave: 64 coalesced loads, then 64 dependent adds fed by
-// v_readlane.  O(M) dependent adds (~0.2 ms at M = 50k); nothing else in the pipeline waits on
-// a shorter chain.
-__global__ __launch_bounds__(64) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
+// value is bit-identical to it.  The chain of M dependent v_add_f64 is the whole cost; one thread
+// walks it out of LDS (b128 reads, issued ahead of the adds) while the other 255 threads stage
+// the next 2048 weights.  Zero padding of the last tile is exact (x + 0.0 == x for x > 0).
+#define MEFF_TILE 2048
+__global__ __launch_bounds__(256) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
 {
-    const int lane = threadIdx.x;
-    double acc = 0.0;
-    for (int base = 0; base < M; base += 64) {
-        const int k = base + lane;
-        const double w = (k < M) ? W[k] : 0.0;
-        const int cntv = min(64, M - base);
-        if (cntv == 64) {
+    __shared__ __attribute__((aligned(16))) double buf[2][MEFF_TILE];
+    const int tid = threadIdx.x;
+    const int ntile = (M + MEFF_TILE - 1) / MEFF_TILE;
+    double r[8];
 #pragma unroll
-            for (int t = 0; t < 64; ++t) acc += __shfl(w, t, 64);
-        } else {
-            for (int t = 0; t < cntv; ++t) acc += __shfl(w, t, 64);
-        }
+    for (int u = 0; u < 8; ++u) {
+        const int k = tid + 256 * u;
+        buf[0][tid + 256 * u] = (k < M) ? W[k] : 0.0;
     }
-    if (lane == 0) sc->Meff = acc;
+    __syncthreads();
+    double acc = 0.0;
+    for (int t = 0; t < ntile; ++t) {
+        const bool more = t + 1 < ntile;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = (t + 1) * MEFF_TILE + tid + 256 * u;
+                r[u] = (k < M) ? W[k] : 0.0;
+            }
+        }
+        if (tid == 0) {
+            const double2 *b2 = reinterpret_cast<const double2 *>(buf[t & 1]);
+#pragma unroll 8
+            for (int e = 0; e < MEFF_TILE / 2; ++e) {
+                const double2 v = b2[e];
+                acc += v.x;
+                acc += v.y;
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) buf[(t + 1) & 1][tid + 256 * u] = r[u];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) sc->Meff = acc;
 }
 
 void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_meff, dim3(1), dim3(64), 0, s, W, M, sc);
+    hipLaunchKernelGGL(k_meff, dim3(1), dim3(256), 0, s, W, M, sc);
 }

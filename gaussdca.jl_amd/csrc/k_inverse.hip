@@ -28,70 +28,108 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define LDS_LD (T + 16)  // f64 elements per k-row in LDS (128-byte pad)
 
 // -------------------------------------------------------------------------------------------------
-// Pivot: P = inverse of the 128 x 128 SPD block at (k0, k0), by a scalar symmetric sweep held in
-// registers (each of 1024 threads owns a 4 x 4 patch; the pivot column is broadcast through LDS).
-// Writes P (128 x 128, column-major) and A_KK <- -P.  Non-positive pivot -> sc->info.
+// Pivot: P = inverse of the 128 x 128 SPD block at (k0, k0) by a scalar symmetric sweep on its
+// LOWER TRIANGLE held in registers: 136 threads each own one 8 x 8 patch (pr >= pc) of the 16 x 16
+// patch grid.  Per pivot j the column j of the symmetric block (rows >= j from column j, rows < j
+// from row j) and p = 1/d are broadcast through LDS (double-buffered: one barrier per pivot), then
+// every element is one FMA:   D[r][c] <- D[r][c] - u[r] * w[c],   u = g,  w = g * p,
+// with the pivot row/column handled by the vectors alone (u[j] = -1, w[j] = -p, old row/column j
+// zeroed):  row j -> g[c] p,  column j -> g[r] p,  (j,j) -> -p.  The j loop is unrolled by 8 so
+// every register index is static.  Writes P (full symmetric) and A_KK <- -P (full tile).
+// A non-positive pivot (the same test dpotrf makes) is reported through sc->info.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_pivot(double *__restrict__ A, size_t ld, int k0, double *__restrict__ P,
-                                                 gdca_dev_scalars *sc, int n_real)
+__global__ __launch_bounds__(256) void k_pivot(double *__restrict__ A, size_t ld, int k0, double *__restrict__ P,
+                                                gdca_dev_scalars *sc, int n_real)
 {
     __shared__ __attribute__((aligned(16))) double g[2][T];
+    __shared__ double pinv[2];
+    __shared__ int badj;
     const int tid = threadIdx.x;
-    const int tr = tid & 31, tc = tid >> 5;
-    const int r0 = tr * 4, c0 = tc * 4;
-    double D[4][4];
+    if (tid == 0) badj = 0;
+    const bool active = tid < 136;
+    int pr = 0, pc = 0;
+    if (active) {
+        pr = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
+        while (pr * (pr + 1) / 2 > tid) --pr;
+        while ((pr + 1) * (pr + 2) / 2 <= tid) ++pr;
+        pc = tid - pr * (pr + 1) / 2;
+    }
+    const int r0 = pr * 8, c0 = pc * 8;
     double *Akk = A + (size_t)k0 + (size_t)k0 * ld;
+    double D[8][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int a = 0; a < 8; ++a) {
             const int r = r0 + a, c = c0 + b;
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;  // lower triangle is authoritative
-            D[a][b] = Akk[(size_t)rr + (size_t)cc * ld];
+            D[a][b] = active ? Akk[(size_t)rr + (size_t)cc * ld] : 0.0;
         }
-    int bad = 0;
-    for (int j = 0; j < T; ++j) {
-        double *gj = g[j & 1];
-        if (tc == (j >> 2)) {
-            const int jb = j & 3;
+    __syncthreads();
+
+    for (int jb = 0; jb < T / 8; ++jb) {
+        const bool inrow = active && (pr == jb);  // my patch holds rows of the pivot octet
+        const bool incol = active && (pc == jb);  // my patch holds columns of the pivot octet
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const double v = (jb == 0) ? D[a][0] : (jb == 1) ? D[a][1] : (jb == 2) ? D[a][2] : D[a][3];
-                gj[r0 + a] = v;
+        for (int jj = 0; jj < 8; ++jj) {
+            const int par = jj & 1;
+            if (incol) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+                    if (pr > jb || a >= jj) g[par][r0 + a] = D[a][jj];  // (r, j), r >= j
             }
+            if (inrow) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (pc < jb || b < jj) g[par][c0 + b] = D[jj][b];   // (j, c), c < j
+            }
+            if (inrow && incol) {
+                const double d = D[jj][jj];
+                pinv[par] = 1.0 / d;
+                if (!(d > 0.0) && badj == 0) badj = jb * 8 + jj + 1;
+            }
+            __syncthreads();
+            const double p = pinv[par];
+            double u[8], w[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) u[a] = g[par][r0 + a];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) w[b] = g[par][c0 + b] * p;
+            // branch-free specials (selects, not predicated moves: keeps one live copy of D)
+            u[jj] = inrow ? -1.0 : u[jj];
+            w[jj] = incol ? -p : w[jj];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) D[jj][b] = inrow ? 0.0 : D[jj][b];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) D[a][jj] = incol ? 0.0 : D[a][jj];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) D[a][b] = fma(-u[a], w[b], D[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
-        const double d = gj[j];
-        if (!(d > 0.0) && bad == 0) bad = j + 1;
-        const double p = 1.0 / d;
-        double gr[4], gc[4];
+    }
+    // D = -inverse (lower triangle valid).  P = -D;  A_KK = D, both written as full symmetric tiles
+    if (active) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) gr[a] = gj[r0 + a];
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) gc[b] = gj[c0 + b];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int a = 0; a < 8; ++a) {
                 const int r = r0 + a, c = c0 + b;
-                const double t = gr[a] * gc[b];  // commutative: keeps the block bitwise symmetric
-                double v = fma(-t, p, D[a][b]);
-                if (r == j) v = (c == j) ? -p : gc[b] * p;
-                else if (c == j) v = gr[a] * p;
-                D[a][b] = v;
+                if (r >= c) {
+                    const double v = D[a][b];
+                    P[(size_t)r + (size_t)c * T] = -v;
+                    Akk[(size_t)r + (size_t)c * ld] = v;
+                    if (r > c) {
+                        P[(size_t)c + (size_t)r * T] = -v;
+                        Akk[(size_t)c + (size_t)r * ld] = v;
+                    }
+                }
             }
     }
-    // D = -inverse.  P = -D;  A_KK = D (full tile)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int r = r0 + a, c = c0 + b;
-            P[(size_t)r + (size_t)c * T] = -D[a][b];
-            Akk[(size_t)r + (size_t)c * ld] = D[a][b];
-        }
-    if (tid == 0 && bad != 0 && (k0 + bad) <= n_real) {
-        if (sc->info == 0) sc->info = k0 + bad;
+    __syncthreads();
+    if (tid == 0 && badj != 0 && (k0 + badj) <= n_real) {
+        if (sc->info == 0) sc->info = k0 + badj;
     }
 }
 
@@ -247,21 +285,35 @@ __global__ __launch_bounds__(256, 2) void k_panel(double *__restrict__ A, size_t
             }
 }
 
-// Update: every lower-triangle tile (I >= J) with I, J != k:  A_IJ += G_I * H_J^T   (H = -G P).
-__global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int kblk, int nblk,
-                                                          const double *__restrict__ Gbuf,
+// Update: lower-triangle tiles  A_IJ += G_I * H_J^T   (H = -G P), in one of two tile sets:
+//   colblk <  0 : every tile (I >= J) with I, J not in {skip0, skip1}   (skip1 = -1: only skip0)
+//   colblk >= 0 : the nblk-1 tiles that involve block `colblk` as row or column (I != skip0) --
+//                 the look-ahead slice that the next pivot and panel need first.
+__global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int skip0, int skip1,
+                                                          int colblk, const double *__restrict__ Gbuf,
                                                           const double *__restrict__ Hbuf, size_t pld)
 {
     __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
-    // decode blockIdx.x -> (ii >= jj) over the nblk-1 active block indices
     const int t = blockIdx.x;
-    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((long long)ii * (ii + 1) / 2 > t) --ii;
-    while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
-    const int jj = t - (int)((long long)ii * (ii + 1) / 2);
-    const int I = ii + (ii >= kblk ? 1 : 0), J = jj + (jj >= kblk ? 1 : 0);
-    (void)nblk;
+    int I, J;
+    if (colblk >= 0) {
+        int b = t;
+        if (b >= skip0) ++b;
+        I = b > colblk ? b : colblk;
+        J = b > colblk ? colblk : b;
+    } else {
+        int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)ii * (ii + 1) / 2 > t) --ii;
+        while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
+        int jj = t - (int)((long long)ii * (ii + 1) / 2);
+        if (ii >= skip0) ++ii;
+        if (skip1 >= 0 && ii >= skip1) ++ii;
+        if (jj >= skip0) ++jj;
+        if (skip1 >= 0 && jj >= skip1) ++jj;
+        I = ii;
+        J = jj;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
@@ -290,25 +342,68 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
             }
 }
 
-void gdca_launch_spd_inverse(hipStream_t s, double *A, int n_pad, const gdca_inverse_ws &ws, gdca_dev_scalars *sc,
-                             int n_real, hipEvent_t *upd_ev, int max_ev, int *n_upd_launch)
+// Host driver of the block sweep.  With a side stream (s1 != nullptr) it runs with look-ahead:
+// for step k the slice of the update that touches block k+1 goes first on the main stream,
+// followed by pivot(k+1) and panel(k+1), while the rest of update k (the big launch) runs on the
+// side stream; G/H panels are double-buffered by step parity.  Steady state: the side stream
+// executes the big update launches back to back and the pivot/panel chain hides behind them.
+void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
+                             gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev, int max_upd_ev,
+                             int *n_upd_launch, double *upd_flops)
 {
     const int nblk = n_pad / T;
     const size_t ld = (size_t)n_pad;
+    const double tile_flops = 2.0 * T * T * T;
     int nl = 0;
-    for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(1024), 0, s, A, ld, k * T, ws.P, sc, n_real);
-        if (nblk > 1) {
-            hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s, A, ld, k, ws.P, ws.G, ws.H, ld);
-            const int m = nblk - 1;
-            const unsigned ntile = (unsigned)((long long)m * (m + 1) / 2);
-            if (upd_ev && 2 * nl + 1 < max_ev) (void)hipEventRecord(upd_ev[2 * nl], s);
-            hipLaunchKernelGGL(k_sweep_update, dim3(ntile), dim3(256), 0, s, A, ld, k, nblk, ws.G, ws.H, ld);
-            if (upd_ev && 2 * nl + 1 < max_ev) (void)hipEventRecord(upd_ev[2 * nl + 1], s);
-            ++nl;
+    double fl = 0.0;
+    auto timed_update = [&](hipStream_t st, unsigned ntile, int skip0, int skip1, const double *G, const double *H) {
+        const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
+        if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
+        hipLaunchKernelGGL(k_sweep_update, dim3(ntile), dim3(256), 0, st, A, ld, skip0, skip1, -1, G, H, ld);
+        if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
+        ++nl;
+        fl += tile_flops * (double)ntile;
+    };
+
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, 0, ws.P, sc, n_real);
+    if (nblk > 1) {
+        hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, 0, ws.P, ws.G[0], ws.H[0], ld);
+        if (!s1) {
+            // serial schedule: pivot -> panel -> full update, one stream
+            for (int k = 0; k < nblk; ++k) {
+                if (k > 0) {
+                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, k * T, ws.P, sc, n_real);
+                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.P, ws.G[0], ws.H[0], ld);
+                }
+                const int m = nblk - 1;
+                timed_update(s0, (unsigned)((long long)m * (m + 1) / 2), k, -1, ws.G[0], ws.H[0]);
+            }
+        } else {
+            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
+            (void)hipEventRecord(Ep[0], s0);
+            for (int k = 0; k < nblk; ++k) {
+                const bool has_next = k + 1 < nblk;
+                const double *G = ws.G[k & 1], *H = ws.H[k & 1];
+                // side stream: everything of update k that does not touch block k+1
+                (void)hipStreamWaitEvent(s1, Ep[k], 0);
+                const int m = nblk - (has_next ? 2 : 1);
+                if (m > 0) timed_update(s1, (unsigned)((long long)m * (m + 1) / 2), k, has_next ? k + 1 : -1, G, H);
+                (void)hipEventRecord(Eb[k], s1);
+                if (has_next) {
+                    if (k >= 1) (void)hipStreamWaitEvent(s0, Eb[k - 1], 0);
+                    // look-ahead slice: the nblk-1 tiles in row/column k+1, then the next pivot and panel
+                    hipLaunchKernelGGL(k_sweep_update, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, -1, k + 1, G, H, ld);
+                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, (k + 1) * T, ws.P, sc, n_real);
+                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k + 1, ws.P, ws.G[(k + 1) & 1],
+                                       ws.H[(k + 1) & 1], ld);
+                    (void)hipEventRecord(Ep[k + 1], s0);
+                }
+            }
+            (void)hipStreamWaitEvent(s0, Eb[nblk - 1], 0);
         }
     }
     if (n_upd_launch) *n_upd_launch = nl;
+    if (upd_flops) *upd_flops = fl;
 }
 
 // -------------------------------------------------------------------------------------------------

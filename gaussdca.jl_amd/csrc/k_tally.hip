@@ -84,13 +84,57 @@ void gdca_launch_pi_finalize(hipStream_t s, const u64 *Pifix, int N, int q, int 
 }
 
 // ---- pair tallies -----------------------------------------------------------------------------------
-#define TALLY_THREADS 512
-#define TALLY_CHUNK 512  // sequences staged per pass (one per thread)
+#define TALLY_THREADS 1024
+#define TALLY_CHUNK 1024  // sequences staged per pass (one per thread)
 
+// Z [M][N] -> Zc [ceil(N/TJ)][M][TJ] (zero padded): for one column block the TJ bytes of
+// consecutive sequences are consecutive in memory, so a workgroup's staging loads are fully
+// coalesced 16-byte accesses with no over-fetch.  Tile transpose through LDS.
+__global__ __launch_bounds__(256) void k_colblock(const int8_t *__restrict__ Z, int8_t *__restrict__ Zc, int N, int M,
+                                                   int TJ)
+{
+    __shared__ int8_t tile[64][64 + 4];
+    const int k0 = blockIdx.y * 64, c0 = blockIdx.x * 64;  // 64 sequences x 64 columns
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = k0 + r * 4 + ty, c = c0 + tx;
+        tile[r * 4 + ty][tx] = (k < M && c < N) ? Z[(size_t)k * N + c] : (int8_t)0;
+    }
+    __syncthreads();
+    // write: for each column block inside this 64-column strip, rows of TJ bytes per sequence
+    const int nb = 64 / TJ;  // column blocks in the strip (2 or 4)
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int blk = e / (64 * TJ), rem = e % (64 * TJ);
+        const int kl = rem / TJ, cl = rem % TJ;
+        const int k = k0 + kl;
+        const int cb = c0 / TJ + blk;
+        if (blk < nb && k < M && cb * TJ < ((N + TJ - 1) / TJ) * TJ)
+            Zc[((size_t)cb * M + k) * TJ + cl] = tile[kl][blk * TJ + cl];
+    }
+}
+
+void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ)
+{
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL(k_colblock, grid, dim3(256), 0, s, Z, Zc, N, M, TJ);
+}
+
+// Workgroup = (column i) x (block of TJ columns j >= i's block), 1024 threads = 16 waves (the
+// histograms take most of the LDS, so one workgroup per CU: the waves have to come from here).
+// Per pass of 1024 sequences the block's TJ bytes of every sequence and a packed
+// {row(Z[i,k]), Wfix[k]} word are staged in LDS (the next pass's global loads are in flight while
+// the current one is tallied), then each wave walks 64 sequences, 64/TJ at a time: lane =
+// (sequence, column j): one ds_read_u8 for Z[j,k], one broadcast ds_read_b64 for the packed word,
+// one ds_add_u64 into hist[a][b][j].
+//
+// The histogram has s+2 columns per row (b = 0 and b = q are junk columns for padding / gaps) so
+// the inner loop needs no validity test at all: an invalid Z[i,k] is staged as weight 0, lanes left
+// of the diagonal tally into columns the epilogue never reads.
 template <int TJ>
 __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
-    const int8_t *__restrict__ Z, const int8_t *__restrict__ Zt, const u64 *__restrict__ Wfix, int N, int M, int q,
-    int fix_shift, const double *__restrict__ Meff_dev, double pc, const double *__restrict__ Pi_pc, int mode,
+    const int8_t *__restrict__ Zc, const int8_t *__restrict__ Zt, const u64 *__restrict__ Wfix, int N, int M,
+    int q, int fix_shift, const double *__restrict__ Meff_dev, double pc, const double *__restrict__ Pi_pc, int mode,
     double *__restrict__ out, size_t ld)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,52 +143,87 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
     const int j0 = blockIdx.x * TJ;
     if (j0 + TJ - 1 < i) return;  // block entirely left of the diagonal: its mirror does the work
 
-    u64 *hist = reinterpret_cast<u64 *>(smem);                       // [s*s][TJ]
-    u64 *w_s = hist + (size_t)s * s * TJ;                            // [TALLY_CHUNK]
-    int8_t *a_s = reinterpret_cast<int8_t *>(w_s + TALLY_CHUNK);     // [TALLY_CHUNK]
+    const int RS = (s + 2) * TJ;                                                  // u64 per histogram row a
+    u64 *hist = reinterpret_cast<u64 *>(smem);                                    // [s][s+2][TJ]
+    u64 *meta_s = hist + (size_t)s * RS;                                          // [TALLY_CHUNK]
+    uint8_t *zs = reinterpret_cast<uint8_t *>(meta_s + TALLY_CHUNK);              // [TALLY_CHUNK][TJ]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int SPI = 64 / TJ;                 // sequences per wave-instruction
+    constexpr int SPI = 64 / TJ;  // sequences per wave-instruction
     constexpr int NWAVE = TALLY_THREADS / 64;
     constexpr int SEQ_PER_WAVE = TALLY_CHUNK / NWAVE;  // 64
+    constexpr int NV = TJ / 16;                        // dwordx4 loads per sequence
+    static_assert(TALLY_CHUNK == TALLY_THREADS, "one staged sequence per thread");
     const int jl = lane % TJ, sub = lane / TJ;
-    const int j = j0 + jl;
-    const bool jok = (j < N) && (j >= i);
+    const u64 wmask = (1ull << 59) - 1;
+    const unsigned qclamp = (unsigned)(s + 1);
 
-    for (int e = tid; e < s * s * TJ; e += TALLY_THREADS) hist[e] = 0;
+    for (int e = tid; e < s * RS; e += TALLY_THREADS) hist[e] = 0;
 
+    // prefetch registers for one pass: this thread's sequence kc + tid.  The raw loads stay
+    // untouched in registers until the LDS write of the NEXT pass, so a whole pass of tallies
+    // covers their latency.  Plain scalars: an indexed uint4 array here goes to scratch.
+    const int8_t *Zblk = Zc + (size_t)blockIdx.x * M * TJ;
+    uint4 z0 = make_uint4(0, 0, 0, 0), z1 = z0;
+    u64 wf = 0;
+    int8_t av = 0;
+#define TALLY_FETCH(KC)                                                                       \
+    do {                                                                                      \
+        int k_ = (KC) + tid;                                                                  \
+        k_ = k_ < M ? k_ : M - 1; /* clamp: the tail is staged with weight 0 */               \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(Zblk + (size_t)k_ * TJ);          \
+        z0 = src_[0];                                                                         \
+        if (NV > 1) z1 = src_[1];                                                             \
+        av = Zt[(size_t)i * M + k_];                                                          \
+        wf = Wfix[k_];                                                                        \
+    } while (0)
+    TALLY_FETCH(0);
     for (int kc = 0; kc < M; kc += TALLY_CHUNK) {
-        __syncthreads();
+        __syncthreads();  // previous pass fully consumed (and hist zeroed, first time)
         {
-            const int k = kc + tid;
-            a_s[tid] = (k < M) ? Zt[(size_t)i * M + k] : (int8_t)0;
-            w_s[tid] = (k < M) ? Wfix[k] : 0ull;
+            reinterpret_cast<uint4 *>(zs + (size_t)tid * TJ)[0] = z0;
+            if (NV > 1) reinterpret_cast<uint4 *>(zs + (size_t)tid * TJ)[1] = z1;
+            const unsigned a = (unsigned)(uint8_t)av - 1u;  // row index 0..s-1 when valid
+            const bool valid = (a < (unsigned)s) && (kc + tid < M);
+            meta_s[tid] = valid ? (((u64)a << 59) | (wf & wmask)) : 0ull;
         }
         __syncthreads();
+        if (kc + TALLY_CHUNK < M) TALLY_FETCH(kc + TALLY_CHUNK);
         const int kw = wv * SEQ_PER_WAVE;
 #pragma unroll 2
         for (int it = 0; it < SEQ_PER_WAVE / SPI; it += 4) {
-            int bsym[4], asym[4];
-            u64 wv4[4];
+            u64 m4[4];
+            unsigned b4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kk = kw + (it + u) * SPI + sub;
-                const int k = kc + kk;
-                asym[u] = a_s[kk];
-                wv4[u] = w_s[kk];
-                bsym[u] = (jok && k < M) ? (int)Z[(size_t)k * N + j] : 0;
+                m4[u] = meta_s[kk];
+                b4[u] = zs[kk * TJ + jl];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int a = asym[u], b = bsym[u];
-                if (a >= 1 && a <= s && b >= 1 && b <= s)
-                    atomicAdd(&hist[(size_t)((a - 1) * s + (b - 1)) * TJ + jl], wv4[u]);
+                const unsigned a = (unsigned)(m4[u] >> 59);
+                const unsigned b = min(b4[u], qclamp);
+                const unsigned idx = __umul24(a, (unsigned)RS) + __umul24(b, (unsigned)TJ) + (unsigned)jl;
+                atomicAdd(&hist[idx], m4[u] & wmask);
             }
         }
     }
     __syncthreads();
 
     // ---- epilogue: histograms -> Pij_true (mode 0) or covariance C (mode 1) ----
+    // Pi' of column i and of the TJ columns of the block are staged in LDS first (the staging
+    // area is free now): the per-element math then touches LDS and registers only.
+    double *pi_i = reinterpret_cast<double *>(meta_s);  // [s]
+    double *pi_j = pi_i + 32;                            // [TJ * s]
+    if (mode == 1) {
+        for (int e = tid; e < s; e += TALLY_THREADS) pi_i[e] = Pi_pc[i * s + e];
+        for (int e = tid; e < TJ * s; e += TALLY_THREADS) {
+            const int jj = j0 + e / s;
+            pi_j[e] = (jj < N) ? Pi_pc[jj * s + (e % s)] : 0.0;
+        }
+    }
+    __syncthreads();
     const double Meff = *Meff_dev;
     const double pcq = pc / (double)q;
     const double off_add = pcq / (double)q;
@@ -155,11 +234,11 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
         const int l = rem / s, b = rem - l * s;
         const int jj = j0 + l;
         if (jj >= N || jj < i) continue;
-        const double pt = ldexp((double)hist[(size_t)(a * s + b) * TJ + l], -fix_shift) / Meff;
+        const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
         double v = pt;
         if (mode == 1) {
             const double pij = (jj != i) ? ((1.0 - pc) * pt + off_add) : ((1.0 - pc) * pt + ((a == b) ? pcq : 0.0));
-            v = pij - Pi_pc[i * s + a] * Pi_pc[jj * s + b];
+            v = pij - pi_i[a] * pi_j[rem];
         }
         out[(size_t)(jj * s + b) + (size_t)(i * s + a) * ld] = v;
     }
@@ -169,41 +248,40 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
         const int b = rem / s, a = rem - b * s;
         const int jj = j0 + l;
         if (jj >= N || jj <= i) continue;  // the diagonal block was written in full by pass 1
-        const double pt = ldexp((double)hist[(size_t)(a * s + b) * TJ + l], -fix_shift) / Meff;
+        const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
         double v = pt;
         if (mode == 1) {
             const double pij = (1.0 - pc) * pt + off_add;
-            v = pij - Pi_pc[i * s + a] * Pi_pc[jj * s + b];
+            v = pij - pi_i[a] * pi_j[l * s + b];
         }
         out[(size_t)(i * s + a) + (size_t)(jj * s + b) * ld] = v;
     }
 }
 
-void gdca_launch_pair_tally(hipStream_t st, const int8_t *Z, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,
+static size_t tally_lds_bytes(int s, int TJ)
+{
+    return (size_t)s * (s + 2) * TJ * 8 + (size_t)TALLY_CHUNK * 8 + (size_t)TALLY_CHUNK * TJ;
+}
+
+int gdca_tally_tj(int q)
+{
+    return tally_lds_bytes(q - 1, 32) <= 160 * 1024 ? 32 : 16;
+}
+
+void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,
                             int fix_shift, const double *Meff_dev, double pc, const double *Pi_pc, int mode,
                             double *out, size_t ld)
 {
     const int s = q - 1;
-    const size_t aux = (size_t)TALLY_CHUNK * 8 + TALLY_CHUNK;
-    if ((size_t)s * s * 32 * 8 + aux <= 160 * 1024) {
-        const size_t lds = (size_t)s * s * 32 * 8 + aux;
-        static bool attr32 = false;
-        if (!attr32) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr32 = true;
-        }
-        hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), lds, st, Z, Zt, Wfix, N, M,
-                           q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+    if (gdca_tally_tj(q) == 32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, Zc,
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
     } else {
-        const size_t lds = (size_t)s * s * 16 * 8 + aux;
-        static bool attr16 = false;
-        if (!attr16) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr16 = true;
-        }
-        hipLaunchKernelGGL(k_pair_tally<16>, dim3((N + 15) / 16, N), dim3(TALLY_THREADS), lds, st, Z, Zt, Wfix, N, M,
-                           q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_pair_tally<16>, dim3((N + 15) / 16, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 16), st, Zc,
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
     }
 }

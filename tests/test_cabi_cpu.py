@@ -1,0 +1,110 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/gdca.h declares, and fails loudly (no CPU fallback) when no GPU is present.  No compute."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gaussdca.jl_amd", "libgdca.so")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    if not os.path.exists(LIB):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "gaussdca.jl_amd", "csrc"), "-j8"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gdca.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gdca_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(lib_path):
+    names = _declared_symbols()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gdca.h but not exported by libgdca.so"
+
+
+def test_python_binding_covers_the_header(lib_path):
+    from gaussdca.jl_amd import _lib
+
+    assert sorted(_lib.SYMBOLS) == _declared_symbols()
+    lib = _lib.load()
+    assert lib.gdca_version() == 1
+    assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 8 + 8 * 9
+    assert ctypes.sizeof(_lib.Params) == 24
+
+
+def test_no_cpu_fallback(lib_path):
+    """Without a GPU every product entry point must raise; nothing may route through the oracle."""
+    import gaussdca.jl_amd as g
+
+    lib = g.load()
+    if lib.gdca_device_count() > 0:
+        pytest.skip("a HIP device is visible here")
+    with pytest.raises(g.GdcaError):
+        g.Context(0)
+    with pytest.raises(g.GdcaError):
+        g.compute_weights(np.ones((4, 5), dtype=np.int8), 21, 0.2)
+    h = ctypes.c_void_p()
+    assert lib.gdca_ctx_create(0, ctypes.byref(h)) != 0 and not h.value
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gaussdca.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "gdca_oracle" not in txt, f
+
+
+def test_argument_checks_mirror_reference(tmp_path):
+    """check_arguments: same order and conditions as src/GaussDCA.jl:49-65 (host side, no GPU)."""
+    import gaussdca.jl_amd as g
+
+    f = os.path.join(ROOT, "tests", "golden", "reference", "small.fasta.gz")
+    assert g.check_arguments(f, 0.8, ":auto", 0.9, ":frob", 5)
+    assert g.check_arguments(f, 0.2, 0.0, 0.8, "DI", 4)
+    for args in [(f, 1.5, ":auto", 0.9, ":frob", 5), (f, 0.8, -0.1, 0.9, ":frob", 5),
+                 (f, 0.8, ":bogus", 0.9, ":frob", 5), (f, 0.8, ":auto", 2.0, ":frob", 5),
+                 (f, 0.8, ":auto", 0.9, ":plm", 5), (f, 0.8, ":auto", 0.9, ":frob", 0),
+                 (str(tmp_path / "missing.fasta"), 0.8, ":auto", 0.9, ":frob", 5)]:
+        with pytest.raises(g.ArgumentError):
+            g.check_arguments(*args)
+
+
+def test_host_fasta_dedup_ranking_match_oracle(refdata):
+    """The host-side pieces around the hot path (FASTA reader, dedup, ranking, printrank)."""
+    import io
+
+    import gaussdca.jl_amd as g
+    from oracle import gdca_oracle as o
+
+    for name, mgf in (("small.fasta.gz", 0.9), ("large.fasta.gz", 0.9), ("small.fasta.gz", 0.8)):
+        p = os.path.join(refdata, name)
+        Z = g.read_fasta_alignment(p, mgf)           # (N, M), Fortran order
+        Zo = o.read_fasta_alignment(p, mgf)          # (M, N), C order
+        assert Z.flags.f_contiguous and Z.dtype == np.int8
+        assert np.array_equal(Z.T, Zo)
+        Zu, idx = g.remove_duplicate_sequences(Z)
+        Zou, idxo = o.remove_duplicate_sequences(Zo)
+        assert np.array_equal(Zu.T, Zou) and np.array_equal(idx, idxo + 1)
+    rng = np.random.default_rng(0)
+    S = rng.random((30, 30))
+    S = S + S.T
+    S[3, 20] = S[20, 3] = S[4, 25] = S[25, 4] = 0.123  # an exact tie: generation order must be kept
+    for sep in (1, 4, 5, 29, 30):
+        assert g.compute_ranking(S, sep) == o.compute_ranking(S, sep)
+    buf = io.StringIO()
+    g.printrank(buf, [(11, 35, 3.649475), (9, 46, -0.6752293)])
+    assert buf.getvalue() == "11 35 3.649475e+00\n9 46 -6.752293e-01\n"

@@ -30,6 +30,84 @@ __global__ __launch_bounds__(512) void k_lds_atomic(T *out, int iters, int rows)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// ---- tally-loop replica: per wave-instruction 2 LDS reads (b64 broadcast per half-wave + u8) and
+// one ds_add_u64; `same_pct` = percent of instructions whose two half-waves use the same row set ----
+__global__ __launch_bounds__(512) void k_tally_like(unsigned long long *out, int iters, int same_pct, int with_reads)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(sm);       // [400][32]
+    unsigned long long *meta = h + 400 * 32 + 64;                              // [512]
+    unsigned char *zs = reinterpret_cast<unsigned char *>(meta + 512);        // [512][32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < 400 * 32 + 64; e += blockDim.x) h[e] = 0;
+    unsigned rng = tid * 2654435761u + 12345u;
+    // per-sequence a (1..20) and weight; per (seq, col) b (1..20)
+    {
+        unsigned r2 = (tid >> (same_pct >= 100 ? 9 : 0)) * 747796405u + 2891336453u;
+        r2 ^= r2 >> 15;
+        unsigned a = 1 + (r2 % 20);
+        if (same_pct < 0 && ((r2 >> 12) % 100) < (unsigned)(-same_pct)) a = 3;  // skewed: dominant symbol
+        if (same_pct > 0 && same_pct < 100 && (tid & 1) && ((r2 >> 8) % 100) < (unsigned)same_pct) a = 0x80;  // marker: copy partner
+        meta[tid] = ((unsigned long long)a << 56) | (rng & 0xffffff);
+        for (int c = 0; c < 32; ++c) {
+            rng = rng * 1664525u + 1013904223u;
+            zs[tid * 32 + c] = 1 + ((rng >> 10) % 20);
+            if (same_pct < 0 && ((rng >> 20) % 100) < (unsigned)(-same_pct)) zs[tid * 32 + c] = 1 + (c % 20);  // conserved column
+        }
+    }
+    __syncthreads();
+    if (same_pct > 0 && same_pct < 100 && (tid & 1)) {
+        if ((meta[tid] >> 56) == 0x80) {  // make sequence tid identical to tid-1 (same a, same b's)
+            meta[tid] = meta[tid - 1];
+            for (int c = 0; c < 32; ++c) zs[tid * 32 + c] = zs[(tid - 1) * 32 + c];
+        }
+    }
+    __syncthreads();
+    const int jl = lane & 31, sub = lane >> 5;
+    for (int it = 0; it < iters; ++it) {
+        const int kk = wv * 64 + ((it * 2) & 63) + sub;
+        unsigned long long m;
+        int b;
+        if (with_reads) {
+            m = meta[kk];
+            b = zs[kk * 32 + jl];
+        } else {
+            m = ((unsigned long long)(1 + (it + sub * 7) % 20) << 56) | 5;
+            b = 1 + ((it * 3 + lane) % 20);
+        }
+        const unsigned a = (unsigned)(m >> 56);
+        const unsigned idx = ((a - 1) * 20 + (b - 1)) * 32 + jl;
+        atomicAdd(&h[idx], m & 0xffffffull);
+    }
+    __syncthreads();
+    unsigned long long acc = 0;
+    for (int e = tid; e < 400 * 32; e += blockDim.x) acc += h[e];
+    out[blockIdx.x * blockDim.x + tid] = acc;
+}
+
+int run_tally_like(int same_pct, int with_reads)
+{
+    const int blocks = 256, threads = 512, iters = 20000;
+    unsigned long long *out;
+    CK(hipMalloc(&out, 8 * blocks * threads));
+    size_t lds = 8 * (400 * 32 + 64) + 8 * 512 + 512 * 32;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tally_like), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_tally_like, dim3(blocks), dim3(threads), lds, 0, out, 100, same_pct, with_reads);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_tally_like, dim3(blocks), dim3(threads), lds, 0, out, iters, same_pct, with_reads);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("tally-like same_pct=%3d reads=%d: %.3f ms, %.2f clk@2.4GHz per wave-instr per CU\n", same_pct, with_reads, ms,
+           ms * 1e-3 * 2.4e9 / ((double)iters * threads / 64));
+    CK(hipFree(out));
+    return 0;
+}
+
 // ---- f64 MFMA / VALU probes with clocks ----
 __global__ __launch_bounds__(256) void k_probe(double *out, long long *clk, int iters, int mode)
 {
@@ -139,6 +217,13 @@ int run_atomic(const char *name, int rows)
 
 int main()
 {
+    run_tally_like(0, 0);
+    run_tally_like(0, 1);
+    run_tally_like(30, 1);
+    run_tally_like(100, 1);
+    run_tally_like(-30, 1);
+    run_tally_like(-60, 1);
+    run_tally_like(-90, 1);
     run_atomic<unsigned long long>("u64", 400);
     run_atomic<unsigned int>("u32", 400);
     run_atomic<unsigned int>("u32", 1200);
