@@ -23,7 +23,7 @@ struct gdca_ctx {
     bool timing;
     char err[512];
     // named device buffers (grow-only)
-    gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, G2, H2, P, Dblk, Ld, colsum, sc;
+    gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, G2, H2, P, Dblk, Ld, Tws, colsum, sc;
     hipStream_t side;          // look-ahead stream of the SPD inverse
     bool lookahead;
     hipEvent_t sev[MAX_EV];    // cross-stream ordering events
@@ -148,7 +148,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->G2, &ctx->H2, &ctx->P, &ctx->Dblk, &ctx->Ld,
-                        &ctx->colsum, &ctx->sc};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -312,7 +312,9 @@ static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int sc
 {
     hipStream_t s = ctx->stream;
     if (score == GDCA_SCORE_DI) {
-        gdca_launch_di(s, (const double *)ctx->A.p, (size_t)n_pad, (const double *)ctx->Ld.p, N, sdim, S_dev);
+        CHK(ensure(ctx, ctx->Tws, gdca_di_ws_bytes(N, sdim)));
+        gdca_launch_di(s, (const double *)ctx->A.p, (size_t)n_pad, (const double *)ctx->Ld.p, N, sdim, S_dev,
+                       (double *)ctx->Tws.p);
     } else {
         gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev);
     }

@@ -96,5 +96,8 @@ void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int block
 void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S);
 // Ld[i] = chol(D[i]) lower, packed s x s
 void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, double *Ld);
-void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S);
+// Tws: workspace of gdca_di_ws_bytes(N, sdim) bytes (tridiagonals of all site pairs)
+size_t gdca_di_ws_bytes(int N, int sdim);
+void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S,
+                    double *Tws);
 void gdca_launch_apc(hipStream_t s, double *S, int N, double *rowsum_ws);

@@ -119,129 +119,192 @@ void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, doub
 }
 
 // ---- DI ---------------------------------------------------------------------------------------------
-#define DI_MAX_SWEEPS 14
-
-__global__ __launch_bounds__(64) void k_di(const double *__restrict__ A, size_t ld, const double *__restrict__ Ld,
-                                            int N, int sdim, double *__restrict__ S)
+// gamma = eigenvalues of V = MM MM^T, MM = L_j^T X L_i (s x s).  Two kernels:
+//   k_di_tridiag: one wave per site pair -- the three small products, then a Householder reduction of
+//                 V to tridiagonal form (4/3 s^3 flops; lanes <-> matrix elements, reflector vectors
+//                 broadcast through LDS).  Writes the diagonal / sub-diagonal to HBM, index-major.
+//   k_di_ql:      one LANE per site pair -- implicit QL (EISPACK tql1) on its tridiagonal, eigenvalues
+//                 only, then DI = z + 1/2 sum log(1 + sqrt(1 + 4 gamma)).
+// ~10x fewer flops than a Jacobi sweep on the full matrix, and the serial part (QL) runs 64 pairs wide.
+__global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A, size_t ld,
+                                                    const double *__restrict__ Ld, int sdim, long long npairs,
+                                                    long long tstride, double *__restrict__ Td,
+                                                    double *__restrict__ Te)
 {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     const int lane = threadIdx.x;
     const int ss = sdim * sdim;
-    double *B0 = dsm, *B1 = dsm + ss, *B2 = dsm + 2 * ss, *B3 = dsm + 3 * ss;
-    double *alpha = dsm + 4 * ss;      // [32] rotation cos per index
-    double *beta = alpha + 32;         // [32] signed sin per index
-    int *partner = reinterpret_cast<int *>(beta + 32);  // [32]
-
+    double *B0 = dsm, *B1 = dsm + ss;
+    double *vv = dsm + 2 * ss;  // [32] reflector
+    double *ww = vv + 32;       // [32]
+    const long long pair = blockIdx.x;
     int i, j;
-    pair_decode((long long)blockIdx.x, i, j);
+    pair_decode(pair, i, j);
     const double *src = A + (size_t)j * sdim + (size_t)i * sdim * ld;
+    const double *Li = Ld + (size_t)i * ss, *Lj = Ld + (size_t)j * ss;
     for (int e = lane; e < ss; e += 64) {
         const int r = e % sdim, c = e / sdim;
-        B0[e] = src[(size_t)r + (size_t)c * ld];        // X (r, c), column-major
-        B1[e] = Ld[(size_t)i * ss + e];                 // L_i
-        B2[e] = Ld[(size_t)j * ss + e];                 // L_j
+        B0[e] = src[(size_t)r + (size_t)c * ld];  // X(r, c), column-major
     }
     __syncthreads();
     // T1 = X L_i :  T1(r,c) = sum_{m >= c} X(r,m) L_i(m,c)
     for (int e = lane; e < ss; e += 64) {
         const int r = e % sdim, c = e / sdim;
         double a = 0.0;
-        for (int m = c; m < sdim; ++m) a += B0[r + m * sdim] * B1[m + c * sdim];
-        B3[e] = a;
+        for (int m = c; m < sdim; ++m) a += B0[r + m * sdim] * Li[m + c * sdim];
+        B1[e] = a;
     }
     __syncthreads();
     // MM = L_j^T T1 :  MM(r,c) = sum_{m >= r} L_j(m,r) T1(m,c)
     for (int e = lane; e < ss; e += 64) {
         const int r = e % sdim, c = e / sdim;
         double a = 0.0;
-        for (int m = r; m < sdim; ++m) a += B2[m + r * sdim] * B3[m + c * sdim];
+        for (int m = r; m < sdim; ++m) a += Lj[m + r * sdim] * B1[m + c * sdim];
         B0[e] = a;
     }
     __syncthreads();
-    // V = MM MM^T (symmetric): V(r,c) = sum_m MM(r,m) MM(c,m)
+    // V = MM MM^T, computed from the ordered index pair so that it is bitwise symmetric
     for (int e = lane; e < ss; e += 64) {
         const int r = e % sdim, c = e / sdim;
-        const int rr = r >= c ? r : c, cc = r >= c ? c : r;  // compute from the ordered pair: bitwise symmetric
+        const int rr = r >= c ? r : c, cc = r >= c ? c : r;
         double a = 0.0;
         for (int m = 0; m < sdim; ++m) a += B0[rr + m * sdim] * B0[cc + m * sdim];
         B1[e] = a;
     }
     __syncthreads();
 
-    // cyclic Jacobi, round-robin ordering over ne = even(s) players (a dummy player if s is odd)
-    double *V = B1, *Vn = B2;
-    const int ne = (sdim + 1) & ~1, np = ne / 2;
-    double frob2 = 0.0;
-    for (int e = lane; e < ss; e += 64) frob2 += V[e] * V[e];
-    frob2 = wave_sum(frob2);
-    for (int sweep = 0; sweep < DI_MAX_SWEEPS; ++sweep) {
-        double off2 = 0.0;
-        for (int e = lane; e < ss; e += 64) {
-            const int r = e % sdim, c = e / sdim;
-            if (r != c) off2 += V[e] * V[e];
-        }
-        off2 = wave_sum(off2);
-        if (off2 <= 1e-30 * frob2) break;
-        for (int round = 0; round < ne - 1; ++round) {
-            if (lane < np) {
-                int pp, qq;
-                if (lane == 0) {
-                    pp = ne - 1;
-                    qq = round;
-                } else {
-                    pp = (round + lane) % (ne - 1);
-                    qq = (round - lane + (ne - 1)) % (ne - 1);
-                }
-                if (pp > qq) {
-                    const int t = pp;
-                    pp = qq;
-                    qq = t;
-                }
-                double c = 1.0, sn = 0.0;
-                if (qq < sdim) {
-                    const double app = V[pp + pp * sdim], aqq = V[qq + qq * sdim], apq = V[pp + qq * sdim];
-                    if (apq != 0.0) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = 1.0 / sqrt(1.0 + t * t);
-                        sn = t * c;
-                    }
-                    alpha[pp] = c;
-                    beta[pp] = -sn;
-                    partner[pp] = qq;
-                    alpha[qq] = c;
-                    beta[qq] = sn;
-                    partner[qq] = pp;
-                } else if (pp < sdim) {  // paired with the dummy player: identity
-                    alpha[pp] = 1.0;
-                    beta[pp] = 0.0;
-                    partner[pp] = pp;
-                }
+    double *V = B1;
+    for (int k = 0; k + 2 < sdim; ++k) {
+        const int m = sdim - k - 1;                  // order of the trailing block V22 = V[k+1.., k+1..]
+        const double *x = V + (k + 1) + k * sdim;    // x[t] = V(k+1+t, k)
+        const double xt = (lane < m) ? x[lane] : 0.0;
+        const double sigma = wave_sum(xt * xt);
+        const double x0 = x[0];
+        const double tail = sigma - x0 * x0;
+        double alpha = x0;  // sub-diagonal entry if the column is already reduced
+        if (tail > 0.0 && sigma > 0.0) {
+            alpha = (x0 >= 0.0) ? -sqrt(sigma) : sqrt(sigma);
+            const double v0 = x0 - alpha;
+            const double beta = 2.0 / (tail + v0 * v0);
+            if (lane < m) vv[lane] = (lane == 0) ? v0 : xt;
+            __syncthreads();
+            // p = beta V22 v   (lane r < m owns row r)
+            double pr = 0.0;
+            if (lane < m) {
+                const double *row = V + (k + 1 + lane) + (k + 1) * sdim;
+                for (int c = 0; c < m; ++c) pr += row[c * sdim] * vv[c];
+                pr *= beta;
+            }
+            const double pv = wave_sum((lane < m) ? pr * vv[lane] : 0.0);
+            const double K = 0.5 * beta * pv;
+            if (lane < m) ww[lane] = pr - K * vv[lane];
+            __syncthreads();
+            // V22 -= v w^T + w v^T
+            for (int e = lane; e < m * m; e += 64) {
+                const int r = e % m, c = e / m;
+                V[(k + 1 + r) + (k + 1 + c) * sdim] -= vv[r] * ww[c] + ww[r] * vv[c];
             }
             __syncthreads();
-            for (int e = lane; e < ss; e += 64) {
-                const int r = e % sdim, c = e / sdim;
-                const int rp = partner[r], cp = partner[c];
-                const double ar = alpha[r], br = beta[r], ac = alpha[c], bc = beta[c];
-                const double v = ar * (ac * V[r + c * sdim] + bc * V[r + cp * sdim]) +
-                                 br * (ac * V[rp + c * sdim] + bc * V[rp + cp * sdim]);
-                Vn[e] = v;
-            }
-            __syncthreads();
-            double *tmp = V;
-            V = Vn;
-            Vn = tmp;
+        }
+        if (lane == 0) {
+            Td[(size_t)k * tstride + pair] = V[k + k * sdim];
+            Te[(size_t)k * tstride + pair] = alpha;
         }
     }
-    // DI = z + 0.5 sum_k log(1 + sqrt(1 + 4 gamma_k)),  z = 0.5 s log 0.5
-    double acc = 0.0;
-    if (lane < sdim) {
-        double g = V[lane + lane * sdim];
-        g = g > 0.0 ? g : 0.0;
-        acc = log(1.0 + sqrt(1.0 + 4.0 * g));
-    }
-    acc = wave_sum(acc);
     if (lane == 0) {
+        if (sdim >= 2) {
+            const int k = sdim - 2;
+            Td[(size_t)k * tstride + pair] = V[k + k * sdim];
+            Te[(size_t)k * tstride + pair] = V[(k + 1) + k * sdim];
+        }
+        Td[(size_t)(sdim - 1) * tstride + pair] = V[(sdim - 1) + (sdim - 1) * sdim];
+        Te[(size_t)(sdim - 1) * tstride + pair] = 0.0;
+    }
+}
+
+__device__ __forceinline__ double pythag(double a, double b)
+{
+    return sqrt(a * a + b * b);
+}
+
+__global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, const double *__restrict__ Te,
+                                               long long tstride, long long npairs, int N, int sdim,
+                                               double *__restrict__ S)
+{
+    extern __shared__ __attribute__((aligned(16))) double qsm[];
+    const int lane = threadIdx.x;
+    double *d = qsm + lane;                 // d[t * 64]
+    double *e = qsm + (size_t)sdim * 64 + lane;  // e[t * 64]
+    const long long pair = (long long)blockIdx.x * 64 + lane;
+    const bool live = pair < npairs;
+    const long long pp = live ? pair : npairs - 1;
+    const int n = sdim;
+    // e[t] = sub-diagonal between t and t+1 (already "shifted down" in tql1's convention), e[n-1] = 0
+    for (int t = 0; t < n; ++t) {
+        d[t * 64] = Td[(size_t)t * tstride + pp];
+        e[t * 64] = Te[(size_t)t * tstride + pp];
+    }
+    double f = 0.0, tst1 = 0.0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0;
+        const double h0 = fabs(d[l * 64]) + fabs(e[l * 64]);
+        if (tst1 < h0) tst1 = h0;
+        int m = l;
+        while (m < n - 1) {
+            if (tst1 + fabs(e[m * 64]) == tst1) break;
+            ++m;
+        }
+        if (m != l) {
+            double tst2;
+            do {
+                if (++iter > 40) break;
+                // form shift
+                const int l1 = l + 1;
+                double g = d[l * 64];
+                double p = (d[l1 * 64] - g) / (2.0 * e[l * 64]);
+                double r = pythag(p, 1.0);
+                const double sr = (p >= 0.0) ? fabs(r) : -fabs(r);
+                d[l * 64] = e[l * 64] / (p + sr);
+                d[l1 * 64] = e[l * 64] * (p + sr);
+                const double dl1 = d[l1 * 64];
+                double h = g - d[l * 64];
+                for (int t = l1 + 1; t < n; ++t) d[t * 64] -= h;
+                f += h;
+                // QL transformation
+                p = d[m * 64];
+                double c = 1.0, c2 = 1.0, c3 = 1.0;
+                const double el1 = e[l1 * 64];
+                double s = 0.0, s2 = 0.0;
+                for (int t = m - 1; t >= l; --t) {
+                    c3 = c2;
+                    c2 = c;
+                    s2 = s;
+                    g = c * e[t * 64];
+                    h = c * p;
+                    r = pythag(p, e[t * 64]);
+                    e[(t + 1) * 64] = s * r;
+                    s = e[t * 64] / r;
+                    c = p / r;
+                    p = c * d[t * 64] - s * g;
+                    d[(t + 1) * 64] = h + s * (c * g + s * d[t * 64]);
+                }
+                p = -s * s2 * c3 * el1 * e[l * 64] / dl1;
+                e[l * 64] = s * p;
+                d[l * 64] = c * p;
+                tst2 = tst1 + fabs(e[l * 64]);
+            } while (tst2 > tst1);
+        }
+        d[l * 64] = d[l * 64] + f;  // eigenvalue l (unordered)
+    }
+    if (live) {
+        double acc = 0.0;
+        for (int t = 0; t < n; ++t) {
+            double gm = d[t * 64];
+            gm = gm > 0.0 ? gm : 0.0;
+            acc += log(1.0 + sqrt(1.0 + 4.0 * gm));
+        }
+        int i, j;
+        pair_decode(pair, i, j);
         const double z = 0.5 * (double)sdim * log(0.5);
         const double v = z + 0.5 * acc;
         S[(size_t)i + (size_t)j * N] = v;
@@ -249,13 +312,25 @@ __global__ __launch_bounds__(64) void k_di(const double *__restrict__ A, size_t 
     }
 }
 
-void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S)
+void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S,
+                    double *Tws)
 {
     (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
     const long long npairs = (long long)N * (N - 1) / 2;
     if (npairs <= 0) return;
-    const size_t lds = (size_t)(4 * sdim * sdim + 64) * sizeof(double) + 32 * sizeof(int);
-    hipLaunchKernelGGL(k_di, dim3((unsigned)npairs), dim3(64), lds, s, A, ld, Ld, N, sdim, S);
+    const long long tstride = (npairs + 63) / 64 * 64;
+    double *Td = Tws, *Te = Tws + (size_t)sdim * tstride;
+    const size_t lds1 = (size_t)(2 * sdim * sdim + 64) * sizeof(double);
+    hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)npairs), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
+    const size_t lds2 = (size_t)2 * sdim * 64 * sizeof(double);
+    hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S);
+}
+
+size_t gdca_di_ws_bytes(int N, int sdim)
+{
+    const long long npairs = (long long)N * (N - 1) / 2;
+    const long long tstride = (npairs + 63) / 64 * 64;
+    return (size_t)2 * sdim * (tstride > 0 ? tstride : 64) * sizeof(double);
 }
 
 // ---- APC --------------------------------------------------------------------------------------------
