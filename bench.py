@@ -49,11 +49,24 @@ def synth_family(N, M, q, seed):
     return np.ascontiguousarray(Z.astype(np.int8))
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/r01_pmc_update_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes);
+    None when the file is absent or the workload differs from the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_update_traffic.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(N, M, q, pc, budget_s=20.0):
-    """The oracle ("port": numpy + OpenMP C loops + OpenBLAS dpotrf/dpotri) timed on the host cores
-    on a bounded sample of the same workload: the Hamming pass on a sequence subsample (cost
-    scaled by pairs), the tallies on a sequence subsample (cost linear in M), the SPD inverse at
-    reduced n (cost scaled by n^3) and FN in full.  Returns an estimate of seconds per family."""
+    """The oracle ("port": numpy + OpenMP/AVX2 C loops + OpenBLAS dpotrf/dpotri) timed on all host
+    cores on a bounded sample of the same workload (about `budget_s` seconds of CPU work): the
+    all-pairs Hamming pass on a sequence subsample sized from a probe (cost scaled by the pair
+    count), the tallies on a sequence subsample (cost linear in M), the SPD inverse at the full n
+    when a probe says it fits the budget (else at reduced n, cost scaled by n^3), pseudocount /
+    covariance / FN / APC in full.  Returns an estimate of seconds per family."""
     import numpy as np
 
     from oracle import gdca_oracle as o
@@ -61,39 +74,52 @@ def cpu_baseline(N, M, q, pc, budget_s=20.0):
     cores = os.cpu_count() or 1
     o.set_threads(cores)
     s = q - 1
+    n = N * s
     t_all = time.time()
-    Ms = min(M, 6000)
-    Zs = synth_family(N, Ms, q, 0xC500)
+    Zfull = synth_family(N, M, q, 0xC500)
+    theta = o.compute_theta(Zfull)
+    thr = o.hamming_threshold(theta, N)
+    # Hamming: probe on 3000 sequences, then a sample sized for ~35 % of the budget
+    Mp = min(M, 3000)
     t = time.time()
-    thr = o.hamming_threshold(o.compute_theta(Zs), N)
-    n = o.neighbour_counts(Zs, thr)
+    o.neighbour_counts(Zfull[:Mp], thr)
+    rate = (Mp * (Mp - 1.0) / 2) / max(1e-6, time.time() - t)          # pairs per second
+    Ms = int(min(M, max(Mp, (2 * 0.35 * budget_s * rate) ** 0.5)))
+    t = time.time()
+    n_k = o.neighbour_counts(Zfull[:Ms], thr)
     t_ham = (time.time() - t) * (M * (M - 1.0)) / (Ms * (Ms - 1.0))
-    W, Meff = o.weights_from_counts(n)
-    Mt = min(Ms, 2000)
+    W, Meff = o.weights_from_counts(n_k)
+    # tallies: linear in M
+    Mt = min(Ms, 4000)
     t = time.time()
-    Pi, Pij = o.compute_frequencies(Zs[:Mt], q, W[:Mt], float(W[:Mt].sum()))
+    Pi, Pij = o.compute_frequencies(Zfull[:Mt], q, W[:Mt], float(W[:Mt].sum()))
     t_freq = (time.time() - t) * (M / Mt)
     t = time.time()
     Pi2, Pij2 = o.add_pseudocount(Pi, Pij, pc, q)
     C = o.compute_C(Pi2, Pij2)
     t_cov = time.time() - t
-    ns = min(N * s, 4000)
+    # SPD inverse: probe at n/4, then full size if it fits
+    npb = max(256, n // 4)
+    t = time.time()
+    o.spd_inverse(np.ascontiguousarray(C[:npb, :npb]))
+    est_full = (time.time() - t) * (n / npb) ** 3
+    ns = n if est_full < 0.4 * budget_s else max(npb, int(n * (0.4 * budget_s / est_full) ** (1 / 3)))
     Cs = np.ascontiguousarray(C[:ns, :ns])
     t = time.time()
-    o.spd_inverse(Cs)
-    t_inv = (time.time() - t) * (N * s / ns) ** 3
-    mJ = o.spd_inverse(C) if N * s <= 4000 else C  # FN cost does not depend on the values
+    mJs = o.spd_inverse(Cs)
+    t_inv = (time.time() - t) * (n / ns) ** 3
+    mJ = mJs if ns == n else C  # FN cost does not depend on the values
     t = time.time()
     o.correct_APC(o.compute_FN(mJ, q))
     t_fn = time.time() - t
     est = t_ham + t_freq + t_cov + t_inv + t_fn
     return dict(value=1.0 / est, unit="families/s", cores=cores, kind="port",
                 sec_per_family_est=est,
-                sample=("oracle (numpy + OpenMP C + OpenBLAS potrf/potri) on %d host threads: Hamming on %d of %d "
-                        "sequences (x pairs ratio), tallies on %d sequences (x M ratio), potrf+potri at n=%d "
-                        "(x n^3 ratio), pseudocount/covariance/FN/APC in full; stage seconds "
-                        "ham=%.2f freq=%.2f cov=%.2f inv=%.2f fn=%.2f; sample wall %.1fs"
-                        % (cores, Ms, M, Mt, ns, t_ham, t_freq, t_cov, t_inv, t_fn, time.time() - t_all)))
+                sample=("oracle (numpy + OpenMP/AVX2 C + OpenBLAS potrf/potri) on %d host threads: Hamming on %d of %d "
+                        "sequences (x pairs ratio), tallies on %d sequences (x M ratio), potrf+potri at n=%d of %d "
+                        "(x n^3 ratio), pseudocount/covariance/FN/APC in full; stage seconds (scaled to the full "
+                        "family) ham=%.2f freq=%.2f cov=%.2f inv=%.2f fn=%.2f; sample wall %.1fs"
+                        % (cores, Ms, M, Mt, ns, n, t_ham, t_freq, t_cov, t_inv, t_fn, time.time() - t_all)))
 
 
 def main():
@@ -195,7 +221,7 @@ def main():
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(),
                 "launches_per_step": upd_launch,
                 "flops_per_launch": upd_flops / max(1, upd_launch),
                 "avg_launch_ms": upd_ms / max(1, upd_launch),

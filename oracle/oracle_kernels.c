@@ -17,6 +17,9 @@
  */
 #include <math.h>
 #include <stdint.h>
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -36,8 +39,26 @@ int orc_set_threads(int n)
 
 static inline int hamming_bytes(const int8_t *a, const int8_t *b, int N)
 {
-    int d = 0;
-    for (int i = 0; i < N; ++i) d += (a[i] != b[i]);
+    int d = 0, i = 0;
+#ifdef __AVX2__
+    /* 32 symbol compares per instruction: the byte-wise counterpart of the 5-bit packed XOR/popcount
+     * DCAUtils uses on UInt64 words */
+    while (i + 32 <= N) {
+        __m256i acc = _mm256_setzero_si256();
+        int blocks = (N - i) / 32;
+        if (blocks > 255) blocks = 255;
+        for (int t = 0; t < blocks; ++t, i += 32) {
+            const __m256i va = _mm256_loadu_si256((const __m256i *)(a + i));
+            const __m256i vb = _mm256_loadu_si256((const __m256i *)(b + i));
+            acc = _mm256_sub_epi8(acc, _mm256_cmpeq_epi8(va, vb)); /* +1 per equal byte */
+        }
+        const __m256i sad = _mm256_sad_epu8(acc, _mm256_setzero_si256());
+        const int eq = (int)(_mm256_extract_epi64(sad, 0) + _mm256_extract_epi64(sad, 1) + _mm256_extract_epi64(sad, 2) +
+                             _mm256_extract_epi64(sad, 3));
+        d += blocks * 32 - eq;
+    }
+#endif
+    for (; i < N; ++i) d += (a[i] != b[i]);
     return d;
 }
 
