@@ -57,6 +57,7 @@ SYMBOLS = {
     "gdca_device_count": (C.c_int32, []),
     "gdca_ctx_create": (C.c_int, [C.c_int32, C.POINTER(_ctx)]),
     "gdca_ctx_create_on_stream": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(_ctx)]),
+    "gdca_ctx_create_peer": (C.c_int, [_ctx, C.POINTER(_ctx)]),
     "gdca_ctx_destroy": (C.c_int, [_ctx]),
     "gdca_ctx_synchronize": (C.c_int, [_ctx]),
     "gdca_last_error": (C.c_char_p, [_ctx]),
@@ -65,6 +66,8 @@ SYMBOLS = {
                            C.POINTER(Stats)]),
     "gdca_run_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
                                C.POINTER(Stats)]),
+    "gdca_run_dev_async": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p]),
+    "gdca_run_collect": (C.c_int, [_ctx, C.POINTER(Stats)]),
     "gdca_pair_identity_sum": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _u64p]),
     "gdca_compute_theta": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _f64p]),
     "gdca_neighbour_counts": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -110,10 +113,13 @@ def _p(a: np.ndarray) -> C.c_void_p:
 class Context:
     """One gdca_ctx = one HIP device + one stream + its workspace."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, _peer_of: "Context | None" = None):
         self.lib = load()
         h = _ctx()
-        if stream is None:
+        if _peer_of is not None:
+            st = self.lib.gdca_ctx_create_peer(_peer_of.h, C.byref(h))
+            device = _peer_of.device
+        elif stream is None:
             st = self.lib.gdca_ctx_create(int(device), C.byref(h))
         else:
             st = self.lib.gdca_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h))
@@ -122,6 +128,10 @@ class Context:
                             "(the gDCA hot path has no CPU fallback)")
         self.h = h
         self.device = int(device)
+
+    def peer(self) -> "Context":
+        """Another context on the same GPU whose inverse stages alternate with this one's (pipeline)."""
+        return Context(_peer_of=self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -171,6 +181,20 @@ class Context:
         st = Stats()
         rc = self.lib.gdca_run_dev(self.h, C.c_void_p(Z_ptr), N, M, int(q), C.byref(prm), C.c_void_p(S_ptr),
                                    C.byref(st))
+        self.check(rc, st.info)
+        return st.as_dict()
+
+
+    def run_dev_async(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int,
+                      S_ptr: int, apc: bool = True):
+        """Enqueue only (no host synchronisation); pair with collect()."""
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        self.check(self.lib.gdca_run_dev_async(self.h, C.c_void_p(Z_ptr), N, M, int(q), C.byref(prm),
+                                               C.c_void_p(S_ptr)))
+
+    def collect(self):
+        st = Stats()
+        rc = self.lib.gdca_run_collect(self.h, C.byref(st))
         self.check(rc, st.info)
         return st.as_dict()
 

@@ -16,8 +16,17 @@ struct gdca_buf {
     size_t cap;
 };
 
+// Shared by the contexts of one pipeline (gdca_ctx_create_peer): orders their SPD-inverse stages one after
+// the other on the device, so that only the non-MFMA stages of the next family overlap the inverse of the
+// current one (two interleaved inverses would just halve each other's MFMA rate).
+struct gdca_gate {
+    hipEvent_t ev[4];
+    int next, last, armed, refs;
+};
+
 struct gdca_ctx {
     int device;
+    gdca_gate *gate;
     hipStream_t stream;
     bool own_stream;
     bool timing;
@@ -32,6 +41,11 @@ struct gdca_ctx {
     gdca_dev_scalars *sc_host;  // pinned
     hipEvent_t ev[MAX_EV];
     int n_ev;
+    // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
+    bool pending;
+    bool pend_timed;
+    int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
+    double pend_upd_flops;
 };
 
 static gdca_status fail(gdca_ctx *ctx, gdca_status st, const char *fmt, const char *a, const char *b)
@@ -141,6 +155,25 @@ gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
     return GDCA_OK;
 }
 
+gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
+{
+    if (!leader || !out) return GDCA_EINVAL;
+    gdca_ctx *ctx = leader;
+    HIPCHK(hipSetDevice(leader->device));
+    if (!leader->gate) {
+        gdca_gate *g = (gdca_gate *)calloc(1, sizeof(gdca_gate));
+        if (!g) return GDCA_ENOMEM;
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
+        g->refs = 1;
+        leader->gate = g;
+    }
+    gdca_status st = gdca_ctx_create(leader->device, out);
+    if (st != GDCA_OK) return st;
+    (*out)->gate = leader->gate;
+    leader->gate->refs += 1;
+    return GDCA_OK;
+}
+
 gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
 {
     if (!ctx) return GDCA_EINVAL;
@@ -153,6 +186,10 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
         if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
+    if (ctx->gate && --ctx->gate->refs == 0) {
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->gate->ev[i]);
+        free(ctx->gate);
+    }
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < ctx->n_sev; ++i) (void)hipEventDestroy(ctx->sev[i]);
     if (ctx->side) {
@@ -351,8 +388,58 @@ static gdca_status begin(gdca_ctx *ctx)
 
 extern "C" {
 
-gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,
-                         double *S_dev, gdca_stats *st)
+gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
+{
+    if (!ctx) return GDCA_EINVAL;
+    if (!ctx->pending) return fail(ctx, GDCA_EINVAL, "no enqueued run to collect%s%s", "", "");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->pending = false;
+    CHK(fetch_scalars(ctx));
+    const gdca_dev_scalars &h = *ctx->sc_host;
+    hipEvent_t *ev = ctx->ev;
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->theta = h.theta;
+        st->Meff = h.Meff;
+        st->pair_identity_sum = h.pair_sum;
+        st->thresh = h.thresh;
+        st->info = h.info;
+        st->N = ctx->pend_N;
+        st->M = ctx->pend_M;
+        st->q = ctx->pend_q;
+        st->n = ctx->pend_n;
+        st->n_pad = ctx->pend_npad;
+        st->update_launches = ctx->pend_nupd;
+        st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
+        st->update_flops = ctx->pend_upd_flops;
+        if (ctx->pend_timed) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
+            st->ms_total = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            st->ms_theta = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
+            st->ms_weights = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3]));
+            st->ms_covariance = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[6], ev[4]));  // from the start of its turn (after any pipeline gate)
+            st->ms_inverse = ms;
+            HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+            st->ms_score = ms;
+            double upd = 0.0;
+            for (int k = 0; k < ctx->pend_nupd && 16 + 2 * k + 1 < ctx->n_ev; ++k) {
+                HIPCHK(hipEventElapsedTime(&ms, ev[16 + 2 * k], ev[16 + 2 * k + 1]));
+                upd += ms;
+            }
+            st->ms_inverse_update = upd;
+        }
+    }
+    if (h.info != 0) return fail(ctx, GDCA_ENOTPD, "covariance matrix is not positive definite%s%s", "", "");
+    return GDCA_OK;
+}
+
+gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                               const gdca_params *p, double *S_dev)
 {
     CHK(validate(ctx, N, M, q));
     if (!Z_dev || !S_dev || !p) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
@@ -361,6 +448,7 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
     if (!(p->theta <= 1.0)) return fail(ctx, GDCA_EINVAL, "invalid theta value%s%s", "", "");
     if (p->score != GDCA_SCORE_FROB && p->score != GDCA_SCORE_DI)
         return fail(ctx, GDCA_EINVAL, "invalid score value%s%s", "", "");
+    if (ctx->pending) (void)gdca_run_collect(ctx, nullptr);  // an uncollected run: its scalars would be overwritten
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
@@ -387,53 +475,38 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
 
     int n_upd = 0;
     double upd_flops = 0.0;
+    if (ctx->gate && ctx->gate->armed) HIPCHK(hipStreamWaitEvent(s, ctx->gate->ev[ctx->gate->last], 0));
+    if (timed) HIPCHK(hipEventRecord(ev[6], s));  // start of this family's turn on the MFMA pipe
     CHK(inverse_stage(ctx, n, n_pad, timed, &n_upd, &upd_flops));
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
+    if (ctx->gate) {
+        gdca_gate *g = ctx->gate;
+        HIPCHK(hipEventRecord(g->ev[g->next], s));
+        g->last = g->next;
+        g->next = (g->next + 1) & 3;
+        g->armed = 1;
+    }
 
     CHK(score_stage(ctx, N, sdim, n_pad, p->score, p->apc, S_dev));
     if (timed) HIPCHK(hipEventRecord(ev[5], s));
 
-    CHK(fetch_scalars(ctx));
-    const gdca_dev_scalars &h = *ctx->sc_host;
-    if (st) {
-        memset(st, 0, sizeof(*st));
-        st->theta = h.theta;
-        st->Meff = h.Meff;
-        st->pair_identity_sum = h.pair_sum;
-        st->thresh = h.thresh;
-        st->info = h.info;
-        st->N = N;
-        st->M = M;
-        st->q = q;
-        st->n = n;
-        st->n_pad = n_pad;
-        st->update_launches = n_upd;
-        st->inverse_flops = inverse_flops_model((double)n);
-        st->update_flops = upd_flops;
-        if (timed) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
-            st->ms_total = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-            st->ms_theta = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
-            st->ms_weights = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3]));
-            st->ms_covariance = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[3], ev[4]));
-            st->ms_inverse = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
-            st->ms_score = ms;
-            double upd = 0.0;
-            for (int k = 0; k < n_upd && 16 + 2 * k + 1 < ctx->n_ev; ++k) {
-                HIPCHK(hipEventElapsedTime(&ms, ev[16 + 2 * k], ev[16 + 2 * k + 1]));
-                upd += ms;
-            }
-            st->ms_inverse_update = upd;
-        }
-    }
-    if (h.info != 0) return fail(ctx, GDCA_ENOTPD, "covariance matrix is not positive definite%s%s", "", "");
+    ctx->pending = true;
+    ctx->pend_timed = timed;
+    ctx->pend_N = N;
+    ctx->pend_M = M;
+    ctx->pend_q = q;
+    ctx->pend_n = n;
+    ctx->pend_npad = n_pad;
+    ctx->pend_nupd = n_upd;
+    ctx->pend_upd_flops = upd_flops;
     return GDCA_OK;
+}
+
+gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                         double *S_dev, gdca_stats *st)
+{
+    CHK(gdca_run_dev_async(ctx, Z_dev, N, M, q, p, S_dev));
+    return gdca_run_collect(ctx, st);
 }
 
 gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,

@@ -29,24 +29,30 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // -------------------------------------------------------------------------------------------------
 // Pivot: P = inverse of the 128 x 128 SPD block at (k0, k0) by a scalar symmetric sweep on its
-// LOWER TRIANGLE held in registers: 136 threads each own one 8 x 8 patch (pr >= pc) of the 16 x 16
-// patch grid.  Per pivot j the column j of the symmetric block (rows >= j from column j, rows < j
-// from row j) and p = 1/d are broadcast through LDS (double-buffered: one barrier per pivot), then
-// every element is one FMA:   D[r][c] <- D[r][c] - u[r] * w[c],   u = g,  w = g * p,
+// LOWER TRIANGLE held in registers: 528 threads (9 waves, spread over the 4 SIMDs) each own one
+// 4 x 4 patch (pr >= pc) of the 32 x 32 patch grid.  Per pivot j the column j of the symmetric
+// block (rows >= j from column j, rows < j from row j) and p = 1/d are broadcast through LDS
+// (double-buffered: one barrier per pivot), then every element is one FMA:
+//       D[r][c] <- D[r][c] - u[r] * w[c],   u = g,  w = g * p,
 // with the pivot row/column handled by the vectors alone (u[j] = -1, w[j] = -p, old row/column j
-// zeroed):  row j -> g[c] p,  column j -> g[r] p,  (j,j) -> -p.  The j loop is unrolled by 8 so
-// every register index is static.  Writes P (full symmetric) and A_KK <- -P (full tile).
-// A non-positive pivot (the same test dpotrf makes) is reported through sc->info.
+// zeroed):  row j -> g[c] p,  column j -> g[r] p,  (j,j) -> -p.  The j loop is unrolled by 4 so
+// every register index is static.  1/d is v_rcp_f64 + two Newton steps (the pivot is a positive,
+// normal number; the full IEEE division sequence would sit on the critical path of every step).
+// Writes P (full symmetric) and A_KK <- -P (full tile).  A non-positive pivot (the same test dpotrf
+// makes) is reported through sc->info.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pivot(double *__restrict__ A, size_t ld, int k0, double *__restrict__ P,
-                                                gdca_dev_scalars *sc, int n_real)
+#define PB 4                      // patch edge
+#define PGRID (T / PB)            // 32 patches per side
+#define PIVOT_THREADS 576         // >= PGRID * (PGRID + 1) / 2 = 528, multiple of 64
+__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ A, size_t ld, int k0,
+                                                          double *__restrict__ P, gdca_dev_scalars *sc, int n_real)
 {
     __shared__ __attribute__((aligned(16))) double g[2][T];
     __shared__ double pinv[2];
     __shared__ int badj;
     const int tid = threadIdx.x;
     if (tid == 0) badj = 0;
-    const bool active = tid < 136;
+    const bool active = tid < PGRID * (PGRID + 1) / 2;
     int pr = 0, pc = 0;
     if (active) {
         pr = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
@@ -54,67 +60,69 @@ __global__ __launch_bounds__(256) void k_pivot(double *__restrict__ A, size_t ld
         while ((pr + 1) * (pr + 2) / 2 <= tid) ++pr;
         pc = tid - pr * (pr + 1) / 2;
     }
-    const int r0 = pr * 8, c0 = pc * 8;
+    const int r0 = pr * PB, c0 = pc * PB;
     double *Akk = A + (size_t)k0 + (size_t)k0 * ld;
-    double D[8][8];
+    double D[PB][PB];
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < PB; ++b)
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
+        for (int a = 0; a < PB; ++a) {
             const int r = r0 + a, c = c0 + b;
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;  // lower triangle is authoritative
             D[a][b] = active ? Akk[(size_t)rr + (size_t)cc * ld] : 0.0;
         }
     __syncthreads();
 
-    for (int jb = 0; jb < T / 8; ++jb) {
-        const bool inrow = active && (pr == jb);  // my patch holds rows of the pivot octet
-        const bool incol = active && (pc == jb);  // my patch holds columns of the pivot octet
+    for (int jb = 0; jb < PGRID; ++jb) {
+        const bool inrow = active && (pr == jb);  // my patch holds rows of the pivot quad
+        const bool incol = active && (pc == jb);  // my patch holds columns of the pivot quad
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < PB; ++jj) {
             const int par = jj & 1;
             if (incol) {
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
+                for (int a = 0; a < PB; ++a)
                     if (pr > jb || a >= jj) g[par][r0 + a] = D[a][jj];  // (r, j), r >= j
             }
             if (inrow) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b)
+                for (int b = 0; b < PB; ++b)
                     if (pc < jb || b < jj) g[par][c0 + b] = D[jj][b];   // (j, c), c < j
             }
             if (inrow && incol) {
                 const double d = D[jj][jj];
-                pinv[par] = 1.0 / d;
-                if (!(d > 0.0) && badj == 0) badj = jb * 8 + jj + 1;
+                double rp = __builtin_amdgcn_rcp(d);
+                rp = fma(rp, fma(-d, rp, 1.0), rp);
+                rp = fma(rp, fma(-d, rp, 1.0), rp);
+                pinv[par] = rp;
+                if (!(d > 0.0) && badj == 0) badj = jb * PB + jj + 1;
             }
             __syncthreads();
             const double p = pinv[par];
-            double u[8], w[8];
+            double u[PB], w[PB];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) u[a] = g[par][r0 + a];
+            for (int a = 0; a < PB; ++a) u[a] = g[par][r0 + a];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) w[b] = g[par][c0 + b] * p;
+            for (int b = 0; b < PB; ++b) w[b] = g[par][c0 + b] * p;
             // branch-free specials (selects, not predicated moves: keeps one live copy of D)
             u[jj] = inrow ? -1.0 : u[jj];
             w[jj] = incol ? -p : w[jj];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) D[jj][b] = inrow ? 0.0 : D[jj][b];
+            for (int b = 0; b < PB; ++b) D[jj][b] = inrow ? 0.0 : D[jj][b];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) D[a][jj] = incol ? 0.0 : D[a][jj];
+            for (int a = 0; a < PB; ++a) D[a][jj] = incol ? 0.0 : D[a][jj];
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < PB; ++a)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) D[a][b] = fma(-u[a], w[b], D[a][b]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int b = 0; b < PB; ++b) D[a][b] = fma(-u[a], w[b], D[a][b]);
         }
     }
     // D = -inverse (lower triangle valid).  P = -D;  A_KK = D, both written as full symmetric tiles
     if (active) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < PB; ++b)
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
+            for (int a = 0; a < PB; ++a) {
                 const int r = r0 + a, c = c0 + b;
                 if (r >= c) {
                     const double v = D[a][b];
@@ -138,12 +146,15 @@ __global__ __launch_bounds__(256) void k_pivot(double *__restrict__ A, size_t ld
 //   acc(r, c) += sum_k Gsrc(r, k) * Hsrc(c, k)
 // Gsrc(r,k) = gsrc[r + k*gld] (or gsrc[k + r*gld] when GT);  Hsrc(c,k) = hsrc[c + k*hld].
 // -------------------------------------------------------------------------------------------------
+// TM = MFMA tiles per wave along the column direction: the workgroup tile is 128 rows x (32 TM) columns
+// (TM = 4: 128 x 128, TM = 2: 128 x 64 for the latency-critical panel product).
+template <int TM>
 struct StageRegs {
-    double g[8], h[8];
+    double g[8], h[2 * TM];
 };
 
-template <bool GT>
-__device__ __forceinline__ void stage_load(StageRegs &R, const double *__restrict__ gsrc, size_t gld,
+template <bool GT, int TM>
+__device__ __forceinline__ void stage_load(StageRegs<TM> &R, const double *__restrict__ gsrc, size_t gld,
                                            const double *__restrict__ hsrc, size_t hld, int kc, int tid)
 {
 #pragma unroll
@@ -160,15 +171,20 @@ __device__ __forceinline__ void stage_load(StageRegs &R, const double *__restric
             R.g[2 * u] = v.x;
             R.g[2 * u + 1] = v.y;
         }
-        const int kk = idx >> 6, c2 = idx & 63;
+    }
+    constexpr int CP = 16 * TM;  // double2 per k-row of the H chunk
+#pragma unroll
+    for (int u = 0; u < TM; ++u) {
+        const int idx = tid + 256 * u;
+        const int kk = idx / CP, c2 = idx % CP;
         const double2 w = *reinterpret_cast<const double2 *>(hsrc + (size_t)(c2 * 2) + (size_t)(kc + kk) * hld);
         R.h[2 * u] = w.x;
         R.h[2 * u + 1] = w.y;
     }
 }
 
-template <bool GT>
-__device__ __forceinline__ void stage_store(const StageRegs &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid)
+template <bool GT, int TM>
+__device__ __forceinline__ void stage_store(const StageRegs<TM> &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid)
 {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -181,43 +197,48 @@ __device__ __forceinline__ void stage_store(const StageRegs &R, double (*Gs)[LDS
             Gs[k2 * 2][r] = R.g[2 * u];
             Gs[k2 * 2 + 1][r] = R.g[2 * u + 1];
         }
-        const int kk = idx >> 6, c2 = idx & 63;
+    }
+    constexpr int CP = 16 * TM;
+#pragma unroll
+    for (int u = 0; u < TM; ++u) {
+        const int idx = tid + 256 * u;
+        const int kk = idx / CP, c2 = idx % CP;
         *reinterpret_cast<double2 *>(&Hs[kk][c2 * 2]) = make_double2(R.h[2 * u], R.h[2 * u + 1]);
     }
 }
 
-__device__ __forceinline__ void chunk_mma(double4_t (&acc)[4][4], double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int wr,
+template <int TM>
+__device__ __forceinline__ void chunk_mma(double4_t (&acc)[TM][4], double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int wr,
                                           int wc, int lane)
 {
     const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int k4 = 0; k4 < KC; k4 += 4) {
-        double a[4], b[4];
+        double a[TM], b[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = Hs[k4 + lq][wc * 64 + t * 16 + l15];
-            b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
-        }
+        for (int t = 0; t < TM; ++t) a[t] = Hs[k4 + lq][wc * (16 * TM) + t * 16 + l15];
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int t = 0; t < 4; ++t) b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
                 acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
 }
 
-template <bool GT>
-__device__ __forceinline__ void tile_product(double4_t (&acc)[4][4], const double *__restrict__ gsrc, size_t gld,
+template <bool GT, int TM>
+__device__ __forceinline__ void tile_product(double4_t (&acc)[TM][4], const double *__restrict__ gsrc, size_t gld,
                                              const double *__restrict__ hsrc, size_t hld, double (*Gs)[LDS_LD],
                                              double (*Hs)[LDS_LD], double *__restrict__ gcopy, size_t gcopy_ld)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1;
-    StageRegs R;
-    stage_load<GT>(R, gsrc, gld, hsrc, hld, 0, tid);
+    StageRegs<TM> R;
+    stage_load<GT, TM>(R, gsrc, gld, hsrc, hld, 0, tid);
     for (int kc = 0; kc < T; kc += KC) {
         __syncthreads();  // previous chunk's LDS reads are done
-        stage_store<GT>(R, Gs, Hs, tid);
+        stage_store<GT, TM>(R, Gs, Hs, tid);
         if (gcopy) {
             // keep an untransposed copy of the G panel: gcopy[r + k * gcopy_ld]
 #pragma unroll
@@ -235,14 +256,16 @@ __device__ __forceinline__ void tile_product(double4_t (&acc)[4][4], const doubl
             }
         }
         __syncthreads();
-        if (kc + KC < T) stage_load<GT>(R, gsrc, gld, hsrc, hld, kc + KC, tid);
-        chunk_mma(acc, Gs, Hs, wr, wc, lane);
+        if (kc + KC < T) stage_load<GT, TM>(R, gsrc, gld, hsrc, hld, kc + KC, tid);
+        chunk_mma<TM>(acc, Gs, Hs, wr, wc, lane);
     }
 }
 
 // Panel: for every row block i != k:  G_i = column block k of the symmetric matrix (read from the
 // lower triangle: A[i,k] for i > k, A[k,i]^T for i < k);  GP = G_i P;  writes
 //   Gbuf[i] = G_i,  Hbuf[i] = -GP,  and the new column block  A[i,k] = GP  (A[k,i] = GP^T for i < k).
+// Two workgroups per row block (64 columns of GP each): the panel sits on the critical path of the
+// look-ahead chain, so it is cut finer than the throughput-bound update.
 __global__ __launch_bounds__(256, 2) void k_panel(double *__restrict__ A, size_t ld, int kblk,
                                                    const double *__restrict__ P, double *__restrict__ Gbuf,
                                                    double *__restrict__ Hbuf, size_t pld)
@@ -251,52 +274,108 @@ __global__ __launch_bounds__(256, 2) void k_panel(double *__restrict__ A, size_t
     __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
     int i = blockIdx.x;
     if (i >= kblk) ++i;  // skip the pivot block itself
+    const int ch = blockIdx.y;  // which 64-column half of GP
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double4_t acc[4][4];
+    double4_t acc[2][4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    double *gcopy = Gbuf + (size_t)i * T;
+    double *gcopy = (ch == 0) ? Gbuf + (size_t)i * T : nullptr;
+    const double *hsrc = P + (size_t)ch * 64;  // rows (= columns, P symmetric) ch*64 .. ch*64+63 of P
     if (i > kblk) {
         const double *gsrc = A + (size_t)i * T + (size_t)kblk * T * ld;
-        tile_product<false>(acc, gsrc, ld, P, T, Gs, Hs, gcopy, pld);
+        tile_product<false, 2>(acc, gsrc, ld, hsrc, T, Gs, Hs, gcopy, pld);
     } else {
         const double *gsrc = A + (size_t)kblk * T + (size_t)i * T * ld;
-        tile_product<true>(acc, gsrc, ld, P, T, Gs, Hs, gcopy, pld);
+        tile_product<true, 2>(acc, gsrc, ld, hsrc, T, Gs, Hs, gcopy, pld);
     }
-    // acc[tm][tn][reg] = GP(r, c):  r = wr*64 + tn*16 + l15,  c = wc*64 + tm*16 + lq + 4*reg
+    // acc[tm][tn][reg] = GP(r, c):  r = wr*64 + tn*16 + l15,  c = ch*64 + wc*32 + tm*16 + lq + 4*reg
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
                 const double v = acc[tm][tn][reg];
                 Hbuf[(size_t)i * T + r + (size_t)c * pld] = -v;
-                if (i > kblk)
-                    A[(size_t)i * T + r + (size_t)(kblk * T + c) * ld] = v;
-                else
-                    A[(size_t)kblk * T + c + (size_t)(i * T + r) * ld] = v;
             }
+}
+
+// Write-back of the new column block: A[i,k] = G_i P = -H_i  (A[k,i] = (G_i P)^T for i < k).  Not done by
+// the panel kernel because the two panel workgroups of a row block both read the OLD A[i,k] as their G
+// operand.  Runs as extra workgroups of the look-ahead update launch (or as a launch of its own at the
+// last step): every thread first loads all of its 64 values, then stores them.
+__device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, size_t ld, int kblk, int i,
+                                                     const double *__restrict__ Hbuf, size_t pld, double (*Ts)[LDS_LD])
+{
+    const int tid = threadIdx.x;
+    const double *H = Hbuf + (size_t)i * T;
+    if (i > kblk) {
+        double *dst = A + (size_t)i * T + (size_t)kblk * T * ld;
+        double v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            const int idx = tid + 256 * u;  // r = idx & 127, c = idx >> 7
+            v[u] = H[(size_t)(idx & 127) + (size_t)(idx >> 7) * pld];
+        }
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            const int idx = tid + 256 * u;
+            dst[(size_t)(idx & 127) + (size_t)(idx >> 7) * ld] = -v[u];
+        }
+    } else {
+        double *dst = A + (size_t)kblk * T + (size_t)i * T * ld;  // dst(c, r) = -H(r, c)
+        // 16 columns of H at a time through LDS: Ts[c][r], then rows of dst are read across c
+        for (int cb = 0; cb < T; cb += KC) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + 256 * u;  // r = idx & 127, c = idx >> 7 (0..15)
+                Ts[idx >> 7][idx & 127] = -H[(size_t)(idx & 127) + (size_t)(cb + (idx >> 7)) * pld];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = tid + 256 * u;  // c = idx & 15, r = idx >> 4
+                dst[(size_t)(cb + (idx & 15)) + (size_t)(idx >> 4) * ld] = Ts[idx & 15][idx >> 4];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_panel_writeback(double *__restrict__ A, size_t ld, int kblk,
+                                                          const double *__restrict__ Hbuf, size_t pld)
+{
+    __shared__ __attribute__((aligned(16))) double Ts[KC][LDS_LD];
+    int i = blockIdx.x;
+    if (i >= kblk) ++i;
+    panel_writeback_tile(A, ld, kblk, i, Hbuf, pld, Ts);
 }
 
 // Update: lower-triangle tiles  A_IJ += G_I * H_J^T   (H = -G P), in one of two tile sets:
 //   colblk <  0 : every tile (I >= J) with I, J not in {skip0, skip1}   (skip1 = -1: only skip0)
 //   colblk >= 0 : the nblk-1 tiles that involve block `colblk` as row or column (I != skip0) --
-//                 the look-ahead slice that the next pivot and panel need first.
+//                 the look-ahead slice that the next pivot and panel need first; workgroups past those
+//                 nblk-1 do the write-back of the pivot column block skip0 (see panel_writeback_tile).
 __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int skip0, int skip1,
-                                                          int colblk, const double *__restrict__ Gbuf,
+                                                          int colblk, int nslice, const double *__restrict__ Gbuf,
                                                           const double *__restrict__ Hbuf, size_t pld)
 {
     __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
     const int t = blockIdx.x;
     int I, J;
+    if (colblk >= 0 && t >= nslice) {
+        int b = t - nslice;
+        if (b >= skip0) ++b;
+        panel_writeback_tile(A, ld, skip0, b, Hbuf, pld, Gs);
+        return;
+    }
     if (colblk >= 0) {
         int b = t;
         if (b >= skip0) ++b;
@@ -329,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
                 const int c = wc * 64 + tm * 16 + lq + 4 * reg;
                 acc[tm][tn][reg] = At[(size_t)r + (size_t)c * ld];
             }
-    tile_product<false>(acc, Gbuf + (size_t)I * T, pld, Hbuf + (size_t)J * T, pld, Gs, Hs, nullptr, 0);
+    tile_product<false, 4>(acc, Gbuf + (size_t)I * T, pld, Hbuf + (size_t)J * T, pld, Gs, Hs, nullptr, 0);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -359,21 +438,23 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     auto timed_update = [&](hipStream_t st, unsigned ntile, int skip0, int skip1, const double *G, const double *H) {
         const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
         if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
-        hipLaunchKernelGGL(k_sweep_update, dim3(ntile), dim3(256), 0, st, A, ld, skip0, skip1, -1, G, H, ld);
+        hipLaunchKernelGGL(k_sweep_update, dim3(ntile), dim3(256), 0, st, A, ld, skip0, skip1, -1, 0, G, H, ld);
         if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
         ++nl;
         fl += tile_flops * (double)ntile;
     };
 
-    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, 0, ws.P, sc, n_real);
+    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, 0, ws.P, sc, n_real);
     if (nblk > 1) {
-        hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, 0, ws.P, ws.G[0], ws.H[0], ld);
+        hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, 0, ws.P, ws.G[0], ws.H[0], ld);
         if (!s1) {
-            // serial schedule: pivot -> panel -> full update, one stream
+            // serial schedule: pivot -> panel -> write-back -> full update, one stream
+            hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, 0, ws.H[0], ld);
             for (int k = 0; k < nblk; ++k) {
                 if (k > 0) {
-                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, k * T, ws.P, sc, n_real);
-                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.P, ws.G[0], ws.H[0], ld);
+                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, k * T, ws.P, sc, n_real);
+                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, ws.G[0], ws.H[0], ld);
+                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.H[0], ld);
                 }
                 const int m = nblk - 1;
                 timed_update(s0, (unsigned)((long long)m * (m + 1) / 2), k, -1, ws.G[0], ws.H[0]);
@@ -392,11 +473,15 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
                 if (has_next) {
                     if (k >= 1) (void)hipStreamWaitEvent(s0, Eb[k - 1], 0);
                     // look-ahead slice: the nblk-1 tiles in row/column k+1, then the next pivot and panel
-                    hipLaunchKernelGGL(k_sweep_update, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, -1, k + 1, G, H, ld);
-                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(256), 0, s0, A, ld, (k + 1) * T, ws.P, sc, n_real);
-                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k + 1, ws.P, ws.G[(k + 1) & 1],
+                    hipLaunchKernelGGL(k_sweep_update, dim3(2 * (nblk - 1)), dim3(256), 0, s0, A, ld, k, -1, k + 1, nblk - 1,
+                                       G, H, ld);
+                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, (k + 1) * T, ws.P, sc, n_real);
+                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k + 1, ws.P, ws.G[(k + 1) & 1],
                                        ws.H[(k + 1) & 1], ld);
                     (void)hipEventRecord(Ep[k + 1], s0);
+                } else {
+                    // last pivot: no look-ahead launch to carry its column write-back
+                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, H, ld);
                 }
             }
             (void)hipStreamWaitEvent(s0, Eb[nblk - 1], 0);

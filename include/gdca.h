@@ -89,6 +89,11 @@ int32_t gdca_device_count(void);
 gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out);
 /* same, but enqueue on an existing hipStream_t (passed as void*); NULL = the null stream */
 gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_ctx **out);
+/* A further context on the leader's device that forms a PIPELINE with it: runs enqueued on the members
+ * execute their SPD-inverse stages one after the other (device-side event chain), so that with
+ * gdca_run_dev_async the reweighting/tally stages of the next family overlap the inverse of the current
+ * one.  All members of a pipeline are driven by one host thread. */
+gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out);
 gdca_status gdca_ctx_destroy(gdca_ctx *ctx);
 gdca_status gdca_ctx_synchronize(gdca_ctx *ctx);
 const char *gdca_last_error(gdca_ctx *ctx); /* valid until the next call on ctx */
@@ -104,6 +109,13 @@ gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, 
  * returning so that *st is complete. */
 gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
                          const gdca_params *p, double *S_dev, gdca_stats *st);
+
+/* Split form for pipelining independent families over several contexts on one GPU: _async only
+ * enqueues (no host synchronisation); gdca_run_collect waits for that run and fills *st.  One run
+ * may be outstanding per ctx; the Z and S buffers must stay valid until it is collected. */
+gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                               const gdca_params *p, double *S_dev);
+gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st);
 
 /* ---- operator level (host pointers): what the DCAUtils-named wrappers bind -------------- */
 /* compute_theta's all-pairs identity sum (inside compute_weighted_frequencies, :28) */

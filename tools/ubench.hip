@@ -30,14 +30,62 @@ __global__ __launch_bounds__(512) void k_lds_atomic(T *out, int iters, int rows)
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// ---- int8 MFMA issue-rate probe (32x32x32, i32 accumulate), NACC independent accumulators ----
+typedef int int16_t_v __attribute__((ext_vector_type(16)));
+typedef int int4_t_v __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void k_probe_i8(int *out, int iters)
+{
+    int16_t_v acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    int4_t_v a = {(int)(threadIdx.x * 0x01010101u), 0x7f3c21e5, (int)0x81c3a55a, 0x12345678};
+    int4_t_v b = {(int)(threadIdx.x * 0x03050709u), 0x0badf00d, (int)0xdeadbeef, 0x7e6d5c4b};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[i], 0, 0, 0);
+    }
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+int run_probe_i8(int wps)
+{
+    const int nb = 256 * wps, iters = 40000 / NACC;
+    int *out;
+    CK(hipMalloc(&out, sizeof(int) * nb * 256));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_probe_i8<NACC>, dim3(nb), dim3(256), 0, 0, out, 100);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_probe_i8<NACC>, dim3(nb), dim3(256), 0, 0, out, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double macs = (double)nb * 4 * iters * NACC * 32768.0;
+    printf("probe_i8 32x32x32 NACC=%d waves/SIMD=%d: %.3f ms, %.1f TMAC/s (= %.1f TOP/s), %.1f clk@2.4GHz per MFMA per SIMD\n", NACC, wps, ms,
+           macs / ms / 1e9, 2 * macs / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * NACC * wps));
+    CK(hipFree(out));
+    return 0;
+}
+
 // ---- tally-loop replica: per wave-instruction 2 LDS reads (b64 broadcast per half-wave + u8) and
 // one ds_add_u64; `same_pct` = percent of instructions whose two half-waves use the same row set ----
-__global__ __launch_bounds__(512) void k_tally_like(unsigned long long *out, int iters, int same_pct, int with_reads)
+__global__ __launch_bounds__(1024) void k_tally_like(unsigned long long *out, int iters, int same_pct, int with_reads)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     unsigned long long *h = reinterpret_cast<unsigned long long *>(sm);       // [400][32]
-    unsigned long long *meta = h + 400 * 32 + 64;                              // [512]
-    unsigned char *zs = reinterpret_cast<unsigned char *>(meta + 512);        // [512][32]
+    unsigned long long *meta = h + 400 * 32 + 64;                              // [1024]
+    unsigned char *zs = reinterpret_cast<unsigned char *>(meta + 1024);       // [1024][32]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int e = tid; e < 400 * 32 + 64; e += blockDim.x) h[e] = 0;
     unsigned rng = tid * 2654435761u + 12345u;
@@ -85,12 +133,12 @@ __global__ __launch_bounds__(512) void k_tally_like(unsigned long long *out, int
     out[blockIdx.x * blockDim.x + tid] = acc;
 }
 
-int run_tally_like(int same_pct, int with_reads)
+int run_tally_like(int same_pct, int with_reads, int threads = 512)
 {
-    const int blocks = 256, threads = 512, iters = 20000;
+    const int blocks = 256, iters = 20000;
     unsigned long long *out;
     CK(hipMalloc(&out, 8 * blocks * threads));
-    size_t lds = 8 * (400 * 32 + 64) + 8 * 512 + 512 * 32;
+    size_t lds = 8 * (400 * 32 + 64) + 8 * 1024 + 1024 * 32;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tally_like), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -102,7 +150,7 @@ int run_tally_like(int same_pct, int with_reads)
     CK(hipDeviceSynchronize());
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("tally-like same_pct=%3d reads=%d: %.3f ms, %.2f clk@2.4GHz per wave-instr per CU\n", same_pct, with_reads, ms,
+    printf("tally-like threads=%d same_pct=%3d reads=%d: %.3f ms, %.2f clk@2.4GHz per wave-instr per CU\n", threads, same_pct, with_reads, ms,
            ms * 1e-3 * 2.4e9 / ((double)iters * threads / 64));
     CK(hipFree(out));
     return 0;
@@ -217,6 +265,15 @@ int run_atomic(const char *name, int rows)
 
 int main()
 {
+    run_probe_i8<1>(1);
+    run_probe_i8<2>(1);
+    run_probe_i8<4>(1);
+    run_probe_i8<2>(2);
+    run_probe_i8<4>(2);
+    run_probe_i8<2>(4);
+    run_tally_like(0, 1, 1024);
+    run_tally_like(-60, 1, 1024);
+    run_tally_like(0, 0, 1024);
     run_tally_like(0, 0);
     run_tally_like(0, 1);
     run_tally_like(30, 1);
