@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void k_probe2(double *out, long long *clk, int
 }
 
 template <int NACC>
-int run_probe2(double *out, long long *clk, int wps)
+int run_probe2(double *out, long long *clk, int wps, int ncu = 256)
 {
-    const int nb = 256 * wps, iters = 40000 / NACC;
+    const int nb = ncu * wps, iters = 40000 / NACC;
     std::vector<long long> h(nb);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -233,7 +233,7 @@ int run_probe2(double *out, long long *clk, int wps)
     for (int i = 0; i < nb; ++i) cyc += h[i];
     cyc /= nb;
     const double fl = (double)nb * 4 * iters * NACC * 2048.0;
-    printf("probe2 NACC=%d waves/SIMD=%d: %.3f ms %.1f TF; %.1f cycles per MFMA per wave => %.1f cycles per MFMA per SIMD\n", NACC, wps, ms,
+    printf("probe2 CUs=%d NACC=%d waves/SIMD=%d: %.3f ms %.1f TF; %.1f cycles per MFMA per wave => %.1f cycles per MFMA per SIMD\n", ncu, NACC, wps, ms,
            fl / ms / 1e9, cyc / ((double)iters * NACC), cyc / ((double)iters * NACC) / wps);
     return 0;
 }
@@ -294,6 +294,7 @@ int main()
     CK(hipMalloc(&out, sizeof(double) * 2048 * 256));
     CK(hipMalloc(&clk, sizeof(long long) * 2048 * 2));
     std::vector<long long> h(blocks * 2);
+    for (int ncu = 16; ncu <= 256; ncu *= 2) run_probe2<4>(out, clk, 2, ncu);
     for (int wps = 1; wps <= 8; wps *= 2) {
         run_probe2<1>(out, clk, wps);
         run_probe2<2>(out, clk, wps);
