@@ -81,6 +81,8 @@ SHAPES = [  # (M, N, q, theta, pc)
     (300, 64, 21, 0.25, 0.8),
     (257, 40, 5, "auto", 0.3),
     (200, 20, 31, 0.3, 0.6),
+    (150, 36, 22, "auto", 0.7),   # s = 21: first size on the 16-column tally variant
+    (1100, 45, 20, "auto", 0.4),  # no gap state present: q = 20, s = 19; more than one 1024-sequence pass
     (1000, 97, 21, "auto", 0.8),
 ]
 
@@ -197,6 +199,43 @@ def test_device_pointer_entry_and_determinism(g, ctx, o):
     S_o = o.scores_from_Z(Zo, 21, 0.8, "auto", "frob")
     ok, max_rel, _ = score_close(S1.cpu().numpy(), S_o)
     assert ok, max_rel
+
+
+def test_async_pipeline_api(g, ctx, o):
+    """gdca_run_dev_async / gdca_run_collect over two contexts (plain and gated peers): same bits as
+    the synchronous entry point."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    fams = [random_msa(rng, 400 + 50 * t, 40 + 7 * t) for t in range(4)]
+    Zd = [torch.from_numpy(z).cuda() for z in fams]
+    ref = []
+    for z, zd in zip(fams, Zd):
+        S = torch.empty((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda")
+        ctx.run_dev(zd.data_ptr(), z.shape[1], z.shape[0], 21, 0.8, -1.0, 0, S.data_ptr())
+        ref.append(S.cpu())
+    for peers in (False, True):
+        c0 = g.Context(0)
+        cs = [c0, c0.peer() if peers else g.Context(0)]
+        outs = [torch.empty((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
+        busy = [False, False]
+        stats = []
+        for t, (z, zd) in enumerate(zip(fams, Zd)):
+            c = t % 2
+            if busy[c]:
+                stats.append(cs[c].collect())
+            cs[c].run_dev_async(zd.data_ptr(), z.shape[1], z.shape[0], 21, 0.8, -1.0, 0, outs[t].data_ptr())
+            busy[c] = True
+        for c in range(2):
+            stats.append(cs[c].collect())
+        torch.cuda.synchronize()
+        assert len(stats) == 4 and all(st["info"] == 0 for st in stats)
+        for t in range(4):
+            assert torch.equal(outs[t].cpu(), ref[t])
+        with pytest.raises(g.ArgumentError):
+            cs[0].collect()  # nothing enqueued
+        for c in cs:
+            c.close()
 
 
 # ---- BASELINE.json's full sizes: size-independent properties ----------------------------------------
