@@ -42,6 +42,8 @@ struct gdca_ctx {
     hipEvent_t ev[MAX_EV];
     int n_ev;
     // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
+    bool meff_pending;  // k_meff enqueued on the side stream, not yet joined
+    hipEvent_t ev_weights, ev_meff;
     bool pending;
     bool pend_timed;
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
@@ -129,6 +131,11 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
         free(ctx);
         return GDCA_EHIP;
     }
+    if (hipEventCreateWithFlags(&ctx->ev_weights, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess) {
+        free(ctx);
+        return GDCA_EHIP;
+    }
     if (hipHostMalloc((void **)&ctx->sc_host, sizeof(gdca_dev_scalars), hipHostMallocDefault) != hipSuccess) {
         free(ctx);
         return GDCA_ENOMEM;
@@ -192,6 +199,8 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     }
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < ctx->n_sev; ++i) (void)hipEventDestroy(ctx->sev[i]);
+    if (ctx->ev_weights) (void)hipEventDestroy(ctx->ev_weights);
+    if (ctx->ev_meff) (void)hipEventDestroy(ctx->ev_meff);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
@@ -285,7 +294,13 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
-    gdca_launch_meff(s, (const double *)ctx->W.p, M, sc);
+    // Meff is one long dependent chain on a single CU: run it on the side stream, next to the kernels that
+    // do not need it yet (transposes, Pi tallies); tally_stage() joins before the first consumer
+    HIPCHK(hipEventRecord(ctx->ev_weights, s));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_weights, 0));
+    gdca_launch_meff(ctx->side, (const double *)ctx->W.p, M, sc);
+    HIPCHK(hipEventRecord(ctx->ev_meff, ctx->side));
+    ctx->meff_pending = true;
     return check_launch(ctx, "weights");
 }
 
@@ -305,6 +320,10 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
     gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M);
+    if (ctx->meff_pending) {
+        HIPCHK(hipStreamWaitEvent(s, ctx->ev_meff, 0));
+        ctx->meff_pending = false;
+    }
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
                             (double *)ctx->Pipc.p);
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
@@ -373,6 +392,10 @@ static gdca_status validate(gdca_ctx *ctx, int N, int M, int q)
 
 static gdca_status fetch_scalars(gdca_ctx *ctx)
 {
+    if (ctx->meff_pending) {
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_meff, 0));
+        ctx->meff_pending = false;
+    }
     HIPCHK(hipMemcpyAsync(ctx->sc_host, ctx->sc.p, sizeof(gdca_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return GDCA_OK;

@@ -41,10 +41,25 @@ __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict_
     if (k < M) {
         const int8_t *src = Z + (size_t)k * N + (size_t)w * 32;
         const int nb = min(32, N - w * 32);
-        for (int b = 0; b < nb; ++b) {
-            const uint32_t z = (uint32_t)src[b] & 31u;
+        if (nb == 32 && (N & 3) == 0) {
+            // aligned fast path: 8 dword loads; bit p of 4 bytes -> 4 adjacent bits by one multiply
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+            uint32_t d[8];
 #pragma unroll
-            for (int p = 0; p < NPLANES; ++p) pl[p] |= ((z >> p) & 1u) << b;
+            for (int j = 0; j < 8; ++j) d[j] = s4[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int p = 0; p < NPLANES; ++p) {
+                    const uint32_t t = (d[j] >> p) & 0x01010101u;
+                    pl[p] |= (((t * 0x01020408u) >> 24) & 0xFu) << (4 * j);
+                }
+        } else {
+            for (int b = 0; b < nb; ++b) {
+                const uint32_t z = (uint32_t)src[b] & 31u;
+#pragma unroll
+                for (int p = 0; p < NPLANES; ++p) pl[p] |= ((z >> p) & 1u) << b;
+            }
         }
     }
 #pragma unroll
