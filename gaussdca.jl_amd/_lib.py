@@ -82,6 +82,13 @@ SYMBOLS = {
     "gdca_fn": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_di": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_apc": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
+    "gdca_fasta_open": (C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_void_p), _i32p, _i32p]),
+    "gdca_fasta_copy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gdca_fasta_close": (C.c_int, [C.c_void_p]),
+    "gdca_remove_duplicates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32p]),
+    "gdca_ranking_length": (C.c_int64, [C.c_int32, C.c_int32]),
+    "gdca_ranking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdca_write_rank": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "gdca_probe_mfma_f64": (C.c_int, [_ctx, C.c_int32, _f64p]),
 }
 

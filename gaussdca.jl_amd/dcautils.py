@@ -46,8 +46,9 @@ def _theta_arg(theta) -> float:
 
 
 # ---- host I/O (reference: DCAUtils.read_fasta_alignment, src/GaussDCA.jl:20) -----------------------
-def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
-    """FASTA (plain or .gz) -> Z::Matrix{Int8}, shape (N, M).  Columns kept = positions of the
+def read_fasta_alignment_py(filename: str, max_gap_fraction: float) -> np.ndarray:
+    """Pure-Python form of read_fasta_alignment (kept as the readable statement of the rules and as a
+    cross-check of the native reader in the tests).  FASTA (plain or .gz) -> Z::Matrix{Int8}, shape (N, M).  Columns kept = positions of the
     first record that are neither '.' nor lowercase; sequences with more than
     ``max_gap_fraction`` gaps ('-') are dropped; ACDEFGHIKLMNPQRSTVWY -> 1..20, else 21."""
     opener = gzip.open if str(filename).endswith(".gz") else open
@@ -82,7 +83,7 @@ def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
     return np.asfortranarray(np.stack(kept, axis=1).astype(np.int8))
 
 
-def remove_duplicate_sequences(Z) -> Tuple[np.ndarray, np.ndarray]:
+def remove_duplicate_sequences_py(Z) -> Tuple[np.ndarray, np.ndarray]:
     """-> (Z without repeated columns, 1-based indices kept); first occurrences, order kept
     (reference call site src/GaussDCA.jl:21-23)."""
     Zf = _zf(Z)
@@ -95,6 +96,55 @@ def remove_duplicate_sequences(Z) -> Tuple[np.ndarray, np.ndarray]:
             keep.append(k)
     keep_a = np.asarray(keep, dtype=np.int64)
     return np.asfortranarray(Zf[:, keep_a]), keep_a + 1
+
+
+# ---- native host utilities (libgdca.so, plain C++; same results as the *_py forms above) -------------------
+def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
+    """read_fasta_alignment(filename, max_gap_fraction) -> Z::Matrix{Int8}, shape (N, M), Fortran order
+    (reference call site src/GaussDCA.jl:20)."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    N, M = C.c_int32(), C.c_int32()
+    st = lib.gdca_fasta_open(str(filename).encode(), float(max_gap_fraction), C.byref(h), C.byref(N), C.byref(M))
+    if st != 0:
+        raise ValueError(f"cannot read FASTA alignment {filename} (empty, unreadable or not aligned)")
+    try:
+        Z = np.empty((N.value, M.value), dtype=np.int8, order="F")
+        lib.gdca_fasta_copy(h, _lib._p(Z))
+    finally:
+        lib.gdca_fasta_close(h)
+    return Z
+
+
+def remove_duplicate_sequences(Z) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (Z without repeated columns, 1-based indices kept)  (reference call site src/GaussDCA.jl:21-23)"""
+    lib = _lib.load()
+    Zf = _zf(Z)
+    N, M = Zf.shape
+    out = np.empty((N, M), dtype=np.int8, order="F")
+    idx = np.empty(M, dtype=np.int32)
+    m = C.c_int32()
+    st = lib.gdca_remove_duplicates(_lib._p(Zf), N, M, _lib._p(out), _lib._p(idx), C.byref(m))
+    if st != 0:
+        raise ArgumentError("remove_duplicate_sequences: invalid arguments")
+    return np.asfortranarray(out[:, :m.value]), idx[:m.value].astype(np.int64)
+
+
+def compute_ranking(S, min_separation: int = 5) -> List[Tuple[int, int, float]]:
+    """compute_ranking(S, min_separation)  (src/GaussDCA.jl:88-99): 1-based (i, j, S[j, i]), stable sort."""
+    lib = _lib.load()
+    Sf = np.asfortranarray(S, dtype=np.float64)
+    N = Sf.shape[0]
+    n = int(lib.gdca_ranking_length(N, int(min_separation)))
+    if n <= 0:
+        return []
+    ii = np.empty(n, dtype=np.int32)
+    jj = np.empty(n, dtype=np.int32)
+    sc = np.empty(n, dtype=np.float64)
+    st = lib.gdca_ranking(_lib._p(Sf), N, int(min_separation), _lib._p(ii), _lib._p(jj), _lib._p(sc))
+    if st != 0:
+        raise ArgumentError("compute_ranking: invalid arguments")
+    return list(zip(ii.tolist(), jj.tolist(), sc.tolist()))
 
 
 # ---- hot operators (libgdca.so) -----------------------------------------------------------------------
@@ -243,7 +293,7 @@ def correct_APC(S, ctx=None) -> np.ndarray:
 
 
 # ---- host ranking (reference: compute_ranking, src/GaussDCA.jl:88-99) ---------------------------------
-def compute_ranking(S, min_separation: int = 5) -> List[Tuple[int, int, float]]:
+def compute_ranking_py(S, min_separation: int = 5) -> List[Tuple[int, int, float]]:
     """[(i, j, S[j, i])] for 1 <= i, j = i + min_separation .. N, sorted by score descending with
     a stable sort (exact ties keep generation order, as Julia's default sort! does)."""
     S = np.asarray(S)
@@ -272,7 +322,13 @@ def printrank(io, R: Sequence[Tuple[int, int, float]] = None):
     if R is None:
         io, R = sys.stdout, io
     if isinstance(io, (str, bytes)):
-        with open(io, "w") as f:
-            return printrank(f, R)
+        lib = _lib.load()
+        ii = np.asarray([r[0] for r in R], dtype=np.int32)
+        jj = np.asarray([r[1] for r in R], dtype=np.int32)
+        sc = np.asarray([r[2] for r in R], dtype=np.float64)
+        path = io if isinstance(io, bytes) else io.encode()
+        if lib.gdca_write_rank(path, _lib._p(ii), _lib._p(jj), _lib._p(sc), len(R)) != 0:
+            raise OSError(f"cannot write {io}")
+        return None
     for (i, j, x) in R:
         io.write("%i %i %e\n" % (i, j, x))

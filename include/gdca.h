@@ -149,6 +149,27 @@ gdca_status gdca_di(gdca_ctx *ctx, const double *mJ, const double *C, int32_t N,
 /* correct_APC(S) (:42, :78-86), in place */
 gdca_status gdca_apc(gdca_ctx *ctx, double *S, int32_t N);
 
+/* ---- host-side utilities around the hot path (plain C++, no GPU): the reference's callers of the path -------- */
+typedef struct gdca_fasta gdca_fasta;
+/* DCAUtils.read_fasta_alignment(filename, max_gap_fraction) (src/GaussDCA.jl:20): parses a FASTA file (plain or
+ * gzip), keeps the columns of the first record that are neither '.' nor lowercase, drops sequences with more
+ * than max_gap_fraction '-' among them, maps ACDEFGHIKLMNPQRSTVWY -> 1..20, anything else -> 21.
+ * open: parse, report N and M;  copy: fill the caller's N x M int8 matrix;  close: free the handle. */
+gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fasta **out, int32_t *N, int32_t *M);
+gdca_status gdca_fasta_copy(const gdca_fasta *h, int8_t *Z);
+gdca_status gdca_fasta_close(gdca_fasta *h);
+/* DCAUtils.remove_duplicate_sequences(Z) (:21-23): first occurrences, order kept.  Z_out may alias Z.
+ * keep_idx (optional, M entries): 1-based indices kept. */
+gdca_status gdca_remove_duplicates(const int8_t *Z, int32_t N, int32_t M, int8_t *Z_out, int32_t *keep_idx,
+                                   int32_t *M_out);
+/* compute_ranking(S, min_separation) (:88-99): (i, j, S[j,i]) for j >= i + min_separation, 1-based, stable sort
+ * by score descending.  Outputs hold gdca_ranking_length(N, min_separation) entries. */
+int64_t gdca_ranking_length(int32_t N, int32_t min_separation);
+gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int32_t *i_out, int32_t *j_out,
+                         double *score_out);
+/* printrank(filename, R) (:67-74): one "%i %i %e" line per entry */
+gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len);
+
 /* ---- measurement helpers (bench.py / profiles; not part of the reference surface) ------- */
 /* Dense f64 MFMA issue-rate probe: returns achieved TFLOP/s of a register-resident
  * v_mfma_f64_16x16x4_f64 loop on every CU. */

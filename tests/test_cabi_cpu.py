@@ -83,28 +83,58 @@ def test_argument_checks_mirror_reference(tmp_path):
             g.check_arguments(*args)
 
 
-def test_host_fasta_dedup_ranking_match_oracle(refdata):
-    """The host-side pieces around the hot path (FASTA reader, dedup, ranking, printrank)."""
+def test_host_fasta_dedup_ranking_match_oracle(refdata, tmp_path):
+    """The host-side pieces around the hot path (FASTA reader, dedup, ranking, printrank): the native
+    (libgdca.so, C++) forms, their pure-Python statements and the oracle agree."""
     import io
 
     import gaussdca.jl_amd as g
     from oracle import gdca_oracle as o
 
-    for name, mgf in (("small.fasta.gz", 0.9), ("large.fasta.gz", 0.9), ("small.fasta.gz", 0.8)):
+    for name, mgf in (("small.fasta.gz", 0.9), ("large.fasta.gz", 0.9), ("small.fasta.gz", 0.8),
+                      ("large.fasta.gz", 0.84)):
         p = os.path.join(refdata, name)
-        Z = g.read_fasta_alignment(p, mgf)           # (N, M), Fortran order
+        Z = g.read_fasta_alignment(p, mgf)           # (N, M), Fortran order, native reader
         Zo = o.read_fasta_alignment(p, mgf)          # (M, N), C order
         assert Z.flags.f_contiguous and Z.dtype == np.int8
         assert np.array_equal(Z.T, Zo)
+        assert np.array_equal(g.read_fasta_alignment_py(p, mgf), Z)
         Zu, idx = g.remove_duplicate_sequences(Z)
         Zou, idxo = o.remove_duplicate_sequences(Zo)
         assert np.array_equal(Zu.T, Zou) and np.array_equal(idx, idxo + 1)
+        Zp, idxp = g.remove_duplicate_sequences_py(Z)
+        assert np.array_equal(Zp, Zu) and np.array_equal(idxp, idx)
+    # 102 -> 97 sequences at 0.9 (five all-gap sequences), 94 after dedup (SURVEY.md 4.2)
+    Zl = g.read_fasta_alignment(os.path.join(refdata, "large.fasta.gz"), 0.9)
+    assert Zl.shape == (400, 97) and g.remove_duplicate_sequences(Zl)[0].shape == (400, 94)
+
+    # untested-by-the-reference corners, pinned to the restated rules: insert columns ('.' / lowercase) of the
+    # first record are dropped, letters BJOUXZ and '*' map to 21, CRLF and wrapped lines, gap filter with '<='
+    fa = tmp_path / "odd.fasta"
+    fa.write_bytes(b">s1 first\r\nAC.dE-\r\nGH\r\n>s2\nBJxyOU\nXZ\n>s3\n--.--A\n--\n\n>s4\nacgtac\ngt\n")
+    for mgf in (0.9, 0.5, 0.49):
+        Zn = g.read_fasta_alignment(str(fa), mgf)
+        assert np.array_equal(Zn, g.read_fasta_alignment_py(str(fa), mgf))
+        assert np.array_equal(Zn.T, o.read_fasta_alignment(str(fa), mgf))
+    Zn = g.read_fasta_alignment(str(fa), 0.9)
+    assert Zn.shape[0] == 6 and Zn[:, 0].tolist() == [1, 2, 4, 21, 6, 7] and Zn[:, 1].tolist() == [21] * 6
+    with pytest.raises(ValueError):
+        g.read_fasta_alignment(str(tmp_path / "missing.fasta"), 0.9)
+    bad = tmp_path / "ragged.fasta"
+    bad.write_text(">a\nACD\n>b\nAC\n")
+    with pytest.raises(ValueError):
+        g.read_fasta_alignment(str(bad), 0.9)
+
     rng = np.random.default_rng(0)
     S = rng.random((30, 30))
     S = S + S.T
     S[3, 20] = S[20, 3] = S[4, 25] = S[25, 4] = 0.123  # an exact tie: generation order must be kept
-    for sep in (1, 4, 5, 29, 30):
-        assert g.compute_ranking(S, sep) == o.compute_ranking(S, sep)
+    for sep in (1, 4, 5, 29, 30, 31):
+        assert g.compute_ranking(S, sep) == o.compute_ranking(S, sep) == g.compute_ranking_py(S, sep)
     buf = io.StringIO()
-    g.printrank(buf, [(11, 35, 3.649475), (9, 46, -0.6752293)])
-    assert buf.getvalue() == "11 35 3.649475e+00\n9 46 -6.752293e-01\n"
+    R = [(11, 35, 3.649475), (9, 46, -0.6752293), (1, 2, 1e-300), (3, 4, 123456789.0)]
+    g.printrank(buf, R)
+    assert buf.getvalue().startswith("11 35 3.649475e+00\n9 46 -6.752293e-01\n")
+    out = tmp_path / "rank.txt"
+    g.printrank(str(out), R)  # native writer: same bytes as the Python "%i %i %e"
+    assert out.read_text() == buf.getvalue()
