@@ -151,6 +151,23 @@ def test_operator_parity(g, ctx, o, M, N, q, theta, pc):
             assert np.array_equal(S, S.T)
 
 
+@pytest.mark.parametrize("name", ["synthetic_a", "synthetic_b", "synthetic_c"])
+def test_committed_synthetic_vectors(g, ctx, name, refdata):
+    """GPU path against the stored oracle vectors of tests/golden/synthetic_*.npz."""
+    d = np.load(os.path.join(os.path.dirname(refdata), name + ".npz"))
+    Zo, q, pc = d["Z"], int(d["q"]), float(d["pseudocount"])
+    theta = -1.0 if str(d["theta_in"]) == "auto" else float(str(d["theta_in"]))
+    Z = np.asfortranarray(Zo.T)
+    assert np.array_equal(g.neighbour_counts(Z, int(d["thresh"]), ctx=ctx), d["n_k"])   # bit-exact
+    if theta < 0:
+        assert g.pair_identity_sum(Z, ctx=ctx) == int(d["pair_identity_sum"])
+    for sc, key in ((0, "S_frob"), (1, "S_DI")):
+        S, st = ctx.run(Z, q, pc, theta, sc)
+        assert st["theta"] == float(d["theta"]) and st["thresh"] == int(d["thresh"]) and st["Meff"] == float(d["Meff"])
+        ok, max_rel, _ = score_close(S, d[key], rtol=1e-6, atol_frac=1e-9)                # 1e-6 relative
+        assert ok, (key, max_rel)
+
+
 def test_theta_zero_and_tiny_theta(g, ctx):
     rng = np.random.default_rng(5)
     Z = np.asfortranarray(random_msa(rng, 90, 53).T)

@@ -160,3 +160,18 @@ def test_argument_checks(refdata, tmp_path):
             o.gDCA(f, **kw)
     with pytest.raises(ValueError):
         o.gDCA(str(tmp_path / "missing.fasta"))
+
+
+@pytest.mark.parametrize("name", ["synthetic_a", "synthetic_b", "synthetic_c"])
+def test_oracle_reproduces_committed_synthetic_vectors(name, refdata):
+    """tests/golden/synthetic_*.npz (made by tests/golden/make_synthetic.py): the oracle still produces them."""
+    d = np.load(os.path.join(os.path.dirname(refdata), name + ".npz"))
+    Z, q, pc = d["Z"], int(d["q"]), float(d["pseudocount"])
+    theta = "auto" if str(d["theta_in"]) == "auto" else float(str(d["theta_in"]))
+    W, Meff, th, thresh = o.compute_weights(Z, theta)
+    assert th == float(d["theta"]) and thresh == int(d["thresh"]) and Meff == float(d["Meff"])
+    assert np.array_equal(o.neighbour_counts(Z, thresh), d["n_k"])
+    assert o.pair_identity_sum(Z) == int(d["pair_identity_sum"])
+    for score, key in (("frob", "S_frob"), ("DI", "S_DI")):
+        S = o.scores_from_Z(Z, q, pc, theta, score)
+        assert np.allclose(S, d[key], rtol=1e-10, atol=1e-13)
