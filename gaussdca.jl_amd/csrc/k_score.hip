@@ -8,9 +8,9 @@
 // only through the singular values of L_j^T X L_i.
 //
 // FN: one wave per site pair, one pass over the block (HBM-bound: 8 s^2 bytes per pair,
-// 8 n (n - s) / 2 bytes in all).  DI: one wave per pair, everything in LDS: two triangular
-// products, V = MM MM^T, then a cyclic Jacobi eigenvalue iteration in round-robin ordering
-// (s/2 independent rotations per round) -- latency/VALU-bound, no HBM traffic to speak of.
+// 8 n (n - s) / 2 bytes in all).  DI: the three small products and a Householder
+// tridiagonalisation per pair (one wave each, LDS-resident), then implicit QL on the
+// tridiagonals, one lane per pair -- latency/VALU-bound, no HBM traffic to speak of.
 #include "gdca_internal.h"
 
 __device__ __forceinline__ void pair_decode(long long p, int &i, int &j)

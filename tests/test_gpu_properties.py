@@ -1,0 +1,47 @@
+"""Property tests on random small alignments (hypothesis): GPU == oracle for every draw.
+Integers bit-exact; scores within 1e-6 relative (+1e-9 of the largest score for zero crossings)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from gdca_testutil import random_msa, score_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import gaussdca.jl_amd as g
+    from oracle import gdca_oracle as o
+
+    ctx = g.Context(0)
+    yield g, o, ctx
+    ctx.close()
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), M=st.integers(2, 300), N=st.integers(2, 40),
+       q=st.sampled_from([3, 5, 21, 24]), theta=st.one_of(st.just("auto"), st.floats(0.0, 0.6)),
+       pc=st.floats(0.05, 1.0), score=st.sampled_from(["frob", "DI"]))
+def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
+    g, o, ctx = env
+    rng = np.random.default_rng(seed)
+    Zo = random_msa(rng, M, N, q)
+    Zo[0, 0] = q
+    Z = np.asfortranarray(Zo.T)
+    W_o, Meff_o, th_o, thr_o = o.compute_weights(Zo, theta)
+    n_o = o.neighbour_counts(Zo, thr_o)
+    assert np.array_equal(g.neighbour_counts(Z, thr_o, ctx=ctx), n_o)
+    try:
+        S_o = o.scores_from_Z(Zo, q, pc, theta, score)
+    except o.NotPositiveDefinite:
+        with pytest.raises(g.PosDefException):
+            ctx.run(Z, q, pc, -1.0 if theta == "auto" else float(theta), 1 if score == "DI" else 0)
+        return
+    if np.linalg.cond(o.compute_C(*o.add_pseudocount(*o.compute_frequencies(Zo, q, W_o, Meff_o), pc, q))) > 1e9:
+        return  # numerically singular covariance: both sides are dominated by rounding
+    S, stt = ctx.run(Z, q, pc, -1.0 if theta == "auto" else float(theta), 1 if score == "DI" else 0)
+    assert stt["thresh"] == thr_o and stt["Meff"] == Meff_o and stt["theta"] == th_o
+    ok, max_rel, _ = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)
+    assert ok, max_rel
