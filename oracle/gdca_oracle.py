@@ -197,6 +197,8 @@ def compute_theta(Z: np.ndarray) -> float:
     if M < 2:
         return 0.0
     phi = pair_identity_sum(Z) / (N * (0.5 * M * (M - 1)))
+    if phi == 0.0:
+        return 0.5  # Julia: 0.1216 / 0.0 == Inf, min(0.5, Inf) == 0.5
     return min(0.5, 0.38 * 0.32 / phi)
 
 

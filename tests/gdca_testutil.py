@@ -70,7 +70,9 @@ def score_close(S, S_ref, rtol=1e-6, atol_frac=1e-9):
     N = S.shape[0]
     off = ~np.eye(N, dtype=bool)
     a, b = S[off], S_ref[off]
-    scale = np.max(np.abs(b))
+    # magnitude reference: all entries, diagonal included (the APC-corrected diagonal is -S_i.^2 / Sa, i.e. the
+    # size of the raw scores; with few sequences every off-diagonal entry can cancel to rounding noise)
+    scale = np.max(np.abs(S_ref))
     ok = bool(np.all(np.abs(a - b) <= rtol * np.abs(b) + atol_frac * scale))
     big = np.abs(b) > 1e-3 * scale
     max_rel = float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big]))) if np.any(big) else 0.0
