@@ -25,28 +25,11 @@ PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355
 
 
 def synth_family(N, M, q, seed):
-    """Deterministic 'Pfam-like' synthetic MSA (SURVEY.md 8d model), returned as (M, N) int8."""
-    import numpy as np
+    """Deterministic 'Pfam-like' synthetic MSA (SplitMix64, native generator in libgdca.so),
+    returned as (M, N) int8."""
+    from gaussdca.jl_amd.synth import synth_family as gen
 
-    rng = np.random.default_rng(seed)
-    root = rng.integers(1, q, size=N)
-    K = max(1, -(-M // 25))
-    centres = np.tile(root, (K, 1))
-    cm = rng.random((K, N)) < 0.25
-    centres[cm] = rng.integers(1, q, size=int(cm.sum()))
-    Z = centres[rng.integers(0, K, size=M)]
-    mu = rng.choice([0.02, 0.05, 0.1, 0.2, 0.3, 0.5], size=M)
-    mask = rng.random((M, N)) < mu[:, None]
-    Z[mask] = rng.integers(1, q, size=int(mask.sum()))
-    nruns = rng.integers(0, 4, size=M)
-    maxlen = max(2, N // 10)
-    for r in range(3):
-        sel = np.nonzero(nruns > r)[0]
-        start = rng.integers(0, N, size=sel.size)
-        length = rng.integers(1, maxlen + 1, size=sel.size)
-        for k, a, ln in zip(sel, start, length):
-            Z[k, a:a + ln] = q
-    return np.ascontiguousarray(Z.astype(np.int8))
+    return gen(N, M, q, seed)
 
 
 def pmc_traffic():

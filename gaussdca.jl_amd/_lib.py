@@ -89,6 +89,8 @@ SYMBOLS = {
     "gdca_ranking_length": (C.c_int64, [C.c_int32, C.c_int32]),
     "gdca_ranking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_write_rank": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gdca_synth_family": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
+    "gdca_write_fasta": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     "gdca_probe_mfma_f64": (C.c_int, [_ctx, C.c_int32, _f64p]),
 }
 

@@ -1,0 +1,353 @@
+// gdca_cli -- command-line driver over the C-ABI of libgdca.so (include/gdca.h): what a user of the reference
+// types at the Julia prompt (README.md "Examples": gDCA("alignment.fasta.gz", pseudocount = 0.2, score = :DI);
+// printrank("results_DI.txt", DIR)), plus the directory-batch mode of SURVEY.md 8e / 8f-4: independent families
+// over every GPU of the node, one gdca_ctx + one worker thread per GPU pulling from a queue ordered by
+// descending cost (greedy LPT), with FASTA parsing done by separate threads so that it overlaps device work.
+// No collective, no shared device state.  Host code only; every number comes from libgdca.so.
+//
+//   gdca_cli [options] alignment.fasta[.gz] [ranking.txt]
+//   gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P]
+//   gdca_cli --synth N M SEED out.fasta[.gz]
+// options (names and defaults of src/GaussDCA.jl:10-15):
+//   --pseudocount X (0.8)  --theta auto|X (auto)  --max_gap_fraction X (0.9)  --score frob|DI (frob)
+//   --min_separation K (5)  --remove_dups
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include "gdca.h"
+
+namespace {
+
+struct Options {
+    double pseudocount = 0.8, theta = -1.0, max_gap_fraction = 0.9;
+    int score = GDCA_SCORE_FROB, min_separation = 5;
+    bool remove_dups = false;
+    std::string batch_dir, out_dir;
+    int gpus = 0, parsers = 4;
+    std::vector<std::string> positional;
+};
+
+double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+[[noreturn]] void die(const std::string &msg)
+{
+    fprintf(stderr, "ERROR: %s\n", msg.c_str());
+    exit(2);
+}
+
+// the checks of check_arguments (src/GaussDCA.jl:49-65), same order and wording
+void check_arguments(const Options &o)
+{
+    char buf[256];
+    if (!(o.pseudocount >= 0 && o.pseudocount <= 1)) {
+        snprintf(buf, sizeof buf, "invalid pseudocount value: %g (must be between 0 and 1)", o.pseudocount);
+        die(buf);
+    }
+    if (!(o.theta < 0 || o.theta <= 1)) {
+        snprintf(buf, sizeof buf, "invalid theta value: %g (must be either :auto, or a number between 0 and 1)", o.theta);
+        die(buf);
+    }
+    if (!(o.max_gap_fraction >= 0 && o.max_gap_fraction <= 1)) {
+        snprintf(buf, sizeof buf, "invalid max_gap_fraction value: %g (must be between 0 and 1)", o.max_gap_fraction);
+        die(buf);
+    }
+    if (!(o.min_separation >= 1)) {
+        snprintf(buf, sizeof buf, "invalid min_separation value: %d (must be >= 1)", o.min_separation);
+        die(buf);
+    }
+}
+
+struct Family {
+    std::string path, name;
+    int32_t N = 0, M = 0, q = 0;
+    std::vector<int8_t> Z;  // [M][N]
+    double parse_s = 0;
+    std::string error;
+};
+
+// src/GaussDCA.jl:20-26: read + filter, optional duplicate removal, q = maximum(Z), q < 32
+bool load_family(const Options &o, Family &f)
+{
+    const double t0 = now();
+    gdca_fasta *h = nullptr;
+    if (gdca_fasta_open(f.path.c_str(), o.max_gap_fraction, &h, &f.N, &f.M) != GDCA_OK) {
+        f.error = "cannot read alignment " + f.path;
+        return false;
+    }
+    f.Z.resize((size_t)f.N * f.M);
+    gdca_fasta_copy(h, f.Z.data());
+    gdca_fasta_close(h);
+    if (o.remove_dups) {
+        int32_t m = 0;
+        gdca_remove_duplicates(f.Z.data(), f.N, f.M, f.Z.data(), nullptr, &m);
+        f.M = m;
+        f.Z.resize((size_t)f.N * f.M);
+    }
+    int q = 0;
+    for (int8_t a : f.Z) q = std::max(q, (int)a);
+    f.q = q;
+    f.parse_s = now() - t0;
+    if (f.M < 1) {
+        f.error = "no sequences left after filtering in " + f.path;
+        return false;
+    }
+    if (q >= 32) {
+        f.error = "parameter q=" + std::to_string(q) + " is too big (max 31 is allowed)";
+        return false;
+    }
+    return true;
+}
+
+// hot path + ranking + printrank for one parsed family on one context
+bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string &out_path, gdca_stats *st,
+             std::string *err)
+{
+    std::vector<double> S((size_t)f.N * f.N);
+    gdca_params p{o.pseudocount, o.theta, o.score, 1};
+    const gdca_status rc = gdca_run(ctx, f.Z.data(), f.N, f.M, f.q, &p, S.data(), st);
+    if (rc == GDCA_ENOTPD) {
+        *err = "PosDefException: matrix is not positive definite; Cholesky factorization failed (info " +
+               std::to_string(st->info) + ")";
+        return false;
+    }
+    if (rc != GDCA_OK) {
+        *err = std::string("gdca_run failed: ") + gdca_last_error(ctx);
+        return false;
+    }
+    const int64_t len = gdca_ranking_length(f.N, o.min_separation);
+    std::vector<int32_t> ri((size_t)len), rj((size_t)len);
+    std::vector<double> rs((size_t)len);
+    if (gdca_ranking(S.data(), f.N, o.min_separation, ri.data(), rj.data(), rs.data()) != GDCA_OK) {
+        *err = "ranking failed";
+        return false;
+    }
+    if (out_path.empty()) {
+        for (int64_t t = 0; t < len; ++t) printf("%i %i %e\n", ri[(size_t)t], rj[(size_t)t], rs[(size_t)t]);
+    } else if (gdca_write_rank(out_path.c_str(), ri.data(), rj.data(), rs.data(), len) != GDCA_OK) {
+        *err = "cannot write " + out_path;
+        return false;
+    }
+    return true;
+}
+
+bool has_suffix(const std::string &s, const char *suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+std::string strip_fasta_suffix(std::string name)
+{
+    if (has_suffix(name, ".gz")) name.resize(name.size() - 3);
+    for (const char *suf : {".fasta", ".fa", ".afa", ".aln"})
+        if (has_suffix(name, suf)) {
+            name.resize(name.size() - strlen(suf));
+            break;
+        }
+    return name;
+}
+
+// A cheap size estimate for the scheduling order without parsing: compressed/plain bytes on disk.  The exact
+// cost model c = (N s)^3 + M^2 N / 8 + N^2 M (batch.py: family_cost) is applied once (N, M) are known; the queue
+// order only needs "big first", for which the file size is a good proxy (bytes ~ N M).
+struct Job {
+    std::string path, name;
+    int64_t bytes = 0;
+};
+
+int run_batch(const Options &o)
+{
+    std::vector<Job> jobs;
+    DIR *d = opendir(o.batch_dir.c_str());
+    if (!d) die("cannot open directory " + o.batch_dir);
+    while (dirent *e = readdir(d)) {
+        const std::string nm = e->d_name;
+        bool ok = false;
+        for (const char *suf : {".fasta", ".fa", ".afa", ".aln", ".fasta.gz", ".fa.gz", ".afa.gz", ".aln.gz"})
+            ok = ok || has_suffix(nm, suf);
+        if (!ok) continue;
+        Job j;
+        j.path = o.batch_dir + "/" + nm;
+        j.name = strip_fasta_suffix(nm);
+        struct stat sb;
+        if (stat(j.path.c_str(), &sb) == 0) j.bytes = has_suffix(nm, ".gz") ? (int64_t)sb.st_size * 6 : (int64_t)sb.st_size;
+        jobs.push_back(j);
+    }
+    closedir(d);
+    if (jobs.empty()) die("no FASTA files in " + o.batch_dir);
+    // big first; name breaks ties so that the order is a function of the directory contents alone
+    std::sort(jobs.begin(), jobs.end(), [](const Job &a, const Job &b) { return a.bytes != b.bytes ? a.bytes > b.bytes : a.name < b.name; });
+    mkdir(o.out_dir.c_str(), 0777);
+
+    const int ndev = gdca_device_count();
+    const int G = o.gpus > 0 ? std::min(o.gpus, ndev) : ndev;
+    if (G < 1) die("no HIP device (there is no CPU fallback)");
+
+    // parser threads fill a bounded queue of parsed families in job order; GPU workers pull from it
+    std::mutex mu;
+    std::condition_variable cv_ready, cv_space;
+    std::deque<Family> ready;
+    size_t next_job = 0, parsed_done = 0;
+    const size_t cap = (size_t)std::max(2 * G, 4);
+    std::atomic<int> failures{0};
+
+    auto parser = [&]() {
+        for (;;) {
+            size_t idx;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_space.wait(lk, [&] { return ready.size() < cap || next_job >= jobs.size(); });
+                if (next_job >= jobs.size()) return;
+                idx = next_job++;
+                if (next_job >= jobs.size()) cv_space.notify_all();
+            }
+            Family f;
+            f.path = jobs[idx].path;
+            f.name = jobs[idx].name;
+            load_family(o, f);  // errors travel with the family and are reported by the worker
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready.push_back(std::move(f));
+                ++parsed_done;
+            }
+            cv_ready.notify_all();
+        }
+    };
+    const double t0 = now();
+    std::vector<double> busy((size_t)G, 0.0);
+    std::vector<int> count((size_t)G, 0);
+    auto worker = [&](int g) {
+        gdca_ctx *ctx = nullptr;
+        if (gdca_ctx_create(g, &ctx) != GDCA_OK) {
+            fprintf(stderr, "ERROR: cannot create a context on GPU %d\n", g);
+            ++failures;
+            return;
+        }
+        for (;;) {
+            Family f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_ready.wait(lk, [&] { return !ready.empty() || parsed_done >= jobs.size(); });
+                if (ready.empty()) break;
+                f = std::move(ready.front());
+                ready.pop_front();
+            }
+            cv_space.notify_one();
+            if (!f.error.empty()) {
+                fprintf(stderr, "ERROR: %s\n", f.error.c_str());
+                ++failures;
+                continue;
+            }
+            gdca_stats st{};
+            std::string err;
+            const double t = now();
+            const bool ok = process(ctx, o, f, o.out_dir + "/" + f.name + ".rank.txt", &st, &err);
+            const double dt = now() - t;
+            busy[(size_t)g] += dt;
+            count[(size_t)g] += 1;
+            if (!ok) {
+                fprintf(stderr, "ERROR: %s: %s\n", f.name.c_str(), err.c_str());
+                ++failures;
+                continue;
+            }
+            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", g,
+                    f.name.c_str(), f.N, f.M, f.q, st.theta, st.Meff, f.parse_s, st.ms_total, dt);
+        }
+        gdca_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> threads;
+    for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
+    for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
+    for (auto &t : threads) t.join();
+    const double wall = now() - t0;
+    fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
+            (double)jobs.size() / wall, failures.load());
+    for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", g, count[(size_t)g], busy[(size_t)g]);
+    return failures.load() ? 1 : 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    for (int a = 1; a < argc; ++a) {
+        const std::string s = argv[a];
+        auto val = [&]() -> const char * {
+            if (a + 1 >= argc) die("missing value after " + s);
+            return argv[++a];
+        };
+        if (s == "--pseudocount") o.pseudocount = atof(val());
+        else if (s == "--theta") {
+            const std::string v = val();
+            o.theta = (v == "auto" || v == ":auto") ? -1.0 : atof(v.c_str());
+            if (!(v == "auto" || v == ":auto") && o.theta < 0) die("invalid theta value: " + v + " (must be either :auto, or a number between 0 and 1)");
+        } else if (s == "--max_gap_fraction") o.max_gap_fraction = atof(val());
+        else if (s == "--score") {
+            const std::string v = val();
+            if (v == "frob" || v == ":frob") o.score = GDCA_SCORE_FROB;
+            else if (v == "DI" || v == ":DI") o.score = GDCA_SCORE_DI;
+            else die("invalid score value: " + v + " (must be either :DI or :frob)");
+        } else if (s == "--min_separation") o.min_separation = atoi(val());
+        else if (s == "--remove_dups") o.remove_dups = true;
+        else if (s == "--batch") o.batch_dir = val();
+        else if (s == "--out") o.out_dir = val();
+        else if (s == "--gpus") o.gpus = atoi(val());
+        else if (s == "--parsers") o.parsers = atoi(val());
+        else if (s == "--synth") {
+            if (a + 4 >= argc) die("usage: --synth N M SEED out.fasta[.gz]");
+            const int N = atoi(argv[a + 1]), M = atoi(argv[a + 2]);
+            const uint64_t seed = strtoull(argv[a + 3], nullptr, 0);
+            std::vector<int8_t> Z((size_t)std::max(N, 1) * std::max(M, 1));
+            if (gdca_synth_family(N, M, 21, seed, Z.data()) != GDCA_OK) die("invalid --synth sizes");
+            if (gdca_write_fasta(argv[a + 4], Z.data(), N, M) != GDCA_OK) die(std::string("cannot write ") + argv[a + 4]);
+            return 0;
+        } else if (s == "-h" || s == "--help") {
+            printf("usage: gdca_cli [--pseudocount X] [--theta auto|X] [--max_gap_fraction X] [--score frob|DI]\n"
+                   "                [--min_separation K] [--remove_dups] alignment.fasta[.gz] [ranking.txt]\n"
+                   "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P]\n"
+                   "       gdca_cli --synth N M SEED out.fasta[.gz]\n");
+            return 0;
+        } else if (!s.empty() && s[0] == '-' && s.size() > 1) die("unknown option " + s);
+        else o.positional.push_back(s);
+    }
+    check_arguments(o);
+    if (!o.batch_dir.empty()) {
+        if (o.out_dir.empty()) die("--batch needs --out OUTDIR");
+        return run_batch(o);
+    }
+    if (o.positional.empty()) die("no alignment given (see --help)");
+    Family f;
+    f.path = o.positional[0];
+    struct stat sb;
+    if (stat(f.path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) die("cannot open file " + f.path);
+    if (!load_family(o, f)) die(f.error);
+    gdca_ctx *ctx = nullptr;
+    if (gdca_ctx_create(0, &ctx) != GDCA_OK) die("no usable HIP device (there is no CPU fallback)");
+    gdca_stats st{};
+    std::string err;
+    const bool ok = process(ctx, o, f, o.positional.size() > 1 ? o.positional[1] : std::string(), &st, &err);
+    if (ok)
+        fprintf(stderr, "theta = %.16g threshold = %d\nM = %d N = %d Meff = %.16g\ndevice %.2f ms (inverse %.2f ms)\n", st.theta,
+                st.thresh, f.M, f.N, st.Meff, st.ms_total, st.ms_inverse);
+    else
+        fprintf(stderr, "ERROR: %s\n", err.c_str());
+    gdca_ctx_destroy(ctx);
+    return ok ? 0 : 1;
+}

@@ -206,4 +206,97 @@ gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j
     return GDCA_OK;
 }
 
+// ---- synthetic families ----------------------------------------------------------------------
+namespace {
+struct SplitMix {
+    uint64_t s;
+    // stream (tag, idx) of a seed: the start state is itself a SplitMix64 output, so streams do not overlap in practice
+    SplitMix(uint64_t seed, uint64_t tag, uint64_t idx) : s(seed ^ (tag << 56) ^ idx) { s = next(); }
+    uint64_t next()
+    {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    uint32_t below(uint32_t n) { return (uint32_t)(((next() >> 32) * (uint64_t)n) >> 32); }
+};
+// one draw per site: high 32 bits against the threshold, low 32 bits pick the replacement symbol 1..q-1
+inline int8_t resample(uint64_t r, uint32_t thresh, uint32_t nsym, int8_t keep)
+{
+    return (uint32_t)(r >> 32) < thresh ? (int8_t)(1 + (((r & 0xFFFFFFFFull) * nsym) >> 32)) : keep;
+}
+}  // namespace
+
+gdca_status gdca_synth_family(int32_t N, int32_t M, int32_t q, uint64_t seed, int8_t *Z)
+{
+    if (!Z || N < 1 || M < 1 || q < 2 || q > 31) return GDCA_EINVAL;
+    static const uint32_t kMu[6] = {85899345u, 214748364u, 429496729u, 858993459u, 1288490188u, 2147483648u};
+    const uint32_t nsym = (uint32_t)(q - 1);
+    std::vector<int8_t> root((size_t)N);
+    {
+        SplitMix g(seed, 0, 0);
+        for (int32_t i = 0; i < N; ++i) root[(size_t)i] = (int8_t)(1 + g.below(nsym));
+    }
+    const int32_t K = (M + 24) / 25;
+    std::vector<int8_t> centres((size_t)K * N);
+    for (int32_t c = 0; c < K; ++c) {
+        SplitMix g(seed, 1, (uint64_t)c);
+        for (int32_t i = 0; i < N; ++i) centres[(size_t)c * N + i] = resample(g.next(), 1u << 30, nsym, root[(size_t)i]);
+    }
+    const uint32_t maxlen = (uint32_t)std::max(2, N / 10);
+    for (int32_t k = 0; k < M; ++k) {
+        SplitMix g(seed, 2, (uint64_t)k);
+        const int8_t *cen = centres.data() + (size_t)g.below((uint32_t)K) * N;
+        const uint32_t thr = kMu[g.below(6)];
+        int8_t *row = Z + (size_t)k * N;
+        for (int32_t i = 0; i < N; ++i) row[i] = resample(g.next(), thr, nsym, cen[i]);
+        const uint32_t nruns = g.below(4);
+        for (uint32_t r = 0; r < nruns; ++r) {
+            const uint32_t a = g.below((uint32_t)N);
+            const uint32_t len = 1 + g.below(maxlen);
+            for (uint32_t i = a; i < std::min((uint32_t)N, a + len); ++i) row[i] = (int8_t)q;
+        }
+    }
+    return GDCA_OK;
+}
+
+gdca_status gdca_write_fasta(const char *path, const int8_t *Z, int32_t N, int32_t M)
+{
+    if (!path || !Z || N < 1 || M < 0) return GDCA_EINVAL;
+    static const char L[] = "?ACDEFGHIKLMNPQRSTVWY-";
+    std::string out;
+    out.reserve((size_t)M * ((size_t)N + 16));
+    char hdr[32];
+    for (int32_t k = 0; k < M; ++k) {
+        out.append(hdr, (size_t)snprintf(hdr, sizeof hdr, ">s%d\n", k));
+        for (int32_t i = 0; i < N; ++i) {
+            const int8_t a = Z[(size_t)k * N + i];
+            if (a < 1 || a > 21) return GDCA_EINVAL;
+            out.push_back(L[a]);
+        }
+        out.push_back('\n');
+    }
+    const size_t plen = strlen(path);
+    if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) {
+        gzFile f = gzopen(path, "wb1");
+        if (!f) return GDCA_EINVAL;
+        size_t off = 0;
+        while (off < out.size()) {
+            const unsigned n = (unsigned)std::min<size_t>(out.size() - off, 1u << 30);
+            if (gzwrite(f, out.data() + off, n) != (int)n) {
+                gzclose(f);
+                return GDCA_EINVAL;
+            }
+            off += n;
+        }
+        return gzclose(f) == Z_OK ? GDCA_OK : GDCA_EINVAL;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return GDCA_EINVAL;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (fclose(f) == 0 && ok) ? GDCA_OK : GDCA_EINVAL;
+}
+
 }  // extern "C"

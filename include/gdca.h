@@ -171,6 +171,15 @@ gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int
 gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len);
 
 /* ---- measurement helpers (bench.py / profiles; not part of the reference surface) ------- */
+/* Deterministic "Pfam-like" synthetic family: SplitMix64 streams, integer-threshold draws only, so
+ * the same (N, M, q, seed) gives the same bytes everywhere.  Root sequence uniform over 1..q-1; ceil(M/25) cluster
+ * centres = root with each site resampled w.p. 1/4; each sequence = a uniformly chosen centre with per-sequence
+ * mutation rate from {.02,.05,.1,.2,.3,.5}, then 0-3 gap runs (symbol q) of length U[1, max(2, N/10)].
+ * Z is [M][N] (= the N x M column-major matrix).  Needs 2 <= q <= 31. */
+gdca_status gdca_synth_family(int32_t N, int32_t M, int32_t q, uint64_t seed, int8_t *Z);
+/* Write Z as FASTA (letters of read_fasta_alignment's map, q=21 symbol '-'; headers ">s<k>"); gzip when the path
+ * ends in ".gz".  So a reference installation can be fed the same family gdca_synth_family produced. */
+gdca_status gdca_write_fasta(const char *path, const int8_t *Z, int32_t N, int32_t M);
 /* Dense f64 MFMA issue-rate probe: returns achieved TFLOP/s of a register-resident
  * v_mfma_f64_16x16x4_f64 loop on every CU. */
 gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops);
