@@ -5,12 +5,14 @@
 // Plain C++ (no HIP): these are host code in the reference too; they live in libgdca.so so that an
 // end-to-end gDCA(filename) spends its time on the GPU, not in an interpreter loop.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -37,28 +39,107 @@ struct LetterMap {
 };
 const LetterMap kMap;
 
+// whole file into memory; gzip (magic 1f 8b) through zlib, anything else with one read
 bool slurp(const char *path, std::string &out)
 {
-    gzFile f = gzopen(path, "rb");  // reads plain files transparently
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, fp);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {
+        if (fseek(fp, 0, SEEK_END) != 0) {
+            fclose(fp);
+            return false;
+        }
+        const long sz = ftell(fp);
+        if (sz < 0) {
+            fclose(fp);
+            return false;
+        }
+        rewind(fp);
+        out.resize((size_t)sz);
+        const size_t n = sz ? fread(&out[0], 1, (size_t)sz, fp) : 0;
+        fclose(fp);
+        return n == (size_t)sz;
+    }
+    // gzip: the trailer's ISIZE (uncompressed size mod 2^32) sizes the buffer up front
+    size_t hint = 0;
+    if (fseek(fp, -4, SEEK_END) == 0) {
+        unsigned char t[4];
+        if (fread(t, 1, 4, fp) == 4) hint = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    }
+    fclose(fp);
+    gzFile f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
-    std::vector<char> buf(1 << 22);
+    out.resize(std::max<size_t>(hint, 1 << 16));
+    size_t len = 0;
     for (;;) {
-        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (len == out.size()) out.resize(out.size() * 2);
+        const unsigned want = (unsigned)std::min<size_t>(out.size() - len, 1u << 30);
+        const int n = gzread(f, &out[len], want);
         if (n < 0) {
             gzclose(f);
             return false;
         }
         if (n == 0) break;
-        out.append(buf.data(), (size_t)n);
+        len += (size_t)n;
     }
     gzclose(f);
+    out.resize(len);
     return true;
 }
 
 inline bool is_space(char c)
 {
     return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f';
+}
+
+struct Span {
+    size_t a, b;  // [a, b)
+};
+
+// run fn(t) for t = 0..T-1 on T threads (inline when T == 1)
+template <class F>
+void parallel(int T, F fn)
+{
+    if (T <= 1) {
+        fn(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)T - 1);
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+}
+
+// the stripped non-empty lines of text[a, b), concatenated (what the reference's reader hands back as one
+// sequence); `single` is set when the body is exactly one line, in which case nothing is copied
+std::string_view body_sequence(const std::string &text, Span body, std::string &scratch)
+{
+    std::string_view first;
+    int pieces = 0;
+    size_t pos = body.a;
+    while (pos < body.b) {
+        const char *nl = (const char *)memchr(text.data() + pos, '\n', body.b - pos);
+        const size_t eol = nl ? (size_t)(nl - text.data()) : body.b;
+        size_t a = pos, b = eol;
+        while (a < b && is_space(text[a])) ++a;
+        while (b > a && is_space(text[b - 1])) --b;
+        if (b > a) {
+            if (pieces == 0) {
+                first = std::string_view(text.data() + a, b - a);
+            } else {
+                if (pieces == 1) scratch.assign(first.data(), first.size());
+                scratch.append(text, a, b - a);
+            }
+            ++pieces;
+        }
+        pos = eol + 1;
+    }
+    return pieces <= 1 ? first : std::string_view(scratch);
 }
 
 }  // namespace
@@ -71,31 +152,40 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     *out = nullptr;
     std::string text;
     if (!slurp(path, text)) return GDCA_EINVAL;
-
-    // records: header line starting with '>', then sequence lines (stripped, concatenated)
-    std::vector<std::string> seqs;
-    bool in_record = false;
-    size_t pos = 0;
     const size_t L = text.size();
-    while (pos < L) {
-        size_t eol = text.find('\n', pos);
-        if (eol == std::string::npos) eol = L;
-        size_t a = pos, b = eol;
-        while (a < b && is_space(text[a])) ++a;
-        while (b > a && is_space(text[b - 1])) --b;
-        if (b > a) {
-            if (text[a] == '>') {
-                seqs.emplace_back();
-                in_record = true;
-            } else if (in_record) {
-                seqs.back().append(text, a, b - a);
-            }
-        }
-        pos = eol + 1;
-    }
-    if (seqs.empty()) return GDCA_EINVAL;
+    const int T = L < (1u << 20) ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
 
-    const std::string &first = seqs[0];
+    // pass 1: header lines (first non-space character '>'), found per chunk of whole lines
+    std::vector<size_t> cut((size_t)T + 1, L);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const size_t guess = L / (size_t)T * (size_t)t;
+        const char *nl = guess < L ? (const char *)memchr(text.data() + guess, '\n', L - guess) : nullptr;
+        cut[(size_t)t] = nl ? (size_t)(nl - text.data()) + 1 : L;
+    }
+    std::vector<std::vector<Span>> found((size_t)T);
+    parallel(T, [&](int t) {
+        size_t pos = cut[(size_t)t];
+        const size_t end = cut[(size_t)t + 1];
+        auto &mine = found[(size_t)t];
+        while (pos < end) {
+            const char *nl = (const char *)memchr(text.data() + pos, '\n', L - pos);
+            const size_t eol = nl ? (size_t)(nl - text.data()) : L;
+            size_t a = pos;
+            while (a < eol && is_space(text[a])) ++a;
+            if (a < eol && text[a] == '>') mine.push_back({pos, eol});
+            pos = eol + 1;
+        }
+    });
+    std::vector<Span> headers;
+    for (auto &v : found) headers.insert(headers.end(), v.begin(), v.end());
+    const size_t R = headers.size();
+    if (R == 0) return GDCA_EINVAL;
+    auto body_of = [&](size_t r) { return Span{std::min(L, headers[r].b + 1), r + 1 < R ? headers[r + 1].a : L}; };
+
+    // the first sequence fixes the alignment columns: everything except '.' and lowercase letters
+    std::string scratch0;
+    const std::string first(body_sequence(text, body_of(0), scratch0));
     std::vector<uint32_t> cols;
     for (size_t p = 0; p < first.size(); ++p) {
         const char c = first[p];
@@ -107,24 +197,42 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     gdca_fasta *h = new (std::nothrow) gdca_fasta();
     if (!h) return GDCA_ENOMEM;
     h->N = n;
-    h->Z.reserve((size_t)n * seqs.size());
-    std::vector<int8_t> row((size_t)n);
-    for (const std::string &sq : seqs) {
-        if (sq.size() != first.size()) {
-            delete h;
-            return GDCA_EINVAL;  // "inputs are not aligned"
+    h->Z.resize((size_t)n * R);
+    std::vector<uint8_t> keep(R, 0);
+    std::atomic<bool> misaligned{false};
+    // pass 2: records in parallel: letter map + gap-fraction filter, every record into its own row
+    parallel(T, [&](int t) {
+        std::string scratch;
+        const size_t r0 = R * (size_t)t / (size_t)T, r1 = R * ((size_t)t + 1) / (size_t)T;
+        for (size_t r = r0; r < r1 && !misaligned.load(std::memory_order_relaxed); ++r) {
+            const std::string_view sq = body_sequence(text, body_of(r), scratch);
+            if (sq.size() != first.size()) {
+                misaligned = true;  // "inputs are not aligned"
+                return;
+            }
+            int8_t *row = h->Z.data() + r * (size_t)n;
+            int ngaps = 0;
+            for (int32_t i = 0; i < n; ++i) {
+                const unsigned char c = (unsigned char)sq[cols[(size_t)i]];
+                ngaps += (c == '-');
+                row[i] = kMap.t[c];
+            }
+            keep[r] = (double)ngaps / (double)n <= max_gap_fraction;
         }
-        int ngaps = 0;
-        for (int32_t i = 0; i < n; ++i) {
-            const unsigned char c = (unsigned char)sq[cols[i]];
-            ngaps += (c == '-');
-            row[i] = kMap.t[c];
-        }
-        if ((double)ngaps / (double)n <= max_gap_fraction) {
-            h->Z.insert(h->Z.end(), row.begin(), row.end());
-            h->M += 1;
-        }
+    });
+    if (misaligned) {
+        delete h;
+        return GDCA_EINVAL;
     }
+    // pass 3: drop the filtered rows, order preserved
+    size_t m = 0;
+    for (size_t r = 0; r < R; ++r)
+        if (keep[r]) {
+            if (m != r) memcpy(h->Z.data() + m * (size_t)n, h->Z.data() + r * (size_t)n, (size_t)n);
+            ++m;
+        }
+    h->M = (int32_t)m;
+    h->Z.resize(m * (size_t)n);
     *out = h;
     *N = h->N;
     *M = h->M;
