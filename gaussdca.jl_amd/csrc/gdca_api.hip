@@ -127,7 +127,29 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     ctx->lookahead = getenv("GDCA_NO_LOOKAHEAD") == nullptr;
-    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
+    // The side stream carries the big trailing updates of the SPD inverse.  Its CU mask leaves ONE compute unit
+    // out, so the single-workgroup pivot kernel of the look-ahead chain (main stream) always finds an idle CU
+    // instead of waiting for register space beside two 256-VGPR update workgroups (0.4 % of the chip for a
+    // pivot that runs at its stand-alone speed).  GDCA_RESERVE_CU=0 turns it off.
+    ctx->side = nullptr;
+    if (!(getenv("GDCA_RESERVE_CU") && atoi(getenv("GDCA_RESERVE_CU")) == 0)) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount >= 64) {
+            const int ncu = prop.multiProcessorCount;
+            uint32_t mask[16];
+            const int words = (ncu + 31) / 32;
+            for (int w = 0; w < words && w < 16; ++w) {
+                const int bits = ncu - 32 * w >= 32 ? 32 : ncu - 32 * w;
+                mask[w] = bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+            }
+            mask[0] &= ~1u;
+            if (hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->side = nullptr;
+            }
+        }
+    }
+    if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
         free(ctx);
         return GDCA_EHIP;
     }
@@ -344,12 +366,16 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     gdca_inverse_ws ws;
     ws.G[0] = ws.G[1] = (double *)ctx->G.p;
     ws.H[0] = ws.H[1] = (double *)ctx->H.p;
+    ws.G[2] = ws.G[3] = ws.H[2] = ws.H[3] = nullptr;
     ws.P = (double *)ctx->P.p;
     if (la) {
-        CHK(ensure(ctx, ctx->G2, pbytes));
-        CHK(ensure(ctx, ctx->H2, pbytes));
-        ws.G[1] = (double *)ctx->G2.p;
-        ws.H[1] = (double *)ctx->H2.p;
+        // four G and four H panels (pivot pairs, double-buffered by pair parity) carved from two buffers
+        CHK(ensure(ctx, ctx->G2, 3 * pbytes));
+        CHK(ensure(ctx, ctx->H2, 3 * pbytes));
+        for (int w = 1; w < 4; ++w) {
+            ws.G[w] = (double *)((char *)ctx->G2.p + (size_t)(w - 1) * pbytes);
+            ws.H[w] = (double *)((char *)ctx->H2.p + (size_t)(w - 1) * pbytes);
+        }
         CHK(need_sync_events(ctx, 2 * nblk));
     }
     hipEvent_t *uev = nullptr;

@@ -157,15 +157,21 @@ template <bool GT, int TM>
 __device__ __forceinline__ void stage_load(StageRegs<TM> &R, const double *__restrict__ gsrc, size_t gld,
                                            const double *__restrict__ hsrc, size_t hld, int kc, int tid)
 {
+    // addresses = (wave-uniform row base) + (one 32-bit per-thread offset): the bases stay in SGPRs and the loads
+    // take the saddr form, so the staging costs one address VGPR per operand instead of a 64-bit pointer per load
+    if (!GT) {
+        const unsigned boff = ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)gld) * 8u;  // bytes
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int idx = tid + 256 * u;
-        if (!GT) {
-            const int kk = idx >> 6, r2 = idx & 63;
-            const double2 v = *reinterpret_cast<const double2 *>(gsrc + (size_t)(r2 * 2) + (size_t)(kc + kk) * gld);
+        for (int u = 0; u < 4; ++u) {
+            const char *rowbase = reinterpret_cast<const char *>(gsrc + (size_t)(kc + 4 * u) * gld);
+            const double2 v = *reinterpret_cast<const double2 *>(rowbase + boff);
             R.g[2 * u] = v.x;
             R.g[2 * u + 1] = v.y;
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u;
             const int r = idx >> 3, k2 = idx & 7;
             const double2 v = *reinterpret_cast<const double2 *>(gsrc + (size_t)(kc + k2 * 2) + (size_t)r * gld);
             R.g[2 * u] = v.x;
@@ -173,13 +179,24 @@ __device__ __forceinline__ void stage_load(StageRegs<TM> &R, const double *__res
         }
     }
     constexpr int CP = 16 * TM;  // double2 per k-row of the H chunk
+    if (CP == 64) {
+        const unsigned boff = ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)hld) * 8u;
 #pragma unroll
-    for (int u = 0; u < TM; ++u) {
-        const int idx = tid + 256 * u;
-        const int kk = idx / CP, c2 = idx % CP;
-        const double2 w = *reinterpret_cast<const double2 *>(hsrc + (size_t)(c2 * 2) + (size_t)(kc + kk) * hld);
-        R.h[2 * u] = w.x;
-        R.h[2 * u + 1] = w.y;
+        for (int u = 0; u < TM; ++u) {
+            const char *rowbase = reinterpret_cast<const char *>(hsrc + (size_t)(kc + 4 * u) * hld);
+            const double2 w = *reinterpret_cast<const double2 *>(rowbase + boff);
+            R.h[2 * u] = w.x;
+            R.h[2 * u + 1] = w.y;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < TM; ++u) {
+            const int idx = tid + 256 * u;
+            const int kk = idx / CP, c2 = idx % CP;
+            const double2 w = *reinterpret_cast<const double2 *>(hsrc + (size_t)(c2 * 2) + (size_t)(kc + kk) * hld);
+            R.h[2 * u] = w.x;
+            R.h[2 * u + 1] = w.y;
+        }
     }
 }
 
@@ -260,6 +277,69 @@ __device__ __forceinline__ void tile_product(double4_t (&acc)[TM][4], const doub
         chunk_mma<TM>(acc, Gs, Hs, wr, wc, lane);
     }
 }
+
+// The update kernel's variant of tile_product: acc starts at ZERO and the 128 x 128 tile of C it is added to is
+// fetched in eight pieces, one per k-chunk, each consumed one chunk after it was requested.  The tile's 128 KB
+// then stream in underneath the MFMAs instead of as one blocking burst in front of them (every workgroup of a
+// launch runs in lockstep, so that burst was 64 MB at once: measured 6 of the 39 us a tile takes).
+// Piece ci = accumulators (tm = ci / 2, tn = 2 (ci % 2) + {0, 1}, reg 0..3): 8 doubles per lane.
+template <int CI>
+__device__ __forceinline__ void cpiece_load(double (&cp)[8], const double *__restrict__ At, size_t ld, int wr, int wc,
+                                            int l15, int lq)
+{
+    constexpr int tm = CI / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int tn = 2 * (CI % 2) + h;
+            const int r = wr * 64 + tn * 16 + l15;
+            const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+            cp[h * 4 + reg] = At[(size_t)r + (size_t)c * ld];
+        }
+}
+
+template <int CI>
+__device__ __forceinline__ void cpiece_add(double4_t (&acc)[4][4], const double (&cp)[8])
+{
+    constexpr int tm = CI / 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[tm][2 * (CI % 2) + h][reg] += cp[h * 4 + reg];
+}
+
+// DUAL: two pivots fused in one pass -- the k loop runs over (G, H) of the first pivot (these unrolled chunks,
+// which also bring in the C tile) and then over (G2, H2) of the second (a plain rolled loop in the kernel), K = 256:
+// the C tile is read and written once per TWO rank-128 updates.  The last chunk here prefetches the first chunk of
+// the second pair.
+template <int CI, bool DUAL>
+struct UpdateChunks {
+    static constexpr int PER = T / KC;  // chunks per operand pair
+    static __device__ __forceinline__ void run(double4_t (&acc)[4][4], StageRegs<4> &R, double (&cp)[8],
+                                               const double *__restrict__ g1, const double *__restrict__ h1,
+                                               const double *__restrict__ g2, const double *__restrict__ h2, size_t pld,
+                                               double (*Gs)[LDS_LD], double (*Hs)[LDS_LD],
+                                               const double *__restrict__ At, size_t ld)
+    {
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+        __syncthreads();  // previous chunk's LDS reads are done
+        stage_store<false, 4>(R, Gs, Hs, tid);
+        __syncthreads();
+        if constexpr (CI > 0) cpiece_add<(CI > 0 ? CI - 1 : 0)>(acc, cp);  // requested one chunk ago
+        cpiece_load<CI>(cp, At, ld, wr, wc, l15, lq);
+        if constexpr (CI + 1 < PER)
+            stage_load<false, 4>(R, g1, pld, h1, pld, (CI + 1) * KC, tid);
+        else if constexpr (DUAL)
+            stage_load<false, 4>(R, g2, pld, h2, pld, 0, tid);
+        chunk_mma<4>(acc, Gs, Hs, wr, wc, lane);
+        if constexpr (CI + 1 < PER)
+            UpdateChunks<CI + 1, DUAL>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
+        else
+            cpiece_add<CI>(acc, cp);
+    }
+};
 
 // Panel: for every row block i != k:  G_i = column block k of the symmetric matrix (read from the
 // lower triangle: A[i,k] for i > k, A[k,i]^T for i < k);  GP = G_i P;  writes
@@ -357,14 +437,19 @@ __global__ __launch_bounds__(256) void k_panel_writeback(double *__restrict__ A,
     panel_writeback_tile(A, ld, kblk, i, Hbuf, pld, Ts);
 }
 
-// Update: lower-triangle tiles  A_IJ += G_I * H_J^T   (H = -G P), in one of two tile sets:
-//   colblk <  0 : every tile (I >= J) with I, J not in {skip0, skip1}   (skip1 = -1: only skip0)
-//   colblk >= 0 : the nblk-1 tiles that involve block `colblk` as row or column (I != skip0) --
-//                 the look-ahead slice that the next pivot and panel need first; workgroups past those
-//                 nblk-1 do the write-back of the pivot column block skip0 (see panel_writeback_tile).
-__global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int skip0, int skip1,
+// Update: lower-triangle tiles  A_IJ += G_I H_J^T (+ G2_I H2_J^T when G2 != nullptr),  H = -G P, in one of two tile
+// sets; blocks in the contiguous range [skip_lo, skip_lo + skip_n) never take part:
+//   colblk <  0 : every tile (I >= J) over the remaining blocks
+//   colblk >= 0 : the nslice = nblk - skip_n tiles that involve block `colblk` as row or column -- a look-ahead
+//                 slice; workgroups past those do the write-back of the pivot column block wb_col from wbH
+//                 (see panel_writeback_tile) when wb_col >= 0.
+template <bool DUAL>
+__global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int skip_lo, int skip_n,
                                                           int colblk, int nslice, const double *__restrict__ Gbuf,
-                                                          const double *__restrict__ Hbuf, size_t pld)
+                                                          const double *__restrict__ Hbuf,
+                                                          const double *__restrict__ G2buf,
+                                                          const double *__restrict__ H2buf, size_t pld, int wb_col,
+                                                          const double *__restrict__ wbH)
 {
     __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
@@ -372,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
     int I, J;
     if (colblk >= 0 && t >= nslice) {
         int b = t - nslice;
-        if (b >= skip0) ++b;
-        panel_writeback_tile(A, ld, skip0, b, Hbuf, pld, Gs);
+        if (b >= wb_col) ++b;
+        panel_writeback_tile(A, ld, wb_col, b, wbH, pld, Gs);
         return;
     }
     if (colblk >= 0) {
         int b = t;
-        if (b >= skip0) ++b;
+        if (b >= skip_lo) b += skip_n;
         I = b > colblk ? b : colblk;
         J = b > colblk ? colblk : b;
     } else {
@@ -386,10 +471,8 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
         while ((long long)ii * (ii + 1) / 2 > t) --ii;
         while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
         int jj = t - (int)((long long)ii * (ii + 1) / 2);
-        if (ii >= skip0) ++ii;
-        if (skip1 >= 0 && ii >= skip1) ++ii;
-        if (jj >= skip0) ++jj;
-        if (skip1 >= 0 && jj >= skip1) ++jj;
+        if (ii >= skip_lo) ii += skip_n;
+        if (jj >= skip_lo) jj += skip_n;
         I = ii;
         J = jj;
     }
@@ -401,14 +484,26 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                acc[tm][tn][reg] = At[(size_t)r + (size_t)c * ld];
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        StageRegs<4> R;
+        double cp[8];
+        const double *g1 = Gbuf + (size_t)I * T, *h1 = Hbuf + (size_t)J * T;
+        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
+        if constexpr (DUAL) {
+            const double *g2 = G2buf + (size_t)I * T, *h2 = H2buf + (size_t)J * T;
+            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
+            for (int kc = 0; kc < T; kc += KC) {  // second pivot of the pair: chunk 0 is already in R
+                __syncthreads();
+                stage_store<false, 4>(R, Gs, Hs, tid);
+                __syncthreads();
+                if (kc + KC < T) stage_load<false, 4>(R, g2, pld, h2, pld, kc + KC, tid);
+                chunk_mma<4>(acc, Gs, Hs, wr, wc, lane);
             }
-    tile_product<false, 4>(acc, Gbuf + (size_t)I * T, pld, Hbuf + (size_t)J * T, pld, Gs, Hs, nullptr, 0);
+        } else {
+            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
+        }
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -421,11 +516,13 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
             }
 }
 
-// Host driver of the block sweep.  With a side stream (s1 != nullptr) it runs with look-ahead:
-// for step k the slice of the update that touches block k+1 goes first on the main stream,
-// followed by pivot(k+1) and panel(k+1), while the rest of update k (the big launch) runs on the
-// side stream; G/H panels are double-buffered by step parity.  Steady state: the side stream
-// executes the big update launches back to back and the pivot/panel chain hides behind them.
+// Host driver of the block sweep.  With a side stream (s1 != nullptr) it runs with look-ahead, by default in
+// PAIRS of pivots: the big trailing update of pivots (2p, 2p+1) is ONE launch with K = 256 on the side stream
+// (half the C-tile traffic per flop of two K = 128 launches -- the trailing update is HBM-bound otherwise), while
+// the main (high-priority) stream runs the chain of the next pair: the slices of the pair update that touch
+// blocks 2p+2 and 2p+3, pivot/panel of 2p+2, its rank-128 update of column 2p+3, pivot/panel of 2p+3 and that
+// pivot's update of column 2p+2.  Panels are double-buffered by pair parity.  The single-pivot look-ahead
+// (GDCA_PAIRS=0) and the serial schedule (s1 == nullptr) are kept for small matrices and for comparison.
 void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
                              gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev, int max_upd_ev,
                              int *n_upd_launch, double *upd_flops)
@@ -435,49 +532,113 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     const double tile_flops = 2.0 * T * T * T;
     int nl = 0;
     double fl = 0.0;
-    auto timed_update = [&](hipStream_t st, unsigned ntile, int skip0, int skip1, const double *G, const double *H) {
+    // big launch over all blocks outside [skip_lo, skip_lo + skip_n)
+    auto timed_update = [&](hipStream_t st, int skip_lo, int skip_n, const double *G, const double *H, const double *G2,
+                            const double *H2) {
+        const int m = nblk - skip_n;
+        if (m <= 0) return;
+        const unsigned ntile = (unsigned)((long long)m * (m + 1) / 2);
         const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
         if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
-        hipLaunchKernelGGL(k_sweep_update, dim3(ntile), dim3(256), 0, st, A, ld, skip0, skip1, -1, 0, G, H, ld);
+        if (G2)
+            hipLaunchKernelGGL(k_sweep_update<true>, dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G, H, G2,
+                               H2, ld, -1, (const double *)nullptr);
+        else
+            hipLaunchKernelGGL(k_sweep_update<false>, dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G, H, G2,
+                               H2, ld, -1, (const double *)nullptr);
         if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
         ++nl;
-        fl += tile_flops * (double)ntile;
+        fl += tile_flops * (double)ntile * (G2 ? 2.0 : 1.0);
     };
+    // slice: the tiles that involve block col (other index outside the skip range), plus, when wb_col >= 0, the
+    // write-back of pivot column wb_col from wbH
+    auto slice = [&](hipStream_t st, int col, int skip_lo, int skip_n, const double *G, const double *H, const double *G2,
+                     const double *H2, int wb_col, const double *wbH) {
+        const int ns = nblk - skip_n;
+        const dim3 grid(ns + (wb_col >= 0 ? nblk - 1 : 0));
+        if (G2)
+            hipLaunchKernelGGL(k_sweep_update<true>, grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2, H2, ld,
+                               wb_col, wbH);
+        else
+            hipLaunchKernelGGL(k_sweep_update<false>, grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2, H2,
+                               ld, wb_col, wbH);
+    };
+    auto pivot = [&](int k) {
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, k * T, ws.P, sc, n_real);
+    };
+    auto panel = [&](int k, double *G, double *H) {
+        hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, G, H, ld);
+    };
+    static const bool pairs_on = !(getenv("GDCA_PAIRS") && atoi(getenv("GDCA_PAIRS")) == 0);
 
-    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, 0, ws.P, sc, n_real);
+    pivot(0);
     if (nblk > 1) {
-        hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, 0, ws.P, ws.G[0], ws.H[0], ld);
         if (!s1) {
             // serial schedule: pivot -> panel -> write-back -> full update, one stream
-            hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, 0, ws.H[0], ld);
             for (int k = 0; k < nblk; ++k) {
-                if (k > 0) {
-                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, k * T, ws.P, sc, n_real);
-                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, ws.G[0], ws.H[0], ld);
-                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.H[0], ld);
-                }
-                const int m = nblk - 1;
-                timed_update(s0, (unsigned)((long long)m * (m + 1) / 2), k, -1, ws.G[0], ws.H[0]);
+                if (k > 0) pivot(k);
+                panel(k, ws.G[0], ws.H[0]);
+                hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.H[0], ld);
+                timed_update(s0, k, 1, ws.G[0], ws.H[0], nullptr, nullptr);
             }
+        } else if (pairs_on && nblk >= 6 && ws.G[2]) {
+            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
+            // panels of pair p: G[2 (p & 1) + {0, 1}]
+            auto PG = [&](int p, int w) { return ws.G[2 * (p & 1) + w]; };
+            auto PH = [&](int p, int w) { return ws.H[2 * (p & 1) + w]; };
+            const int np = nblk / 2;
+            // chain of pair 0
+            panel(0, PG(0, 0), PH(0, 0));
+            slice(s0, 1, 0, 1, PG(0, 0), PH(0, 0), nullptr, nullptr, 0, PH(0, 0));
+            pivot(1);
+            panel(1, PG(0, 1), PH(0, 1));
+            slice(s0, 0, 1, 1, PG(0, 1), PH(0, 1), nullptr, nullptr, 1, PH(0, 1));
+            (void)hipEventRecord(Ep[0], s0);
+            for (int p = 0; p < np; ++p) {
+                const int k1 = 2 * p, k3 = k1 + 2, k4 = k1 + 3;
+                const bool has3 = k3 < nblk, has4 = k4 < nblk;
+                // side stream: the pair's update of everything outside the pair and outside the next chain's columns
+                (void)hipStreamWaitEvent(s1, Ep[p], 0);
+                timed_update(s1, k1, 2 + (has3 ? 1 : 0) + (has4 ? 1 : 0), PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1));
+                (void)hipEventRecord(Eb[p], s1);
+                if (!has3) break;
+                if (p >= 1) (void)hipStreamWaitEvent(s0, Eb[p - 1], 0);  // columns k3, k4 carry update p-1
+                slice(s0, k3, k1, 2, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr);
+                if (has4) slice(s0, k4, k1, 3, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr);
+                pivot(k3);
+                panel(k3, PG(p + 1, 0), PH(p + 1, 0));
+                if (has4) {
+                    slice(s0, k4, k3, 1, PG(p + 1, 0), PH(p + 1, 0), nullptr, nullptr, k3, PH(p + 1, 0));
+                    pivot(k4);
+                    panel(k4, PG(p + 1, 1), PH(p + 1, 1));
+                    slice(s0, k3, k4, 1, PG(p + 1, 1), PH(p + 1, 1), nullptr, nullptr, k4, PH(p + 1, 1));
+                    (void)hipEventRecord(Ep[p + 1], s0);
+                } else {
+                    // odd block count: the last pivot stands alone
+                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k3, PH(p + 1, 0), ld);
+                    (void)hipStreamWaitEvent(s0, Eb[p], 0);
+                    timed_update(s0, k3, 1, PG(p + 1, 0), PH(p + 1, 0), nullptr, nullptr);
+                }
+            }
+            (void)hipStreamWaitEvent(s0, Eb[np - 1], 0);
         } else {
             hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
+            panel(0, ws.G[0], ws.H[0]);
             (void)hipEventRecord(Ep[0], s0);
             for (int k = 0; k < nblk; ++k) {
                 const bool has_next = k + 1 < nblk;
                 const double *G = ws.G[k & 1], *H = ws.H[k & 1];
                 // side stream: everything of update k that does not touch block k+1
                 (void)hipStreamWaitEvent(s1, Ep[k], 0);
-                const int m = nblk - (has_next ? 2 : 1);
-                if (m > 0) timed_update(s1, (unsigned)((long long)m * (m + 1) / 2), k, has_next ? k + 1 : -1, G, H);
+                timed_update(s1, k, has_next ? 2 : 1, G, H, nullptr, nullptr);
                 (void)hipEventRecord(Eb[k], s1);
                 if (has_next) {
                     if (k >= 1) (void)hipStreamWaitEvent(s0, Eb[k - 1], 0);
-                    // look-ahead slice: the nblk-1 tiles in row/column k+1, then the next pivot and panel
-                    hipLaunchKernelGGL(k_sweep_update, dim3(2 * (nblk - 1)), dim3(256), 0, s0, A, ld, k, -1, k + 1, nblk - 1,
-                                       G, H, ld);
-                    hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, (k + 1) * T, ws.P, sc, n_real);
-                    hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k + 1, ws.P, ws.G[(k + 1) & 1],
-                                       ws.H[(k + 1) & 1], ld);
+                    // look-ahead slice: the nblk-1 tiles in row/column k+1 (+ write-back of column k), then the next
+                    // pivot and panel
+                    slice(s0, k + 1, k, 1, G, H, nullptr, nullptr, k, H);
+                    pivot(k + 1);
+                    panel(k + 1, ws.G[(k + 1) & 1], ws.H[(k + 1) & 1]);
                     (void)hipEventRecord(Ep[k + 1], s0);
                 } else {
                     // last pivot: no look-ahead launch to carry its column write-back
