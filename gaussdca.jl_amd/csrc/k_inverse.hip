@@ -569,7 +569,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     auto panel = [&](int k, double *G, double *H) {
         hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, G, H, ld);
     };
-    static const bool pairs_on = !(getenv("GDCA_PAIRS") && atoi(getenv("GDCA_PAIRS")) == 0);
+    // pairs pay off once the trailing update dominates (measured crossover on MI355X at 66 blocks = n ~ 8400;
+    // below that the longer chain per pivot costs more than the halved C-tile traffic saves); GDCA_PAIRS=0/1 forces
+    static const int pairs_env = getenv("GDCA_PAIRS") ? atoi(getenv("GDCA_PAIRS")) : -1;
+    const bool pairs_on = pairs_env < 0 ? nblk >= 66 : pairs_env != 0;
 
     pivot(0);
     if (nblk > 1) {
