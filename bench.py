@@ -255,7 +255,8 @@ def main():
                           "ms_score")},
             "theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"],
             "roofline": {
-                "kernel": "k_sweep_update (f64 MFMA 128x128x128 tile products of the SPD inverse)",
+                "kernel": "k_sweep_update<true,false>: trailing update of the SPD inverse, f64 MFMA 128x128 tiles, two pivots "
+                          "per launch (K=256); odd block counts add one K=128 launch (k_sweep_update<false,false>)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
