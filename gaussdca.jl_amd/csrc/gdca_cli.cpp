@@ -114,11 +114,10 @@ bool load_family(const Options &o, Family &f)
     return true;
 }
 
-// hot path + ranking + printrank for one parsed family on one context
-bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string &out_path, gdca_stats *st,
-             std::string *err)
+// the hot path for one parsed family on one context: S (N x N) comes back
+bool compute(gdca_ctx *ctx, const Options &o, const Family &f, std::vector<double> &S, gdca_stats *st, std::string *err)
 {
-    std::vector<double> S((size_t)f.N * f.N);
+    S.resize((size_t)f.N * f.N);
     gdca_params p{o.pseudocount, o.theta, o.score, 1};
     const gdca_status rc = gdca_run(ctx, f.Z.data(), f.N, f.M, f.q, &p, S.data(), st);
     if (rc == GDCA_ENOTPD) {
@@ -130,10 +129,16 @@ bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string
         *err = std::string("gdca_run failed: ") + gdca_last_error(ctx);
         return false;
     }
-    const int64_t len = gdca_ranking_length(f.N, o.min_separation);
+    return true;
+}
+
+// compute_ranking + printrank (src/GaussDCA.jl:88-99, :67-74): host work, off the GPU worker's thread in batch mode
+bool emit(const Options &o, const std::vector<double> &S, int32_t N, const std::string &out_path, std::string *err)
+{
+    const int64_t len = gdca_ranking_length(N, o.min_separation);
     std::vector<int32_t> ri((size_t)len), rj((size_t)len);
     std::vector<double> rs((size_t)len);
-    if (gdca_ranking(S.data(), f.N, o.min_separation, ri.data(), rj.data(), rs.data()) != GDCA_OK) {
+    if (gdca_ranking(S.data(), N, o.min_separation, ri.data(), rj.data(), rs.data()) != GDCA_OK) {
         *err = "ranking failed";
         return false;
     }
@@ -144,6 +149,13 @@ bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string
         return false;
     }
     return true;
+}
+
+bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string &out_path, gdca_stats *st,
+             std::string *err)
+{
+    std::vector<double> S;
+    return compute(ctx, o, f, S, st, err) && emit(o, S, f.N, out_path, err);
 }
 
 bool has_suffix(const std::string &s, const char *suf)
@@ -229,6 +241,33 @@ int run_batch(const Options &o)
             cv_ready.notify_all();
         }
     };
+    // rankings are sorted and written by their own threads: the GPU worker goes straight to the next family
+    struct Result {
+        std::string name;
+        int32_t N;
+        std::vector<double> S;
+    };
+    std::mutex omu;
+    std::condition_variable cv_out;
+    std::deque<Result> outq;
+    bool workers_done = false;
+    auto writer = [&]() {
+        for (;;) {
+            Result r;
+            {
+                std::unique_lock<std::mutex> lk(omu);
+                cv_out.wait(lk, [&] { return !outq.empty() || workers_done; });
+                if (outq.empty()) return;
+                r = std::move(outq.front());
+                outq.pop_front();
+            }
+            std::string err;
+            if (!emit(o, r.S, r.N, o.out_dir + "/" + r.name + ".rank.txt", &err)) {
+                fprintf(stderr, "ERROR: %s: %s\n", r.name.c_str(), err.c_str());
+                ++failures;
+            }
+        }
+    };
     const double t0 = now();
     std::vector<double> busy((size_t)G, 0.0);
     std::vector<int> count((size_t)G, 0);
@@ -257,7 +296,8 @@ int run_batch(const Options &o)
             gdca_stats st{};
             std::string err;
             const double t = now();
-            const bool ok = process(ctx, o, f, o.out_dir + "/" + f.name + ".rank.txt", &st, &err);
+            Result res;
+            const bool ok = compute(ctx, o, f, res.S, &st, &err);
             const double dt = now() - t;
             busy[(size_t)g] += dt;
             count[(size_t)g] += 1;
@@ -268,13 +308,27 @@ int run_batch(const Options &o)
             }
             fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", g,
                     f.name.c_str(), f.N, f.M, f.q, st.theta, st.Meff, f.parse_s, st.ms_total, dt);
+            res.name = f.name;
+            res.N = f.N;
+            {
+                std::lock_guard<std::mutex> lk(omu);
+                outq.push_back(std::move(res));
+            }
+            cv_out.notify_one();
         }
         gdca_ctx_destroy(ctx);
     };
-    std::vector<std::thread> threads;
+    std::vector<std::thread> threads, writers;
     for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
     for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
+    for (int w = 0; w < std::max(2, 2 * G); ++w) writers.emplace_back(writer);
     for (auto &t : threads) t.join();
+    {
+        std::lock_guard<std::mutex> lk(omu);
+        workers_done = true;
+    }
+    cv_out.notify_all();
+    for (auto &t : writers) t.join();
     const double wall = now() - t0;
     fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
             (double)jobs.size() / wall, failures.load());
