@@ -440,9 +440,10 @@ __global__ __launch_bounds__(256) void k_panel_writeback(double *__restrict__ A,
 // Update: lower-triangle tiles  A_IJ += G_I H_J^T (+ G2_I H2_J^T when G2 != nullptr),  H = -G P, in one of two tile
 // sets; blocks in the contiguous range [skip_lo, skip_lo + skip_n) never take part:
 //   colblk <  0 : every tile (I >= J) over the remaining blocks
-//   colblk >= 0 : the nslice = nblk - skip_n tiles that involve block `colblk` as row or column -- a look-ahead
-//                 slice; workgroups past those do the write-back of the pivot column block wb_col from wbH
-//                 (see panel_writeback_tile) when wb_col >= 0.
+//   SLICE       : the tiles that involve block `colblk` as row or column (nslice1 = nblk - skip_n of them) and,
+//                 when colblk2 >= 0, those that involve colblk2 = skip_lo + skip_n + 1 (nslice - nslice1 more) --
+//                 look-ahead slices; workgroups past nslice do the write-back of the pivot column block wb_col
+//                 from wbH (see panel_writeback_tile) when wb_col >= 0.
 // SLICE is a template parameter so that the big trailing-update launches are their own kernel symbol
 // (k_sweep_update<DUAL, false>): profiler summaries then report them apart from the small look-ahead launches.
 template <bool DUAL, bool SLICE>
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
                                                           const double *__restrict__ Hbuf,
                                                           const double *__restrict__ G2buf,
                                                           const double *__restrict__ H2buf, size_t pld, int wb_col,
-                                                          const double *__restrict__ wbH)
+                                                          const double *__restrict__ wbH, int colblk2, int nslice1)
 {
     __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
@@ -466,10 +467,14 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
         }
     }
     if constexpr (SLICE) {
-        int b = t;
-        if (b >= skip_lo) b += skip_n;
-        I = b > colblk ? b : colblk;
-        J = b > colblk ? colblk : b;
+        // tiles [0, nslice1) involve block colblk; tiles [nslice1, nslice) involve block colblk2, whose skip range
+        // is one longer (it also leaves out colblk = skip_lo + skip_n: that tile belongs to the first set)
+        const bool second = t >= nslice1;
+        int b = second ? t - nslice1 : t;
+        if (b >= skip_lo) b += skip_n + (second ? 1 : 0);
+        const int cb = second ? colblk2 : colblk;
+        I = b > cb ? b : cb;
+        J = b > cb ? cb : b;
     } else {
         int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((long long)ii * (ii + 1) / 2 > t) --ii;
@@ -546,10 +551,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
         if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
         if (G2)
             hipLaunchKernelGGL((k_sweep_update<true, false>), dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G, H,
-                               G2, H2, ld, -1, (const double *)nullptr);
+                               G2, H2, ld, -1, (const double *)nullptr, -1, 0);
         else
             hipLaunchKernelGGL((k_sweep_update<false, false>), dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G,
-                               H, G2, H2, ld, -1, (const double *)nullptr);
+                               H, G2, H2, ld, -1, (const double *)nullptr, -1, 0);
         if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
         ++nl;
         fl += tile_flops * (double)ntile * (G2 ? 2.0 : 1.0);
@@ -557,15 +562,16 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     // slice: the tiles that involve block col (other index outside the skip range), plus, when wb_col >= 0, the
     // write-back of pivot column wb_col from wbH
     auto slice = [&](hipStream_t st, int col, int skip_lo, int skip_n, const double *G, const double *H, const double *G2,
-                     const double *H2, int wb_col, const double *wbH) {
-        const int ns = nblk - skip_n;
+                     const double *H2, int wb_col, const double *wbH, int col2 = -1) {
+        const int ns1 = nblk - skip_n;
+        const int ns = ns1 + (col2 >= 0 ? nblk - skip_n - 1 : 0);
         const dim3 grid(ns + (wb_col >= 0 ? nblk - 1 : 0));
         if (G2)
             hipLaunchKernelGGL((k_sweep_update<true, true>), grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2,
-                               H2, ld, wb_col, wbH);
+                               H2, ld, wb_col, wbH, col2, ns1);
         else
             hipLaunchKernelGGL((k_sweep_update<false, true>), grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2,
-                               H2, ld, wb_col, wbH);
+                               H2, ld, wb_col, wbH, col2, ns1);
     };
     auto pivot = [&](int k) {
         hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, k * T, ws.P, sc, n_real);
@@ -610,8 +616,8 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
                 (void)hipEventRecord(Eb[p], s1);
                 if (!has3) break;
                 if (p >= 1) (void)hipStreamWaitEvent(s0, Eb[p - 1], 0);  // columns k3, k4 carry update p-1
-                slice(s0, k3, k1, 2, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr);
-                if (has4) slice(s0, k4, k1, 3, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr);
+                // one launch for the tiles of pair p's update that involve block k3 and (if any) block k4
+                slice(s0, k3, k1, 2, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr, has4 ? k4 : -1);
                 pivot(k3);
                 panel(k3, PG(p + 1, 0), PH(p + 1, 0));
                 if (has4) {
