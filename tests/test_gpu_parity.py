@@ -310,3 +310,47 @@ def test_large_spd_inverse_residual(g, ctx):
     R = A @ (X @ V) - V
     assert np.max(np.abs(R)) <= 1e-9 * np.max(np.abs(V))
     assert np.array_equal(X, X.T)
+
+
+_SCHEDULE_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import gaussdca.jl_amd as g
+ctx = g.Context(0)
+rng = np.random.default_rng(7)
+out = {}
+for n in (128, 300, 640, 768, 896, 1100, 1536, 1700):      # 1 .. 14 pivot blocks, even and odd counts
+    B = rng.standard_normal((n, 40))
+    A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
+    X = g.inv_cholesky(A, ctx=ctx)
+    Xr = np.linalg.inv(A)
+    out[str(n)] = [float(np.max(np.abs(X - Xr)) / np.max(np.abs(Xr))), bool(np.array_equal(X, X.T))]
+A[5, 5] = -1.0                                            # not positive definite: leading minor 6
+try:
+    g.inv_cholesky(A, ctx=ctx)
+    out["info"] = 0
+except g.PosDefException as e:
+    out["info"] = e.info
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [{"GDCA_PAIRS": "1"}, {"GDCA_PAIRS": "0"}, {"GDCA_NO_LOOKAHEAD": "1"},
+                                 {"GDCA_PAIRS": "1", "GDCA_RESERVE_CU": "0"}])
+def test_every_inverse_schedule_matches_lapack(env):
+    """The SPD inverse has three schedules (serial, single-pivot look-ahead, pivot pairs) chosen by size; each one,
+    forced through its environment switch in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks
+    (even and odd block counts, the pair schedule's odd tail included) and the same `info` on a non-PD matrix."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _SCHEDULE_SCRIPT, root], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out.pop("info") == 6
+    for n, (rel, sym) in out.items():
+        assert rel <= 1e-10 and sym, (env, n, rel, sym)    # cond ~ 1e2: far inside the 1e-6 bar for scores
