@@ -36,7 +36,16 @@ __global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, 
     const int kend = min(M, kbeg + seq_per_block);
     if (i < N) {
         const int8_t *p = Z + (size_t)kbeg * N + i;
-        for (int k = kbeg; k < kend; ++k) {
+        int k = kbeg;
+        for (; k + 16 <= kend; k += 16) {  // 16 strided byte loads in flight before the dependent LDS adds
+            int z[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) z[u] = p[(size_t)u * N] & 31;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h[z[u]][t] += Wfix[k + u];
+            p += (size_t)16 * N;
+        }
+        for (; k < kend; ++k) {
             h[p[0] & 31][t] += Wfix[k];
             p += N;
         }
@@ -51,7 +60,7 @@ __global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, 
 void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const u64 *Wfix, u64 *Pifix, int N, int M)
 {
     const int cb = (N + 127) / 128;
-    int chunks = (1024 + cb - 1) / cb;
+    int chunks = (512 + cb - 1) / cb;  // every chunk ends in one global atomic per counter
     int spb = (M + chunks - 1) / chunks;
     if (spb < 64) spb = 64;
     chunks = (M + spb - 1) / spb;

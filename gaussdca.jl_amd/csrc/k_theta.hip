@@ -50,13 +50,15 @@ __global__ __launch_bounds__(256) void k_column_hist(const int8_t *__restrict__ 
     if (i < N) {
         const int8_t *p = Z + (size_t)kbeg * N + i;
         int k = kbeg;
-        for (; k + 4 <= kend; k += 4) {
-            const int z0 = p[0] & 31, z1 = p[(size_t)N] & 31, z2 = p[(size_t)2 * N] & 31, z3 = p[(size_t)3 * N] & 31;
-            h[z0][t] += 1;
-            h[z1][t] += 1;
-            h[z2][t] += 1;
-            h[z3][t] += 1;
-            p += (size_t)4 * N;
+        // 16 strided byte loads in flight per thread before the dependent LDS increments: the loop is bound by
+        // memory latency, not by bandwidth (25 MB in total)
+        for (; k + 16 <= kend; k += 16) {
+            int z[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) z[u] = p[(size_t)u * N] & 31;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h[z[u]][t] += 1;
+            p += (size_t)16 * N;
         }
         for (; k < kend; ++k) {
             h[p[0] & 31][t] += 1;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void k_column_hist(const int8_t *__restrict__ 
 void gdca_launch_column_hist(hipStream_t s, const int8_t *Z, uint32_t *cnt, int N, int M)
 {
     const int cb = (N + 255) / 256;
-    int chunks = (1024 + cb - 1) / cb;  // ~1024 workgroups: 4 per CU
+    int chunks = (256 + cb - 1) / cb;  // ~256 workgroups: every chunk ends in one global atomic per counter
     int spb = (M + chunks - 1) / chunks;
     if (spb < 64) spb = 64;
     chunks = (M + spb - 1) / spb;
