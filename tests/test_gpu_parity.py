@@ -298,10 +298,11 @@ def test_headline_config_properties(g, ctx):
     assert len(R) == (N - 5) * (N - 4) // 2 and all(R[t][2] >= R[t + 1][2] for t in range(len(R) - 1))
 
 
-def test_large_spd_inverse_residual(g, ctx):
-    """n = 6000 (47 pivot blocks, look-ahead schedule): A X v == v on random probes."""
+@pytest.mark.parametrize("n", [6000, 9100])
+def test_large_spd_inverse_residual(g, ctx, n):
+    """n = 6000 (47 pivot blocks: single-pivot look-ahead) and n = 9100 (72 blocks: pivot pairs, K = 256 trailing
+    updates): A X v == v on random probes."""
     rng = np.random.default_rng(4)
-    n = 6000
     B = rng.standard_normal((n, 64))
     d = 0.5 + rng.random(n)
     A = (B @ B.T) / 64 + np.diag(d)
