@@ -224,13 +224,13 @@ __device__ __forceinline__ void stage_store(const StageRegs<TM> &R, double (*Gs)
     }
 }
 
-template <int TM>
+template <int TM, int K4_BEGIN = 0, int K4_END = KC>
 __device__ __forceinline__ void chunk_mma(double4_t (&acc)[TM][4], double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int wr,
                                           int wc, int lane)
 {
     const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int k4 = 0; k4 < KC; k4 += 4) {
+    for (int k4 = K4_BEGIN; k4 < K4_END; k4 += 4) {
         double a[TM], b[4];
 #pragma unroll
         for (int t = 0; t < TM; ++t) a[t] = Hs[k4 + lq][wc * (16 * TM) + t * 16 + l15];
@@ -311,29 +311,34 @@ __device__ __forceinline__ void cpiece_add(double4_t (&acc)[4][4], const double 
 
 // DUAL: two pivots fused in one pass -- the k loop runs over (G, H) of the first pivot (these unrolled chunks,
 // which also bring in the C tile) and then over (G2, H2) of the second (a plain rolled loop in the kernel), K = 256:
-// the C tile is read and written once per TWO rank-128 updates.  The last chunk here prefetches the first chunk of
-// the second pair.
+// the C tile is read and written once per TWO rank-128 updates.
+// The operand chunks are double-buffered in LDS (chunk c in buffer c & 1): while chunk c is multiplied, chunk c+1
+// goes registers -> LDS (after the first quarter of the MFMAs, so its global loads have had more than a chunk to
+// land) and chunk c+2's global loads are issued; ONE barrier per chunk.
+typedef double (*lds_chunk_t)[LDS_LD];
+
 template <int CI, bool DUAL>
 struct UpdateChunks {
     static constexpr int PER = T / KC;  // chunks per operand pair
     static __device__ __forceinline__ void run(double4_t (&acc)[4][4], StageRegs<4> &R, double (&cp)[8],
                                                const double *__restrict__ g1, const double *__restrict__ h1,
                                                const double *__restrict__ g2, const double *__restrict__ h2, size_t pld,
-                                               double (*Gs)[LDS_LD], double (*Hs)[LDS_LD],
+                                               double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD],
                                                const double *__restrict__ At, size_t ld)
     {
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-        __syncthreads();  // previous chunk's LDS reads are done
-        stage_store<false, 4>(R, Gs, Hs, tid);
-        __syncthreads();
+        // on entry: LDS buffer CI & 1 holds chunk CI (barrier passed); R holds (or is receiving) chunk CI + 1
         if constexpr (CI > 0) cpiece_add<(CI > 0 ? CI - 1 : 0)>(acc, cp);  // requested one chunk ago
         cpiece_load<CI>(cp, At, ld, wr, wc, l15, lq);
-        if constexpr (CI + 1 < PER)
-            stage_load<false, 4>(R, g1, pld, h1, pld, (CI + 1) * KC, tid);
+        chunk_mma<4, 0, 4>(acc, Gs[CI & 1], Hs[CI & 1], wr, wc, lane);
+        if constexpr (CI + 1 < PER || DUAL) stage_store<false, 4>(R, Gs[(CI + 1) & 1], Hs[(CI + 1) & 1], tid);
+        if constexpr (CI + 2 < PER)
+            stage_load<false, 4>(R, g1, pld, h1, pld, (CI + 2) * KC, tid);
         else if constexpr (DUAL)
-            stage_load<false, 4>(R, g2, pld, h2, pld, 0, tid);
-        chunk_mma<4>(acc, Gs, Hs, wr, wc, lane);
+            stage_load<false, 4>(R, g2, pld, h2, pld, (CI + 2 - PER) * KC, tid);
+        chunk_mma<4, 4, KC>(acc, Gs[CI & 1], Hs[CI & 1], wr, wc, lane);
+        __syncthreads();  // buffer CI & 1 is free, buffer (CI + 1) & 1 is complete
         if constexpr (CI + 1 < PER)
             UpdateChunks<CI + 1, DUAL>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
         else
@@ -454,15 +459,15 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
                                                           const double *__restrict__ H2buf, size_t pld, int wb_col,
                                                           const double *__restrict__ wbH, int colblk2, int nslice1)
 {
-    __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
     const int t = blockIdx.x;
     int I, J;
     if constexpr (SLICE) {
         if (t >= nslice) {
             int b = t - nslice;
             if (b >= wb_col) ++b;
-            panel_writeback_tile(A, ld, wb_col, b, wbH, pld, Gs);
+            panel_writeback_tile(A, ld, wb_col, b, wbH, pld, Gs[0]);
             return;
         }
     }
@@ -499,15 +504,21 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
         double cp[8];
         const double *g1 = Gbuf + (size_t)I * T, *h1 = Hbuf + (size_t)J * T;
         stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
+        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
+        __syncthreads();
         if constexpr (DUAL) {
             const double *g2 = G2buf + (size_t)I * T, *h2 = H2buf + (size_t)J * T;
             UpdateChunks<0, true>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
-            for (int kc = 0; kc < T; kc += KC) {  // second pivot of the pair: chunk 0 is already in R
+            // second pivot of the pair: chunk c of it is chunk 8 + c of the pass (buffer c & 1); on entry chunk 0 is
+            // in LDS buffer 0 and chunk 1 in R
+#pragma unroll 1
+            for (int c = 0; c < T / KC; ++c) {
+                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                if (c + 1 < T / KC) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+                if (c + 2 < T / KC) stage_load<false, 4>(R, g2, pld, h2, pld, (c + 2) * KC, tid);
+                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
                 __syncthreads();
-                stage_store<false, 4>(R, Gs, Hs, tid);
-                __syncthreads();
-                if (kc + KC < T) stage_load<false, 4>(R, g2, pld, h2, pld, kc + KC, tid);
-                chunk_mma<4>(acc, Gs, Hs, wr, wc, lane);
             }
         } else {
             UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
