@@ -10,7 +10,7 @@ from .dcautils import (add_pseudocount, compute_C, compute_DI_gauss, compute_FN,
                        compute_theta, compute_weighted_frequencies, compute_weights, correct_APC,
                        inv_cholesky, neighbour_counts, pair_identity_sum, printrank,
                        read_fasta_alignment, read_fasta_alignment_py, remove_duplicate_sequences,
-                       remove_duplicate_sequences_py, compute_ranking_py)
+                       remove_duplicate_sequences_py, compute_ranking_py, Ranking)
 from .gdca import check_arguments, gDCA  # noqa: F401
 
 __all__ = ["gDCA", "printrank"]

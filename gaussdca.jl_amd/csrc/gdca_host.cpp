@@ -285,21 +285,51 @@ gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int
     const int64_t len = gdca_ranking_length(N, min_separation);
     if (len == 0) return GDCA_OK;
     if (!i_out || !j_out || !score_out) return GDCA_EINVAL;
-    struct Ent {
-        int32_t i, j;
-        double s;
-    };
-    std::vector<Ent> R;
-    R.reserve((size_t)len);
+    // sort!(R, by = x -> x[3], rev = true): a stable sort by `isless` on the score, reversed.  Done as a stable LSD
+    // radix sort on a 64-bit key that orders doubles the way isless does (-0.0 < 0.0, every NaN greatest), bits
+    // flipped for the descending direction; equal scores keep their generation order (i ascending, then j).
+    const size_t n = (size_t)len;
+    std::vector<uint64_t> key(n), key2(n);
+    std::vector<uint32_t> idx(n), idx2(n);
+    std::vector<int32_t> gi(n), gj(n);
+    size_t t = 0;
     for (int32_t i = 1; i <= N - min_separation; ++i)
-        for (int32_t j = i + min_separation; j <= N; ++j)
-            R.push_back({i, j, S[(size_t)(j - 1) + (size_t)(i - 1) * N]});  // S[j, i], column-major
-    // sort!(R, by = x -> x[3], rev = true): stable, so exact ties keep generation order
-    std::stable_sort(R.begin(), R.end(), [](const Ent &a, const Ent &b) { return a.s > b.s; });
-    for (int64_t t = 0; t < len; ++t) {
-        i_out[t] = R[(size_t)t].i;
-        j_out[t] = R[(size_t)t].j;
-        score_out[t] = R[(size_t)t].s;
+        for (int32_t j = i + min_separation; j <= N; ++j, ++t) {
+            const double x = S[(size_t)(j - 1) + (size_t)(i - 1) * N];  // S[j, i], column-major
+            uint64_t u;
+            memcpy(&u, &x, 8);
+            uint64_t asc = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+            if (x != x) asc = ~0ull;
+            key[t] = ~asc;
+            idx[t] = (uint32_t)t;
+            gi[t] = i;
+            gj[t] = j;
+        }
+    constexpr int RB = 16, NB = 1 << RB;
+    std::vector<uint32_t> hist((size_t)4 * NB, 0);
+    for (size_t e = 0; e < n; ++e)
+        for (int pass = 0; pass < 4; ++pass) hist[(size_t)pass * NB + ((key[e] >> (RB * pass)) & (NB - 1))]++;
+    for (int pass = 0; pass < 4; ++pass) {
+        uint32_t *h = hist.data() + (size_t)pass * NB;
+        uint32_t run = 0;
+        for (int bkt = 0; bkt < NB; ++bkt) {
+            const uint32_t c = h[bkt];
+            h[bkt] = run;
+            run += c;
+        }
+        for (size_t e = 0; e < n; ++e) {
+            const uint32_t pos = h[(key[e] >> (RB * pass)) & (NB - 1)]++;
+            key2[pos] = key[e];
+            idx2[pos] = idx[e];
+        }
+        key.swap(key2);
+        idx.swap(idx2);
+    }
+    for (size_t e = 0; e < n; ++e) {
+        const uint32_t g = idx[e];
+        i_out[e] = gi[g];
+        j_out[e] = gj[g];
+        score_out[e] = S[(size_t)(gj[g] - 1) + (size_t)(gi[g] - 1) * N];
     }
     return GDCA_OK;
 }

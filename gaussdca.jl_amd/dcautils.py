@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import gzip
 import math
+from collections.abc import Sequence as _SequenceABC
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -130,21 +131,55 @@ def remove_duplicate_sequences(Z) -> Tuple[np.ndarray, np.ndarray]:
     return np.asfortranarray(out[:, :m.value]), idx[:m.value].astype(np.int64)
 
 
-def compute_ranking(S, min_separation: int = 5) -> List[Tuple[int, int, float]]:
-    """compute_ranking(S, min_separation)  (src/GaussDCA.jl:88-99): 1-based (i, j, S[j, i]), stable sort."""
+class Ranking(_SequenceABC):
+    """The ranking as a sequence of (i, j, score) tuples (what the reference returns as a
+    Vector{Tuple{Int,Int,Float64}}), backed by the three arrays the native sort filled: building
+    122 760 Python tuples costs more than the sort, so they are made on access.  `.i`, `.j`, `.score`
+    are the arrays; slicing gives a list of tuples; comparing with a list compares element-wise."""
+
+    __slots__ = ("i", "j", "score")
+
+    def __init__(self, i, j, score):
+        self.i, self.j, self.score = i, j, score
+
+    def __len__(self):
+        return int(self.i.shape[0])
+
+    def __getitem__(self, t):
+        if isinstance(t, slice):
+            return list(zip(self.i[t].tolist(), self.j[t].tolist(), self.score[t].tolist()))
+        return (int(self.i[t]), int(self.j[t]), float(self.score[t]))
+
+    def __iter__(self):
+        return iter(zip(self.i.tolist(), self.j.tolist(), self.score.tolist()))
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(a == tuple(b) for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        head = ", ".join(repr(x) for x in self[:3])
+        return f"Ranking(len={len(self)}: [{head}{', ...' if len(self) > 3 else ''}])"
+
+
+def compute_ranking(S, min_separation: int = 5) -> "Ranking":
+    """compute_ranking(S, min_separation)  (src/GaussDCA.jl:88-99): 1-based (i, j, S[j, i]), stable sort by
+    `isless` on the score, reversed (NaN first, 0.0 before -0.0, exact ties in generation order)."""
     lib = _lib.load()
     Sf = np.asfortranarray(S, dtype=np.float64)
     N = Sf.shape[0]
     n = int(lib.gdca_ranking_length(N, int(min_separation)))
     if n <= 0:
-        return []
+        return Ranking(np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.float64))
     ii = np.empty(n, dtype=np.int32)
     jj = np.empty(n, dtype=np.int32)
     sc = np.empty(n, dtype=np.float64)
     st = lib.gdca_ranking(_lib._p(Sf), N, int(min_separation), _lib._p(ii), _lib._p(jj), _lib._p(sc))
     if st != 0:
         raise ArgumentError("compute_ranking: invalid arguments")
-    return list(zip(ii.tolist(), jj.tolist(), sc.tolist()))
+    return Ranking(ii, jj, sc)
 
 
 # ---- hot operators (libgdca.so) -----------------------------------------------------------------------
@@ -309,7 +344,10 @@ def compute_ranking_py(S, min_separation: int = 5) -> List[Tuple[int, int, float
     ii = np.concatenate(ii)
     jj = np.concatenate(jj)
     sc = S[jj, ii]
-    order = np.argsort(-sc, kind="stable")
+    # Julia's isless, reversed: NaN first, then descending, 0.0 before -0.0; stable
+    nan = np.isnan(sc)
+    negzero = (sc == 0) & np.signbit(sc)
+    order = np.lexsort((negzero, np.where(nan, 0.0, -sc), ~nan))  # last key is the primary one; lexsort is stable
     return [(int(ii[t]) + 1, int(jj[t]) + 1, float(sc[t])) for t in order]
 
 
@@ -323,9 +361,13 @@ def printrank(io, R: Sequence[Tuple[int, int, float]] = None):
         io, R = sys.stdout, io
     if isinstance(io, (str, bytes)):
         lib = _lib.load()
-        ii = np.asarray([r[0] for r in R], dtype=np.int32)
-        jj = np.asarray([r[1] for r in R], dtype=np.int32)
-        sc = np.asarray([r[2] for r in R], dtype=np.float64)
+        if isinstance(R, Ranking):
+            ii, jj, sc = (np.ascontiguousarray(R.i, dtype=np.int32), np.ascontiguousarray(R.j, dtype=np.int32),
+                          np.ascontiguousarray(R.score, dtype=np.float64))
+        else:
+            ii = np.asarray([r[0] for r in R], dtype=np.int32)
+            jj = np.asarray([r[1] for r in R], dtype=np.int32)
+            sc = np.asarray([r[2] for r in R], dtype=np.float64)
         path = io if isinstance(io, bytes) else io.encode()
         if lib.gdca_write_rank(path, _lib._p(ii), _lib._p(jj), _lib._p(sc), len(R)) != 0:
             raise OSError(f"cannot write {io}")

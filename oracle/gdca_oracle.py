@@ -398,7 +398,8 @@ def compute_ranking(S: np.ndarray, min_separation: int = 5) -> List[Tuple[int, i
     for i in range(N - min_separation):
         for j in range(i + min_separation, N):
             R.append((i + 1, j + 1, float(S[j, i])))
-    R.sort(key=lambda t: -t[2])  # Python's sort is stable, like Julia's default for `by`
+    # sort!(R, by = x -> x[3], rev = true): stable, ordered by isless reversed -- NaN first, 0.0 before -0.0
+    R.sort(key=lambda t: (0, 0.0, 0) if t[2] != t[2] else (1, -t[2], 1 if (t[2] == 0 and math.copysign(1.0, t[2]) < 0) else 0))
     return R
 
 

@@ -138,3 +138,38 @@ def test_host_fasta_dedup_ranking_match_oracle(refdata, tmp_path):
     out = tmp_path / "rank.txt"
     g.printrank(str(out), R)  # native writer: same bytes as the Python "%i %i %e"
     assert out.read_text() == buf.getvalue()
+
+
+def test_ranking_order_is_julias_isless_reversed():
+    """sort!(R, by = x -> x[3], rev = true) (src/GaussDCA.jl:96): stable, NaN first, 0.0 before -0.0, exact ties in
+    generation order -- native radix sort, the numpy statement and the oracle agree, and the lazy Ranking behaves
+    like the list of tuples the reference returns."""
+    import gaussdca.jl_amd as g
+    from oracle import gdca_oracle as o
+
+    rng = np.random.default_rng(3)
+    N = 60
+    S = rng.standard_normal((N, N))
+    S = S + S.T
+    for (a, b, v) in [(3, 40, np.nan), (7, 50, -0.0), (8, 55, 0.0), (9, 30, np.inf), (10, 44, -np.inf), (11, 45, np.nan)]:
+        S[a, b] = S[b, a] = v
+    S[20:25, 40:48] = 0.5
+    S[40:48, 20:25] = 0.5
+    R = g.compute_ranking(S, 5)
+    Rp = g.compute_ranking_py(S, 5)
+    Ro = o.compute_ranking(S, 5)
+    same = lambda x, y: x == y or (x != x and y != y)  # noqa: E731
+    assert len(R) == len(Rp) == len(Ro) == (N - 5) * (N - 4) // 2
+    for a, b, c in zip(R, Rp, Ro):
+        assert a[:2] == b[:2] == c[:2] and same(a[2], b[2]) and same(a[2], c[2])
+    assert np.isnan(R[0][2]) and np.isnan(R[1][2]) and R[2][2] == np.inf and R[len(R) - 1][2] == -np.inf
+    zeros = [t for t in range(len(R)) if R[t][2] == 0]
+    assert [np.signbit(R[t][2]) for t in zeros] == [False, True]
+    ties = [R[t][:2] for t in range(len(R)) if R[t][2] == 0.5]
+    assert ties == sorted(ties) and len(ties) == 40
+    # list-like behaviour
+    assert isinstance(R[2:5], list) and R[2:5] == [R[2], R[3], R[4]] == Rp[2:5]      # (NaN != NaN: skip the first two)
+    assert R[5] == tuple(R[5]) and len(list(iter(R))) == len(R)
+    Rf = g.compute_ranking(np.where(np.isnan(S), 1.0, S), 5)
+    assert Rf == list(Rf) and list(Rf) == g.compute_ranking_py(np.where(np.isnan(S), 1.0, S), 5)
+    assert g.compute_ranking(S, N) == [] and len(g.compute_ranking(S, N - 1)) == 1
