@@ -6,7 +6,7 @@
 // No collective, no shared device state.  Host code only; every number comes from libgdca.so.
 //
 //   gdca_cli [options] alignment.fasta[.gz] [ranking.txt]
-//   gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P]
+//   gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K]
 //   gdca_cli --synth N M SEED out.fasta[.gz]
 // options (names and defaults of src/GaussDCA.jl:10-15):
 //   --pseudocount X (0.8)  --theta auto|X (auto)  --max_gap_fraction X (0.9)  --score frob|DI (frob)
@@ -36,7 +36,7 @@ struct Options {
     int score = GDCA_SCORE_FROB, min_separation = 5;
     bool remove_dups = false;
     std::string batch_dir, out_dir;
-    int gpus = 0, parsers = 4;
+    int gpus = 0, parsers = 4, inflight = 2;
     std::vector<std::string> positional;
 };
 
@@ -216,7 +216,7 @@ int run_batch(const Options &o)
     std::condition_variable cv_ready, cv_space;
     std::deque<Family> ready;
     size_t next_job = 0, parsed_done = 0;
-    const size_t cap = (size_t)std::max(2 * G, 4);
+    const size_t cap = (size_t)std::max(2 * G * std::max(1, o.inflight), 4);
     std::atomic<int> failures{0};
 
     auto parser = [&]() {
@@ -299,8 +299,11 @@ int run_batch(const Options &o)
             Result res;
             const bool ok = compute(ctx, o, f, res.S, &st, &err);
             const double dt = now() - t;
-            busy[(size_t)g] += dt;
-            count[(size_t)g] += 1;
+            {
+                std::lock_guard<std::mutex> lk(omu);  // several workers per GPU share the counters
+                busy[(size_t)g] += dt;
+                count[(size_t)g] += 1;
+            }
             if (!ok) {
                 fprintf(stderr, "ERROR: %s: %s\n", f.name.c_str(), err.c_str());
                 ++failures;
@@ -320,7 +323,10 @@ int run_batch(const Options &o)
     };
     std::vector<std::thread> threads, writers;
     for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
-    for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
+    // --inflight contexts per GPU: while one family's latency-bound pivot chain runs, another family's kernels fill
+    // the idle CUs (independent gdca_ctx objects on the same device, no ordering between them)
+    for (int k = 0; k < std::max(1, o.inflight); ++k)
+        for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
     for (int w = 0; w < std::max(2, 2 * G); ++w) writers.emplace_back(writer);
     for (auto &t : threads) t.join();
     {
@@ -364,6 +370,7 @@ int main(int argc, char **argv)
         else if (s == "--out") o.out_dir = val();
         else if (s == "--gpus") o.gpus = atoi(val());
         else if (s == "--parsers") o.parsers = atoi(val());
+        else if (s == "--inflight") o.inflight = atoi(val());
         else if (s == "--synth") {
             if (a + 4 >= argc) die("usage: --synth N M SEED out.fasta[.gz]");
             const int N = atoi(argv[a + 1]), M = atoi(argv[a + 2]);
@@ -375,7 +382,7 @@ int main(int argc, char **argv)
         } else if (s == "-h" || s == "--help") {
             printf("usage: gdca_cli [--pseudocount X] [--theta auto|X] [--max_gap_fraction X] [--score frob|DI]\n"
                    "                [--min_separation K] [--remove_dups] alignment.fasta[.gz] [ranking.txt]\n"
-                   "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P]\n"
+                   "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K]\n"
                    "       gdca_cli --synth N M SEED out.fasta[.gz]\n");
             return 0;
         } else if (!s.empty() && s[0] == '-' && s.size() > 1) die("unknown option " + s);
