@@ -173,3 +173,49 @@ def test_ranking_order_is_julias_isless_reversed():
     Rf = g.compute_ranking(np.where(np.isnan(S), 1.0, S), 5)
     assert Rf == list(Rf) and list(Rf) == g.compute_ranking_py(np.where(np.isnan(S), 1.0, S), 5)
     assert g.compute_ranking(S, N) == [] and len(g.compute_ranking(S, N - 1)) == 1
+
+
+def test_threaded_fasta_reader_on_a_large_file(tmp_path):
+    """Files over 1 MB take the multi-threaded path of gdca_fasta_open (header scan per chunk, records in parallel,
+    order-preserving compaction): wrapped lines, CRLF, blank lines, an insert column, filtered (gap-rich) records and
+    a misaligned record in the middle, against the pure-Python statement of the same rules and the oracle."""
+    import gaussdca.jl_amd as g
+    from gaussdca.jl_amd import synth
+    from oracle import gdca_oracle as o
+
+    N, M = 150, 9000
+    Z = synth.synth_family(N, M, 21, 77)
+    letters = np.frombuffer(b"?ACDEFGHIKLMNPQRSTVWY-", dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    gappy = set(rng.choice(M, size=300, replace=False).tolist())
+    lines = []
+    for k in range(M):
+        row = Z[k].copy()
+        if k in gappy:
+            row[: int(0.95 * N)] = 21                       # 95 % gaps: dropped at max_gap_fraction 0.9
+        seq = letters[row].tobytes()
+        seq = seq[:70] + (b"a" if k % 2 else b".") + seq[70:]   # an insert column after position 70
+        eol = b"\r\n" if k % 3 == 0 else b"\n"
+        lines.append(b">seq%d some description" % k + eol)
+        for a in range(0, len(seq), 60):                    # wrapped at 60 characters
+            lines.append(seq[a:a + 60] + eol)
+        if k % 7 == 0:
+            lines.append(eol)
+    path = tmp_path / "big.fasta"
+    path.write_bytes(b"".join(lines))
+    assert path.stat().st_size > (1 << 20)
+    Zn = g.read_fasta_alignment(str(path), 0.9)
+    keep = np.array([k not in gappy for k in range(M)])
+    assert Zn.shape == (N, int(keep.sum()))
+    Zexp = Z.copy()
+    for k in gappy:
+        Zexp[k, : int(0.95 * N)] = 21
+    assert np.array_equal(Zn.T, Zexp[keep])
+    assert np.array_equal(Zn.T, o.read_fasta_alignment(str(path), 0.9))
+    assert np.array_equal(g.read_fasta_alignment(str(path), 1.0).T, Zexp)
+    # a record of the wrong length deep inside the file: "inputs are not aligned"
+    bad = tmp_path / "bad.fasta"
+    cut = len(lines) // 2
+    bad.write_bytes(b"".join(lines[:cut]) + b">short\nACDEF\n" + b"".join(lines[cut:]))
+    with pytest.raises(ValueError):
+        g.read_fasta_alignment(str(bad), 0.9)
