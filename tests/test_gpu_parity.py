@@ -355,3 +355,21 @@ def test_every_inverse_schedule_matches_lapack(env):
     assert out.pop("info") == 6
     for n, (rel, sym) in out.items():
         assert rel <= 1e-10 and sym, (env, n, rel, sym)    # cond ~ 1e2: far inside the 1e-6 bar for scores
+
+
+@pytest.mark.parametrize("N,M,score,pc", [(430, 4000, "frob", 0.8), (260, 5000, "DI", 0.2)])
+def test_mid_size_families_match_oracle(g, ctx, o, N, M, score, pc):
+    """Whole hot path against the oracle at sizes where the production schedules are active: N = 430 (n = 8600,
+    68 pivot blocks: pivot pairs, K = 256 trailing updates) and N = 260 (41 blocks: single-pivot look-ahead).
+    Integers bit-exact, scores within 1e-6 relative (north_star)."""
+    from gaussdca.jl_amd import synth
+
+    Zo = synth.synth_family(N, M, 21, 0xE100 + N)
+    S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 1 if score == "DI" else 0)
+    W_o, Meff_o, th_o, thr_o = o.compute_weights(Zo, "auto")
+    assert st["theta"] == th_o and st["thresh"] == thr_o and st["Meff"] == Meff_o and st["info"] == 0
+    S_o = o.scores_from_Z(Zo, 21, pc, "auto", score)
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)
+    assert ok, (max_rel, max_abs)
+    R, R_o = g.compute_ranking(S, 5), o.compute_ranking(S_o, 5)
+    assert [t[:2] for t in R[:200]] == [t[:2] for t in R_o[:200]]       # the contacts a user looks at: same order
