@@ -4,6 +4,7 @@
 // Printed next to the achieved TFLOP/s and the TFLOP/s the same issue rate would give at 2.4 GHz.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -111,7 +112,15 @@ int main()
     CK(hipMalloc(&in, sizeof(double) * 4096));
     CK(hipMalloc(&clk, sizeof(unsigned long long) * 2048));
     double h[4096];
-    for (int i = 0; i < 4096; ++i) h[i] = 1e-3 * ((i * 2654435761u) % 1000) - 0.5;
+    // GDCA_UBENCH_RANDOM=1: full-entropy mantissas (a 64-bit LCG) instead of 1000 distinct three-digit values: the
+    // f64 matrix pipe draws more power on them
+    const bool rnd = getenv("GDCA_UBENCH_RANDOM") != nullptr;
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 4096; ++i) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        h[i] = rnd ? ((double)(st >> 11) / 9007199254740992.0 - 0.5) : (1e-3 * ((i * 2654435761u) % 1000) - 0.5);
+    }
+    printf("operands: %s\n", rnd ? "random mantissas" : "three-digit values");
     CK(hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
