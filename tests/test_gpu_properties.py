@@ -49,5 +49,10 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
         # the GPU path must be non-finite in the same places
         assert np.array_equal(np.isfinite(S), np.isfinite(S_o))
         return
+    if np.max(np.abs(S_o)) < 1e-10:
+        # no signal at all (e.g. two all-gap sequences): the exact scores are 0 and both sides hold rounding noise of the
+        # O(1) inverse-covariance entries they were computed from
+        assert np.max(np.abs(S)) < 1e-10
+        return
     ok, max_rel, _ = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)
     assert ok, max_rel
