@@ -255,8 +255,8 @@ def main():
                           "ms_score")},
             "theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"],
             "roofline": {
-                "kernel": "k_sweep_update<true,false>: trailing update of the SPD inverse, f64 MFMA 128x128 tiles, two pivots "
-                          "per launch (K=256); odd block counts add one K=128 launch (k_sweep_update<false,false>)",
+                "kernel": "k_group_update<false,true>: trailing update of the SPD inverse, f64 MFMA 128x128 tiles, three "
+                          "pivots per launch at this size (K=384; a shorter last group adds one smaller launch)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,

@@ -366,13 +366,14 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     gdca_inverse_ws ws;
     ws.G[0] = ws.G[1] = (double *)ctx->G.p;
     ws.H[0] = ws.H[1] = (double *)ctx->H.p;
-    ws.G[2] = ws.G[3] = ws.H[2] = ws.H[3] = nullptr;
+    for (int w = 2; w < 8; ++w) ws.G[w] = ws.H[w] = nullptr;
     ws.P = (double *)ctx->P.p;
     if (la) {
-        // four G and four H panels (pivot pairs, double-buffered by pair parity) carved from two buffers
-        CHK(ensure(ctx, ctx->G2, 3 * pbytes));
-        CHK(ensure(ctx, ctx->H2, 3 * pbytes));
-        for (int w = 1; w < 4; ++w) {
+        // eight G and eight H panels carved from two buffers
+        const int npan = 8;  // 2 x 4 panels: pivot groups of up to four, double-buffered by group parity (pairs use 2 x 2)
+        CHK(ensure(ctx, ctx->G2, (size_t)(npan - 1) * pbytes));
+        CHK(ensure(ctx, ctx->H2, (size_t)(npan - 1) * pbytes));
+        for (int w = 1; w < npan; ++w) {
             ws.G[w] = (double *)((char *)ctx->G2.p + (size_t)(w - 1) * pbytes);
             ws.H[w] = (double *)((char *)ctx->H2.p + (size_t)(w - 1) * pbytes);
         }

@@ -76,10 +76,10 @@ void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int
 
 // ---- k_inverse.hip -------------------------------------------------------------------------
 struct gdca_inverse_ws {
-    double *G[4];  // n_pad x 128 panels (column k of the swept matrix): [0], [1] double-buffered by step parity for
-                   // the single-pivot look-ahead; [2 (p & 1) + {0, 1}] = the two panels of pivot pair p (G[2] may be
-                   // nullptr: no pair schedule)
-    double *H[4];  // n_pad x 128 panels, -G * P
+    double *G[8];  // n_pad x 128 panels (column k of the swept matrix): [0], [1] double-buffered by step parity for
+                   // the single-pivot look-ahead; [2 (p & 1) + {0, 1}] = the two panels of pivot pair p; [4 (p & 1) + w] =
+                   // panel w of pivot group p (G[2] / G[4] may be nullptr: no pair / group schedule)
+    double *H[8];  // n_pad x 128 panels, -G * P
     double *P;     // 128 x 128 inverse of the pivot block
 };
 // In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles

@@ -19,6 +19,8 @@
 // load/store instruction moves 4 columns x 128 contiguous bytes.  Operands go through LDS as
 // [k][row] with a 128-byte pad per k-row, which puts the four k-rows a ds_read_b64 touches on
 // disjoint bank halves (conflict-free).
+#include <algorithm>
+
 #include "gdca_internal.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -536,6 +538,104 @@ __global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A,
             }
 }
 
+// ---- groups of up to four pivots per trailing update ----------------------------------------------------------------
+// Generalisation of the pair kernel above for large matrices: one launch applies the rank-128 updates of nop <= 4
+// pivots (K = 128 nop) -- the C tile is read and written once per nop updates and a workgroup's launch / first-chunk /
+// store-drain overhead is paid once per nop times the work.  Big mode: every tile outside [skip_lo, skip_lo + skip_n).
+// Slice mode: the tiles that involve one of up to four column blocks col[m], the other index running over all blocks
+// outside that column's own contiguous skip range [cskip_lo[m], cskip_lo[m] + cskip_n[m]) (first[m] .. first[m+1]-1
+// are column m's tiles); workgroups from first[ncol] on write pivot column wb_col back from wbH.
+struct GroupUpd {
+    const double *G[4];
+    const double *H[4];
+    int nop;
+    int skip_lo, skip_n;
+    int ncol;
+    int col[4], first[5], cskip_lo[4], cskip_n[4];
+    int wb_col;
+    const double *wbH;
+};
+
+template <bool SLICE, bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A, size_t ld, size_t pld, const GroupUpd P)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
+    const int t = blockIdx.x;
+    int I, J;
+    if constexpr (SLICE) {
+        if (t >= P.first[P.ncol]) {
+            int b = t - P.first[P.ncol];
+            if (b >= P.wb_col) ++b;
+            panel_writeback_tile(A, ld, P.wb_col, b, P.wbH, pld, Gs[0]);
+            return;
+        }
+        int m = 0;
+        while (m + 1 < P.ncol && t >= P.first[m + 1]) ++m;
+        int b = t - P.first[m];
+        if (b >= P.cskip_lo[m]) b += P.cskip_n[m];
+        const int cb = P.col[m];
+        I = b > cb ? b : cb;
+        J = b > cb ? cb : b;
+    } else {
+        int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)ii * (ii + 1) / 2 > t) --ii;
+        while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
+        int jj = t - (int)((long long)ii * (ii + 1) / 2);
+        if (ii >= P.skip_lo) ii += P.skip_n;
+        if (jj >= P.skip_lo) jj += P.skip_n;
+        I = ii;
+        J = jj;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    double *At = A + (size_t)I * T + (size_t)J * T * ld;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        StageRegs<4> R;
+        double cp[8];
+        const size_t go = (size_t)I * T, ho = (size_t)J * T;
+        const double *g1 = P.G[0] + go, *h1 = P.H[0] + ho;
+        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
+        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
+        __syncthreads();
+        if constexpr (MULTI) {
+            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, P.G[1] + go, P.H[1] + ho, pld, Gs, Hs, At, ld);
+            // pivots 2 .. nop of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
+            // chunk 0 is in LDS buffer 0 and chunk 1 in R
+            const int total = (T / KC) * (P.nop - 1);
+#pragma unroll 1
+            for (int c = 0; c < total; ++c) {
+                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+                if (c + 2 < total) {
+                    const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
+                    stage_load<false, 4>(R, P.G[op] + go, pld, P.H[op] + ho, pld, kc, tid);
+                }
+                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                __syncthreads();
+            }
+        } else {
+            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = wr * 64 + tn * 16 + l15;
+                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
+            }
+}
+
 // Host driver of the block sweep.  With a side stream (s1 != nullptr) it runs with look-ahead, by default in
 // PAIRS of pivots: the big trailing update of pivots (2p, 2p+1) is ONE launch with K = 256 on the side stream
 // (half the C-tile traffic per flop of two K = 128 launches -- the trailing update is HBM-bound otherwise), while
@@ -594,6 +694,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     // below that the longer chain per pivot costs more than the halved C-tile traffic saves); GDCA_PAIRS=0/1 forces
     static const int pairs_env = getenv("GDCA_PAIRS") ? atoi(getenv("GDCA_PAIRS")) : -1;
     const bool pairs_on = pairs_env < 0 ? nblk >= 66 : pairs_env != 0;
+    // groups of 3-4 pivots per trailing update (k_group_update) once the matrix is large enough for the longer chain of
+    // a group to stay hidden (measured: 3 from 66 blocks, 4 from 100); GDCA_GROUP=g forces (0..2: pairs / single pivots)
+    static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
+    const int group_g = group_env >= 0 ? std::min(group_env, 4) : (nblk >= 100 ? 4 : (nblk >= 66 ? 3 : 0));
 
     pivot(0);
     if (nblk > 1) {
@@ -605,6 +709,113 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
                 hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.H[0], ld);
                 timed_update(s0, k, 1, ws.G[0], ws.H[0], nullptr, nullptr);
             }
+        } else if (group_g >= 3 && nblk >= 2 * group_g && ws.G[4]) {
+            // ---- groups of group_g pivots (large matrices) ----
+            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
+            const int g = group_g, ng = (nblk + g - 1) / g;
+            auto base = [&](int p) { return p * g; };
+            auto size = [&](int p) { return std::min(g, nblk - p * g); };
+            auto GG = [&](int p, int w) { return ws.G[4 * (p & 1) + w]; };
+            auto HH = [&](int p, int w) { return ws.H[4 * (p & 1) + w]; };
+            auto launch_group = [&](hipStream_t st, bool slice_mode, unsigned grid, const GroupUpd &P) {
+                if (slice_mode) {
+                    if (P.nop > 1)
+                        hipLaunchKernelGGL((k_group_update<true, true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+                    else
+                        hipLaunchKernelGGL((k_group_update<true, false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+                } else {
+                    if (P.nop > 1)
+                        hipLaunchKernelGGL((k_group_update<false, true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+                    else
+                        hipLaunchKernelGGL((k_group_update<false, false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+                }
+            };
+            auto set_ops = [&](GroupUpd &P, int p, int first_op, int nop) {
+                for (int w = 0; w < 4; ++w) {
+                    P.G[w] = GG(p, std::min(first_op + w, 3));
+                    P.H[w] = HH(p, std::min(first_op + w, 3));
+                }
+                P.nop = nop;
+            };
+            // the chain of group p: pivots one after the other, each applied at once to the other columns of the group
+            auto chain = [&](int p) {
+                const int b0 = base(p), sz = size(p);
+                for (int i = 0; i < sz; ++i) {
+                    const int k = b0 + i;
+                    if (k > 0) pivot(k);  // pivot 0 was launched above, before the schedules branch
+                    panel(k, GG(p, i), HH(p, i));
+                    GroupUpd P{};
+                    set_ops(P, p, i, 1);
+                    P.wb_col = k;
+                    P.wbH = HH(p, i);
+                    int m = 0, first = 0;
+                    for (int c = k + 1; c < b0 + sz; ++c, ++m) {  // later columns of the group: skip [k, c)
+                        P.col[m] = c;
+                        P.cskip_lo[m] = k;
+                        P.cskip_n[m] = c - k;
+                        P.first[m] = first;
+                        first += nblk - P.cskip_n[m];
+                    }
+                    for (int c = k - 1; c >= b0; --c, ++m) {  // earlier columns: skip (c, b0 + sz)
+                        P.col[m] = c;
+                        P.cskip_lo[m] = c + 1;
+                        P.cskip_n[m] = b0 + sz - (c + 1);
+                        P.first[m] = first;
+                        first += nblk - P.cskip_n[m];
+                    }
+                    P.ncol = m;
+                    P.first[m] = first;
+                    launch_group(s0, true, (unsigned)(first + nblk - 1), P);
+                }
+            };
+            chain(0);
+            (void)hipEventRecord(Ep[0], s0);
+            for (int p = 0; p < ng; ++p) {
+                const int b0 = base(p), sz = size(p);
+                const bool has_next = p + 1 < ng;
+                const int nsz = has_next ? size(p + 1) : 0;
+                // side stream: the group's update of everything outside its own and the next group's blocks
+                (void)hipStreamWaitEvent(s1, Ep[p], 0);
+                {
+                    GroupUpd P{};
+                    set_ops(P, p, 0, sz);
+                    P.skip_lo = b0;
+                    P.skip_n = sz + nsz;
+                    const int m = nblk - P.skip_n;
+                    if (m > 0) {
+                        const unsigned ntile = (unsigned)((long long)m * (m + 1) / 2);
+                        const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
+                        if (tm) (void)hipEventRecord(upd_ev[2 * nl], s1);
+                        launch_group(s1, false, ntile, P);
+                        if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], s1);
+                        ++nl;
+                        fl += tile_flops * (double)ntile * (double)sz;
+                    }
+                }
+                (void)hipEventRecord(Eb[p], s1);
+                if (!has_next) break;
+                if (p >= 1) (void)hipStreamWaitEvent(s0, Eb[p - 1], 0);  // the next group's columns carry update p-1
+                {
+                    // the tiles of group p's update that involve the next group's blocks, one launch
+                    GroupUpd P{};
+                    set_ops(P, p, 0, sz);
+                    P.wb_col = -1;
+                    int first = 0;
+                    for (int m = 0; m < nsz; ++m) {
+                        P.col[m] = b0 + sz + m;
+                        P.cskip_lo[m] = b0;
+                        P.cskip_n[m] = sz + m;
+                        P.first[m] = first;
+                        first += nblk - P.cskip_n[m];
+                    }
+                    P.ncol = nsz;
+                    P.first[nsz] = first;
+                    launch_group(s0, true, (unsigned)first, P);
+                }
+                chain(p + 1);
+                (void)hipEventRecord(Ep[p + 1], s0);
+            }
+            (void)hipStreamWaitEvent(s0, Eb[ng - 1], 0);
         } else if (pairs_on && nblk >= 6 && ws.G[2]) {
             hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
             // panels of pair p: G[2 (p & 1) + {0, 1}]

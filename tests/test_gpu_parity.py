@@ -300,8 +300,8 @@ def test_headline_config_properties(g, ctx):
 
 @pytest.mark.parametrize("n", [6000, 9100])
 def test_large_spd_inverse_residual(g, ctx, n):
-    """n = 6000 (47 pivot blocks: single-pivot look-ahead) and n = 9100 (72 blocks: pivot pairs, K = 256 trailing
-    updates): A X v == v on random probes."""
+    """n = 6000 (47 pivot blocks: single-pivot look-ahead) and n = 9100 (72 blocks: groups of three pivots, K = 384
+    trailing updates): A X v == v on random probes."""
     rng = np.random.default_rng(4)
     B = rng.standard_normal((n, 64))
     d = 0.5 + rng.random(n)
@@ -338,11 +338,12 @@ print(json.dumps(out))
 
 
 @pytest.mark.parametrize("env", [{"GDCA_PAIRS": "1"}, {"GDCA_PAIRS": "0"}, {"GDCA_NO_LOOKAHEAD": "1"},
-                                 {"GDCA_PAIRS": "1", "GDCA_RESERVE_CU": "0"}])
+                                 {"GDCA_PAIRS": "1", "GDCA_RESERVE_CU": "0"}, {"GDCA_GROUP": "3"}, {"GDCA_GROUP": "4"}])
 def test_every_inverse_schedule_matches_lapack(env):
-    """The SPD inverse has three schedules (serial, single-pivot look-ahead, pivot pairs) chosen by size; each one,
-    forced through its environment switch in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks
-    (even and odd block counts, the pair schedule's odd tail included) and the same `info` on a non-PD matrix."""
+    """The SPD inverse has four schedules (serial, single-pivot look-ahead, pivot pairs, groups of 3-4 pivots) chosen
+    by size; each one, forced through its environment switch in a fresh process, must give the LAPACK inverse on
+    1..14 pivot blocks (even and odd block counts, short last groups included) and the same `info` on a non-PD
+    matrix."""
     import json
     import subprocess
     import sys
@@ -360,7 +361,7 @@ def test_every_inverse_schedule_matches_lapack(env):
 @pytest.mark.parametrize("N,M,score,pc", [(430, 4000, "frob", 0.8), (260, 5000, "DI", 0.2)])
 def test_mid_size_families_match_oracle(g, ctx, o, N, M, score, pc):
     """Whole hot path against the oracle at sizes where the production schedules are active: N = 430 (n = 8600,
-    68 pivot blocks: pivot pairs, K = 256 trailing updates) and N = 260 (41 blocks: single-pivot look-ahead).
+    68 pivot blocks: groups of three pivots, K = 384 trailing updates) and N = 260 (41 blocks: single-pivot look-ahead).
     Integers bit-exact, scores within 1e-6 relative (north_star)."""
     from gaussdca.jl_amd import synth
 
