@@ -695,9 +695,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     static const int pairs_env = getenv("GDCA_PAIRS") ? atoi(getenv("GDCA_PAIRS")) : -1;
     const bool pairs_on = pairs_env < 0 ? nblk >= 66 : pairs_env != 0;
     // groups of 3-4 pivots per trailing update (k_group_update) once the matrix is large enough for the longer chain of
-    // a group to stay hidden (measured: 3 from 66 blocks, 4 from 100); GDCA_GROUP=g forces (0..2: pairs / single pivots)
+    // a group to stay hidden (measured: 3 from 66 blocks, 4 from 90); GDCA_GROUP=g forces (0..2: pairs / single pivots)
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    const int group_g = group_env >= 0 ? std::min(group_env, 4) : (nblk >= 100 ? 4 : (nblk >= 66 ? 3 : 0));
+    const int group_g = group_env >= 0 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 66 ? 3 : 0));
 
     pivot(0);
     if (nblk > 1) {
