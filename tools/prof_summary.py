@@ -5,7 +5,7 @@
 
 `pmc`: per kernel and counter, launches / mean / sum (counters as reported; FETCH_SIZE and WRITE_SIZE are in KB).
 `traffic`: HBM bytes per launch of the dominant kernel (the big trailing-update launches of the SPD inverse:
-k_sweep_update with a grid of more than 1000 workgroups) from two separate passes, one counter each, as
+k_group_update / k_sweep_update with a grid of more than 1000 workgroups) from two separate passes, one counter each, as
 MI355X_MICROARCH.md prescribes; no x2 correction on FETCH_SIZE (8-byte-per-lane tile loads).
 """
 import argparse
@@ -56,11 +56,11 @@ def cmd_traffic(args):
                 continue
             k = short(r["Kernel_Name"])
             allk[k] += float(r["Counter_Value"])
-            if k.startswith("k_sweep_update") and int(r["Grid_Size"]) > 1000 * int(r["Workgroup_Size"]):
+            if k.startswith(("k_sweep_update", "k_group_update")) and int(r["Grid_Size"]) > 1000 * int(r["Workgroup_Size"]):
                 vals.append((float(r["Counter_Value"]), k))
         res[cname] = vals
         per_kernel[cname + "_all_kernels_sum_kb"] = dict(allk)
-    out = {"kernel": "k_sweep_update (big trailing-update launches only: grid > 1000 workgroups)",
+    out = {"kernel": "trailing update of the SPD inverse (k_group_update / k_sweep_update launches with more than 1000 workgroups)",
            "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
                       "--steps 1 --warmup 1 --no-cpu-baseline (two separate passes)"}
     n = min(len(res["FETCH_SIZE"]), len(res["WRITE_SIZE"]))
