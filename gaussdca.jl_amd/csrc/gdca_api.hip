@@ -807,7 +807,7 @@ gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops)
     if (!ctx || !tflops || iters < 1) return GDCA_EINVAL;
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
-    const int blocks = 256 * 4;  // 4 waves per SIMD
+    const int blocks = 256 * 2;  // 2 waves per SIMD, all resident at once
     CHK(ensure(ctx, ctx->scratch[6], (size_t)blocks * 256 * sizeof(double)));
     CHK(need_events(ctx, 2));
     gdca_launch_probe_mfma_f64(s, (double *)ctx->scratch[6].p, 16, blocks);  // warm-up
@@ -818,7 +818,7 @@ gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops)
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    const double flops = (double)blocks * 4.0 * (double)((iters + 1) / 2) * 16.0 * 2.0 * 16 * 16 * 4;  // 16 MFMAs per trip
     *tflops = flops / ((double)ms * 1e-3) / 1e12;
     return GDCA_OK;
 }

@@ -890,19 +890,30 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
 // -------------------------------------------------------------------------------------------------
 // f64 MFMA issue-rate probe (register-resident, 8 independent accumulators per wave).
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_probe_mfma_f64(double *out, int iters)
+__global__ __launch_bounds__(256, 2) void k_probe_mfma_f64(double *out, int iters)
 {
-    double4_t acc[8];
+    // 16 independent accumulators per wave (4 A x 4 B fragments, as in the tile kernels): with 8 the loop is bound by
+    // the accumulator dependency, not by the matrix pipe (46-49 instead of 76-77 TFLOP/s chip-wide)
+    double4_t acc[4][4];
+    double a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
-    for (int it = 0; it < iters; ++it) {
+    for (int i = 0; i < 4; ++i) {
+        a[i] = 1.0 + 1e-9 * (threadIdx.x + 64 * i);
+        b[i] = 1.0 - 1e-9 * (threadIdx.x + 64 * i);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int it = 0; it < iters; it += 2) {  // 16 MFMAs per trip = two of the former 8-MFMA iterations
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     double sacc = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sacc += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = sacc;
 }
 

@@ -181,7 +181,7 @@ gdca_status gdca_synth_family(int32_t N, int32_t M, int32_t q, uint64_t seed, in
  * ends in ".gz".  So a reference installation can be fed the same family gdca_synth_family produced. */
 gdca_status gdca_write_fasta(const char *path, const int8_t *Z, int32_t N, int32_t M);
 /* Dense f64 MFMA issue-rate probe: returns achieved TFLOP/s of a register-resident
- * v_mfma_f64_16x16x4_f64 loop on every CU. */
+ * v_mfma_f64_16x16x4_f64 loop (16 independent accumulators per wave) on every CU: 76-77 on MI355X. */
 gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops);
 
 #ifdef __cplusplus

@@ -34,6 +34,34 @@ __global__ __launch_bounds__(256, 2) void k_load(double *out, unsigned long long
     }
 }
 
+// The same loop with 8 accumulators and a 4-waves-per-SIMD register budget, to see what 3 and 4 MFMA-issuing waves per
+// SIMD do to the matrix pipe (the trailing update shares its SIMDs with the waves of the look-ahead chain).
+__global__ __launch_bounds__(256, 4) void k_load_occ(double *out, unsigned long long *clk, const double *in, int iters)
+{
+    double4_t acc[2][4];
+    double a[2], b[4];
+    for (int i = 0; i < 4; ++i) b[i] = in[2048 + threadIdx.x + 64 * i];
+    for (int i = 0; i < 2; ++i) {
+        a[i] = in[threadIdx.x + 64 * i];
+        for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0, 0, 0, 0};
+    }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = c1 - c0;
+        clk[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
 // Same MFMA stream, operands re-read from LDS every k4 step exactly as the trailing-update kernel does (8 ds_read_b64,
 // wait, 16 MFMAs), optional barrier every 4 steps (one 16-deep chunk); still no global traffic.
 template <bool BARRIER>
@@ -147,6 +175,18 @@ int main()
             printf("workgroups=%4d (%d per CU on %3d CUs): %.2f ms  %.1f TFLOP/s  shader clock %.2f GHz  -> %.1f clk per MFMA per SIMD\n",
                    nb, wgs, cus, ms, tf, ghz, ghz * 1e9 * (ms * 1e-3) / ((double)iters * 16 * wgs));
         }
+    for (int wgs = 1; wgs <= 4; ++wgs) {
+        const int nb = 256 * wgs, iters = 40000;
+        hipLaunchKernelGGL(k_load_occ, dim3(nb), dim3(256), 0, 0, out, clk, in, 1000);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_load_occ, dim3(nb), dim3(256), 0, 0, out, clk, in, iters);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("8 accumulators per wave, %d wave(s) per SIMD: %.1f TFLOP/s\n", wgs, (double)nb * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12);
+    }
     run_variant("LDS-fed k4 steps, no barrier", k_load_lds<false>, out, clk, in);
     run_variant("LDS-fed k4 steps, barrier per chunk", k_load_lds<true>, out, clk, in);
     return 0;
