@@ -5,12 +5,12 @@ DCAUtils-named operators are in :mod:`dcautils`.  All hot-path arithmetic runs i
 library ``libgdca.so`` (C-ABI: include/gdca.h); importing this package never falls back to a
 CPU implementation -- calling any operator without the built library or without a GPU raises.
 """
-from ._lib import (ArgumentError, Context, GdcaError, PosDefException, default_context, load)  # noqa: F401
+from ._lib import (ArgumentError, Context, ConvergenceError, DeviceBuffer, GdcaError, PosDefException,  # noqa: F401
+                   default_context, load)
 from .dcautils import (add_pseudocount, compute_C, compute_DI_gauss, compute_FN, compute_ranking,  # noqa: F401
                        compute_theta, compute_weighted_frequencies, compute_weights, correct_APC,
                        inv_cholesky, neighbour_counts, pair_identity_sum, printrank,
-                       read_fasta_alignment, read_fasta_alignment_py, remove_duplicate_sequences,
-                       remove_duplicate_sequences_py, compute_ranking_py, Ranking)
+                       read_fasta_alignment, remove_duplicate_sequences, Ranking)
 from .gdca import check_arguments, gDCA  # noqa: F401
 
 __all__ = ["gDCA", "printrank"]

@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgdca.so")
 
-GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM = 0, 1, 2, 3, 4
+GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV = 0, 1, 2, 3, 4, 5
 SCORE_FROB, SCORE_DI = 0, 1
 
 
@@ -28,6 +28,15 @@ class PosDefException(ArithmeticError):
     def __init__(self, info: int):
         super().__init__(f"matrix is not positive definite; Cholesky factorization failed (info={info})")
         self.info = int(info)
+
+
+class ConvergenceError(ArithmeticError):
+    """Mirror of the LAPACKException an eigenvalue routine raises inside DCAUtils.compute_DI_gauss
+    (src/GaussDCA.jl:37) when its iteration does not converge."""
+
+    def __init__(self, npairs: int):
+        super().__init__(f"eigenvalue iteration did not converge for {npairs} site pair(s)")
+        self.npairs = int(npairs)
 
 
 class Params(C.Structure):
@@ -68,6 +77,26 @@ SYMBOLS = {
                                C.POINTER(Stats)]),
     "gdca_run_dev_async": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p]),
     "gdca_run_collect": (C.c_int, [_ctx, C.POINTER(Stats)]),
+    "gdca_dbuf_alloc": (C.c_int, [_ctx, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "gdca_dbuf_free": (C.c_int, [C.c_void_p]),
+    "gdca_dbuf_ptr": (C.c_void_p, [C.c_void_p]),
+    "gdca_dbuf_bytes": (C.c_uint64, [C.c_void_p]),
+    "gdca_dbuf_upload": (C.c_int, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "gdca_dbuf_download": (C.c_int, [_ctx, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "gdca_pair_identity_sum_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _u64p]),
+    "gdca_compute_theta_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "gdca_neighbour_counts_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_compute_weights_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, _f64p,
+                                           _f64p, _i32p]),
+    "gdca_frequencies_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                       C.c_void_p, C.c_void_p]),
+    "gdca_add_pseudocount_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p,
+                                           C.c_void_p]),
+    "gdca_covariance_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "gdca_spd_inverse_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _i32p]),
+    "gdca_fn_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_di_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gdca_apc_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
     "gdca_pair_identity_sum": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _u64p]),
     "gdca_compute_theta": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, _f64p]),
     "gdca_neighbour_counts": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -164,6 +193,8 @@ class Context:
             raise PosDefException(info)
         if st == GDCA_ENOMEM:
             raise MemoryError(msg)
+        if st == GDCA_ENOCONV:
+            raise ConvergenceError(-info if info < 0 else 0)
         raise GdcaError(f"HIP error: {msg}")
 
     def synchronize(self):
@@ -206,6 +237,47 @@ class Context:
         rc = self.lib.gdca_run_collect(self.h, C.byref(st))
         self.check(rc, st.info)
         return st.as_dict()
+
+
+class DeviceBuffer:
+    """An owned HBM allocation (gdca_dbuf): what a host language without a GPU array type keeps the
+    intermediates of the statement-by-statement pipeline in.  `.ptr` is the device pointer the `_dev`
+    operators take."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.gdca_dbuf_alloc(ctx.h, int(nbytes), C.byref(h)))
+        self.h = h
+        self.nbytes = int(ctx.lib.gdca_dbuf_bytes(h))
+        self.ptr = int(ctx.lib.gdca_dbuf_ptr(h) or 0)
+
+    @classmethod
+    def from_array(cls, ctx: Context, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a) if not (a.flags.c_contiguous or a.flags.f_contiguous) else a
+        b = cls(ctx, a.nbytes)
+        b.upload(a)
+        return b
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        assert a.flags.c_contiguous or a.flags.f_contiguous
+        self.ctx.check(self.ctx.lib.gdca_dbuf_upload(self.ctx.h, self.h, int(offset), _p(a), a.nbytes))
+
+    def download(self, shape, dtype=np.float64, order="F", offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype, order=order)
+        self.ctx.check(self.ctx.lib.gdca_dbuf_download(self.ctx.h, self.h, int(offset), _p(out), out.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.gdca_dbuf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 _default_ctx = None

@@ -149,17 +149,20 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
             }
         }
     }
+    // from here on every failure goes through gdca_ctx_destroy, which frees whatever has been created so far
     if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
-        free(ctx);
+        ctx->side = nullptr;
+        gdca_ctx_destroy(ctx);
         return GDCA_EHIP;
     }
     if (hipEventCreateWithFlags(&ctx->ev_weights, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess) {
-        free(ctx);
+        gdca_ctx_destroy(ctx);
         return GDCA_EHIP;
     }
     if (hipHostMalloc((void **)&ctx->sc_host, sizeof(gdca_dev_scalars), hipHostMallocDefault) != hipSuccess) {
-        free(ctx);
+        ctx->sc_host = nullptr;
+        gdca_ctx_destroy(ctx);
         return GDCA_ENOMEM;
     }
     *out = ctx;
@@ -207,7 +210,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
 {
     if (!ctx) return GDCA_EINVAL;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->G2, &ctx->H2, &ctx->P, &ctx->Dblk, &ctx->Ld,
                         &ctx->Tws, &ctx->colsum, &ctx->sc};
@@ -286,7 +289,7 @@ static int round_up(int x, int m)
 }
 
 // stage 1+2: theta, threshold, neighbour counts, W, Wfix, Meff  (all on device)
-static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, double theta_in, int fixed_thresh,
+static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, int q, double theta_in, int fixed_thresh,
                                  bool want_theta_only, hipEvent_t ev_after_theta)
 {
     hipStream_t s = ctx->stream;
@@ -312,7 +315,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t), s));
-    gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M);
+    gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M, q, sc);
     gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
@@ -341,7 +344,8 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
     gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
-    gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M);
+    gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M, q,
+                         (gdca_dev_scalars *)ctx->sc.p);
     if (ctx->meff_pending) {
         HIPCHK(hipStreamWaitEvent(s, ctx->ev_meff, 0));
         ctx->meff_pending = false;
@@ -397,7 +401,7 @@ static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int sc
     if (score == GDCA_SCORE_DI) {
         CHK(ensure(ctx, ctx->Tws, gdca_di_ws_bytes(N, sdim)));
         gdca_launch_di(s, (const double *)ctx->A.p, (size_t)n_pad, (const double *)ctx->Ld.p, N, sdim, S_dev,
-                       (double *)ctx->Tws.p);
+                       (double *)ctx->Tws.p, (gdca_dev_scalars *)ctx->sc.p);
     } else {
         gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev);
     }
@@ -484,7 +488,12 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
             st->ms_inverse_update = upd;
         }
     }
+    if (h.bad_symbol) return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
     if (h.info != 0) return fail(ctx, GDCA_ENOTPD, "covariance matrix is not positive definite%s%s", "", "");
+    if (h.di_noconv != 0) {
+        if (st) st->info = -h.di_noconv;
+        return fail(ctx, GDCA_ENOCONV, "eigenvalue iteration of a DI block did not converge%s%s", "", "");
+    }
     return GDCA_OK;
 }
 
@@ -498,7 +507,8 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     if (!(p->theta <= 1.0)) return fail(ctx, GDCA_EINVAL, "invalid theta value%s%s", "", "");
     if (p->score != GDCA_SCORE_FROB && p->score != GDCA_SCORE_DI)
         return fail(ctx, GDCA_EINVAL, "invalid score value%s%s", "", "");
-    if (ctx->pending) (void)gdca_run_collect(ctx, nullptr);  // an uncollected run: its scalars would be overwritten
+    if (ctx->pending)  // one run may be outstanding per ctx: its scalars and events would be overwritten
+        return fail(ctx, GDCA_EINVAL, "a run is still enqueued on this context: call gdca_run_collect first%s%s", "", "");
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
@@ -508,7 +518,7 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
 
     if (timed) HIPCHK(hipEventRecord(ev[0], s));
-    CHK(weights_stage(ctx, Z_dev, N, M, p->theta, -1, false, timed ? ev[1] : nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, q, p->theta, -1, false, timed ? ev[1] : nullptr));
     if (timed) HIPCHK(hipEventRecord(ev[2], s));
 
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
@@ -576,157 +586,184 @@ gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, 
     return GDCA_OK;
 }
 
-// ---- operator level ---------------------------------------------------------------------------------
+// ---- caller-visible device buffers ----------------------------------------------------------------------
+// A gdca_dbuf is nothing but an owned HBM allocation: the `_dev` operators below take plain device pointers
+// (gdca_dbuf_ptr of such a buffer, or any other device memory of the same GPU, e.g. a torch tensor's data_ptr).
 
-static gdca_status upload_Z(gdca_ctx *ctx, const int8_t *Z, int N, int M, const int8_t **Zd)
+struct gdca_dbuf {
+    void *p;
+    size_t bytes;
+    int device;
+};
+
+gdca_status gdca_dbuf_alloc(gdca_ctx *ctx, uint64_t bytes, gdca_dbuf **out)
 {
-    CHK(ensure(ctx, ctx->scratch[0], (size_t)N * M));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
-    *Zd = (const int8_t *)ctx->scratch[0].p;
+    if (!ctx || !out) return GDCA_EINVAL;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    gdca_dbuf *b = (gdca_dbuf *)calloc(1, sizeof(gdca_dbuf));
+    if (!b) return GDCA_ENOMEM;
+    const size_t want = bytes ? (size_t)bytes : 16;
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+        free(b);
+        (void)hipGetLastError();
+        return fail(ctx, GDCA_ENOMEM, "hipMalloc failed: %s%s", hipGetErrorString(e), "");
+    }
+    b->bytes = want;
+    b->device = ctx->device;
+    *out = b;
     return GDCA_OK;
 }
 
-gdca_status gdca_pair_identity_sum(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, uint64_t *out)
+gdca_status gdca_dbuf_free(gdca_dbuf *b)
+{
+    if (!b) return GDCA_OK;
+    (void)hipSetDevice(b->device);
+    if (b->p) (void)hipFree(b->p);
+    free(b);
+    return GDCA_OK;
+}
+
+void *gdca_dbuf_ptr(const gdca_dbuf *b)
+{
+    return b ? b->p : nullptr;
+}
+
+uint64_t gdca_dbuf_bytes(const gdca_dbuf *b)
+{
+    return b ? (uint64_t)b->bytes : 0;
+}
+
+gdca_status gdca_dbuf_upload(gdca_ctx *ctx, gdca_dbuf *b, uint64_t offset, const void *host, uint64_t bytes)
+{
+    if (!ctx || !b || (!host && bytes) || offset + bytes > b->bytes) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(hipMemcpyAsync((char *)b->p + offset, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the host buffer may be reused on return
+    return GDCA_OK;
+}
+
+gdca_status gdca_dbuf_download(gdca_ctx *ctx, const gdca_dbuf *b, uint64_t offset, void *host, uint64_t bytes)
+{
+    if (!ctx || !b || (!host && bytes) || offset + bytes > b->bytes) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(host, (const char *)b->p + offset, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+// ---- operator level, device-resident (`_dev`): every matrix argument is a device pointer ----------------------
+// Each call enqueues on the ctx stream and returns after the stream has drained only where a host scalar comes
+// back (weights: Meff/theta/thresh; spd_inverse: info; di: convergence; frequencies: the symbol-range check); the
+// elementwise ones (add_pseudocount, covariance, fn, apc) return right after the launch.
+
+static gdca_status symbols_ok(gdca_ctx *ctx)
+{
+    if (ctx->sc_host->bad_symbol)
+        return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
+    return GDCA_OK;
+}
+
+gdca_status gdca_pair_identity_sum_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, uint64_t *out)
 {
     CHK(validate(ctx, N, M, 2));
-    if (!Z || !out) return GDCA_EINVAL;
+    if (!Z_dev || !out) return GDCA_EINVAL;
     CHK(begin(ctx));
-    const int8_t *Zd;
-    CHK(upload_Z(ctx, Z, N, M, &Zd));
-    CHK(weights_stage(ctx, Zd, N, M, -1.0, -1, true, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, nullptr));
     CHK(fetch_scalars(ctx));
     *out = ctx->sc_host->pair_sum;
     return GDCA_OK;
 }
 
-gdca_status gdca_compute_theta(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double *theta)
+gdca_status gdca_compute_theta_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, double *theta)
 {
     CHK(validate(ctx, N, M, 2));
-    if (!Z || !theta) return GDCA_EINVAL;
+    if (!Z_dev || !theta) return GDCA_EINVAL;
     CHK(begin(ctx));
-    const int8_t *Zd;
-    CHK(upload_Z(ctx, Z, N, M, &Zd));
-    CHK(weights_stage(ctx, Zd, N, M, -1.0, -1, true, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, nullptr));
     CHK(fetch_scalars(ctx));
     *theta = ctx->sc_host->theta;
     return GDCA_OK;
 }
 
-gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t thresh,
-                                  int32_t *n_out)
+gdca_status gdca_neighbour_counts_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t thresh,
+                                      int32_t *n_dev)
 {
     CHK(validate(ctx, N, M, 2));
-    if (!Z || !n_out || thresh < 0) return GDCA_EINVAL;
+    if (!Z_dev || !n_dev || thresh < 0) return GDCA_EINVAL;
     CHK(begin(ctx));
-    const int8_t *Zd;
-    CHK(upload_Z(ctx, Z, N, M, &Zd));
-    CHK(weights_stage(ctx, Zd, N, M, 0.0, thresh, false, nullptr));
-    HIPCHK(hipMemcpyAsync(n_out, ctx->nk.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return GDCA_OK;
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, 0.0, thresh, false, nullptr));
+    HIPCHK(hipMemcpyAsync(n_dev, ctx->nk.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    CHK(fetch_scalars(ctx));
+    return symbols_ok(ctx);
 }
 
-gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta, double *W,
-                                 double *Meff, double *theta_used, int32_t *thresh)
+gdca_status gdca_compute_weights_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, double theta,
+                                     double *W_dev, double *Meff, double *theta_used, int32_t *thresh)
 {
     CHK(validate(ctx, N, M, 2));
-    if (!Z || !W || !Meff || !(theta <= 1.0)) return GDCA_EINVAL;
+    if (!Z_dev || !W_dev || !Meff || !(theta <= 1.0)) return GDCA_EINVAL;
     CHK(begin(ctx));
-    const int8_t *Zd;
-    CHK(upload_Z(ctx, Z, N, M, &Zd));
-    CHK(weights_stage(ctx, Zd, N, M, theta, -1, false, nullptr));
-    HIPCHK(hipMemcpyAsync(W, ctx->W.p, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, theta, -1, false, nullptr));
+    HIPCHK(hipMemcpyAsync(W_dev, ctx->W.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     CHK(fetch_scalars(ctx));
     *Meff = ctx->sc_host->Meff;
     if (theta_used) *theta_used = ctx->sc_host->theta;
     if (thresh) *thresh = ctx->sc_host->thresh;
-    return GDCA_OK;
+    return symbols_ok(ctx);
 }
 
-gdca_status gdca_frequencies(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const double *W,
-                             double Meff, double *Pi, double *Pij)
+gdca_status gdca_frequencies_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                                 const double *W_dev, double Meff, double *Pi_dev, double *Pij_dev)
 {
     CHK(validate(ctx, N, M, q));
-    if (!Z || !W || !Pi || !Pij || !(Meff > 0.0)) return GDCA_EINVAL;
+    if (!Z_dev || !W_dev || !Pi_dev || !Pij_dev || !(Meff > 0.0)) return GDCA_EINVAL;
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim;
-    const int8_t *Zd;
-    CHK(upload_Z(ctx, Z, N, M, &Zd));
-    CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
+    gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
-    CHK(ensure(ctx, ctx->scratch[1], (size_t)n * n * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[2], (size_t)n * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[3], sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->W.p, W, (size_t)M * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, &Meff, sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_fix_weights(s, (const double *)ctx->W.p, M, gdca_fix_shift(M), (unsigned long long *)ctx->Wfix.p);
-    CHK(tally_stage(ctx, Zd, N, M, q, (const double *)ctx->scratch[3].p, 0.0, 0, (double *)ctx->scratch[2].p,
-                    (double *)ctx->scratch[1].p, (size_t)n));
-    HIPCHK(hipMemcpyAsync(Pi, ctx->scratch[2].p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(Pij, ctx->scratch[1].p, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    // Meff travels through the device scalar block (the tally kernels read it from HBM)
+    HIPCHK(hipMemcpyAsync(&sc->Meff, &Meff, sizeof(double), hipMemcpyHostToDevice, s));
+    // W outside [0, 1] would overflow the 59-bit fixed-point weight field: flagged on the device
+    gdca_launch_fix_weights(s, W_dev, M, gdca_fix_shift(M), (unsigned long long *)ctx->Wfix.p, sc);
+    CHK(tally_stage(ctx, Z_dev, N, M, q, &sc->Meff, 0.0, 0, Pi_dev, Pij_dev, (size_t)n));
+    CHK(fetch_scalars(ctx));
+    if (ctx->sc_host->bad_symbol & 2) return fail(ctx, GDCA_EINVAL, "weights must lie in [0, 1]%s%s", "", "");
+    return symbols_ok(ctx);
 }
 
-gdca_status gdca_add_pseudocount(gdca_ctx *ctx, const double *Pi_true, const double *Pij_true, int32_t N, int32_t q,
-                                 double pc, double *Pi, double *Pij)
+gdca_status gdca_add_pseudocount_dev(gdca_ctx *ctx, const double *Pi_true_dev, const double *Pij_true_dev, int32_t N,
+                                     int32_t q, double pc, double *Pi_dev, double *Pij_dev)
 {
     CHK(validate(ctx, N, 1, q));
-    if (!Pi_true || !Pij_true || !Pi || !Pij || !(pc >= 0.0 && pc <= 1.0)) return GDCA_EINVAL;
-    CHK(begin(ctx));
-    hipStream_t s = ctx->stream;
-    const size_t n = (size_t)N * (q - 1);
-    CHK(ensure(ctx, ctx->scratch[1], n * n * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[2], n * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[4], n * n * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[5], n * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, Pij_true, n * n * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, Pi_true, n * sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_add_pseudocount(s, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, N, q, pc,
-                                (double *)ctx->scratch[5].p, (double *)ctx->scratch[4].p);
-    CHK(check_launch(ctx, "add_pseudocount"));
-    HIPCHK(hipMemcpyAsync(Pi, ctx->scratch[5].p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(Pij, ctx->scratch[4].p, n * n * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    if (!Pi_true_dev || !Pij_true_dev || !Pi_dev || !Pij_dev || !(pc >= 0.0 && pc <= 1.0)) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    gdca_launch_add_pseudocount(ctx->stream, Pi_true_dev, Pij_true_dev, N, q, pc, Pi_dev, Pij_dev);
+    return check_launch(ctx, "add_pseudocount");
 }
 
-gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, int32_t n, double *C)
+gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const double *Pij_dev, int32_t n, double *C_dev)
 {
-    if (!ctx || !Pi || !Pij || !C || n < 1 || n > 60000) return GDCA_EINVAL;
-    CHK(begin(ctx));
-    hipStream_t s = ctx->stream;
-    const size_t nn = (size_t)n;
-    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[2], nn * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[4], nn * nn * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, Pij, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, Pi, nn * sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_covariance(s, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, n,
-                           (double *)ctx->scratch[4].p);
-    CHK(check_launch(ctx, "covariance"));
-    HIPCHK(hipMemcpyAsync(C, ctx->scratch[4].p, nn * nn * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    if (!ctx || !Pi_dev || !Pij_dev || !C_dev || n < 1 || n > 60000) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    gdca_launch_covariance(ctx->stream, Pi_dev, Pij_dev, n, C_dev);
+    return check_launch(ctx, "covariance");
 }
 
-gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
+gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
 {
-    if (!ctx || !A || n < 1 || n > 60000) return GDCA_EINVAL;
+    if (!ctx || !A_dev || n < 1 || n > 60000) return GDCA_EINVAL;
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
     const int n_pad = round_up(n, GDCA_TILE);
-    const size_t nn = (size_t)n;
-    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, A, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_copy_in(s, (const double *)ctx->scratch[1].p, n, (double *)ctx->A.p, n_pad);
+    gdca_launch_copy_in(s, A_dev, n, (double *)ctx->A.p, n_pad);
     int n_upd = 0;
     CHK(inverse_stage(ctx, n, n_pad, false, &n_upd, nullptr));
-    gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, (double *)ctx->scratch[1].p, n);
+    gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, A_dev, n);
     CHK(check_launch(ctx, "copy_out"));
-    HIPCHK(hipMemcpyAsync(A, ctx->scratch[1].p, nn * nn * sizeof(double), hipMemcpyDeviceToHost, s));
     CHK(fetch_scalars(ctx));
     if (info) *info = ctx->sc_host->info;
     if (ctx->sc_host->info != 0)
@@ -734,72 +771,201 @@ gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
     return GDCA_OK;
 }
 
-// mJ (host, n x n full) -> ctx->A as "-mJ" with ld = n_pad (lower triangle is what the score kernels read)
-static gdca_status upload_neg_mJ(gdca_ctx *ctx, const double *mJ, int n, int n_pad)
+// mJ (device, n x n full, ld n) -> ctx->A as "-mJ" with ld = n_pad (the score kernels read its lower triangle)
+static gdca_status stage_neg_mJ(gdca_ctx *ctx, const double *mJ_dev, int n, int n_pad)
 {
-    hipStream_t s = ctx->stream;
-    const size_t nn = (size_t)n;
-    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
-    CHK(ensure(ctx, ctx->scratch[4], nn * nn * sizeof(double)));
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, mJ, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
-    // negate via the symmetric copy-out helper (ld n -> n), then pad
-    gdca_launch_copy_out_neg_sym(s, (const double *)ctx->scratch[1].p, n, (double *)ctx->scratch[4].p, n);
-    gdca_launch_copy_in(s, (const double *)ctx->scratch[4].p, n, (double *)ctx->A.p, n_pad);
-    return check_launch(ctx, "upload_mJ");
+    gdca_launch_copy_in_neg(ctx->stream, mJ_dev, n, (double *)ctx->A.p, n_pad);
+    return check_launch(ctx, "stage_mJ");
+}
+
+gdca_status gdca_fn_dev(gdca_ctx *ctx, const double *mJ_dev, int32_t N, int32_t q, double *S_dev)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!mJ_dev || !S_dev) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
+    CHK(stage_neg_mJ(ctx, mJ_dev, n, n_pad));
+    return score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_FROB, 0, S_dev);
+}
+
+gdca_status gdca_di_dev(gdca_ctx *ctx, const double *mJ_dev, const double *C_dev, int32_t N, int32_t q, double *S_dev)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!mJ_dev || !C_dev || !S_dev) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    hipStream_t s = ctx->stream;
+    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
+    CHK(ensure(ctx, ctx->Dblk, (size_t)N * sdim * sdim * sizeof(double)));
+    CHK(ensure(ctx, ctx->Ld, (size_t)N * sdim * sdim * sizeof(double)));
+    gdca_launch_save_diag_blocks(s, C_dev, (size_t)n, N, sdim, (double *)ctx->Dblk.p);
+    gdca_launch_diag_chol(s, (const double *)ctx->Dblk.p, N, sdim, (double *)ctx->Ld.p);
+    CHK(stage_neg_mJ(ctx, mJ_dev, n, n_pad));
+    CHK(score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_DI, 0, S_dev));
+    CHK(fetch_scalars(ctx));
+    if (ctx->sc_host->di_noconv)
+        return fail(ctx, GDCA_ENOCONV, "eigenvalue iteration of a DI block did not converge%s%s", "", "");
+    return GDCA_OK;
+}
+
+gdca_status gdca_apc_dev(gdca_ctx *ctx, double *S_dev, int32_t N)
+{
+    if (!ctx || !S_dev || N < 1) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
+    gdca_launch_apc(ctx->stream, S_dev, N, (double *)ctx->colsum.p);
+    return check_launch(ctx, "apc");
+}
+
+// ---- operator level, host pointers: copy in, run the `_dev` form, copy out --------------------------------------
+// (what a statement-by-statement caller with ordinary Julia arrays binds; every n x n argument crosses PCIe, so a
+// caller who chains several operators should keep the matrices in gdca_dbuf buffers and use the `_dev` forms)
+
+static gdca_status to_dev(gdca_ctx *ctx, gdca_buf &b, const void *host, size_t bytes)
+{
+    CHK(ensure(ctx, b, bytes));
+    HIPCHK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GDCA_OK;
+}
+
+static gdca_status to_host(gdca_ctx *ctx, void *host, const gdca_buf &b, size_t bytes)
+{
+    HIPCHK(hipMemcpyAsync(host, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+gdca_status gdca_pair_identity_sum(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, uint64_t *out)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !out) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(to_dev(ctx, ctx->scratch[0], Z, (size_t)N * M));
+    return gdca_pair_identity_sum_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, out);
+}
+
+gdca_status gdca_compute_theta(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double *theta)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !theta) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(to_dev(ctx, ctx->scratch[0], Z, (size_t)N * M));
+    return gdca_compute_theta_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, theta);
+}
+
+gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t thresh,
+                                  int32_t *n_out)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !n_out || thresh < 0) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(to_dev(ctx, ctx->scratch[0], Z, (size_t)N * M));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)M * sizeof(int32_t)));
+    CHK(gdca_neighbour_counts_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, thresh, (int32_t *)ctx->scratch[2].p));
+    return to_host(ctx, n_out, ctx->scratch[2], (size_t)M * sizeof(int32_t));
+}
+
+gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta, double *W,
+                                 double *Meff, double *theta_used, int32_t *thresh)
+{
+    CHK(validate(ctx, N, M, 2));
+    if (!Z || !W || !Meff || !(theta <= 1.0)) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(to_dev(ctx, ctx->scratch[0], Z, (size_t)N * M));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)M * sizeof(double)));
+    CHK(gdca_compute_weights_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, theta, (double *)ctx->scratch[2].p, Meff,
+                                 theta_used, thresh));
+    return to_host(ctx, W, ctx->scratch[2], (size_t)M * sizeof(double));
+}
+
+gdca_status gdca_frequencies(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const double *W,
+                             double Meff, double *Pi, double *Pij)
+{
+    CHK(validate(ctx, N, M, q));
+    if (!Z || !W || !Pi || !Pij || !(Meff > 0.0)) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)N * (q - 1);
+    CHK(to_dev(ctx, ctx->scratch[0], Z, (size_t)N * M));
+    CHK(to_dev(ctx, ctx->W, W, (size_t)M * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[1], n * n * sizeof(double)));
+    CHK(ensure(ctx, ctx->scratch[2], n * sizeof(double)));
+    CHK(gdca_frequencies_dev(ctx, (const int8_t *)ctx->scratch[0].p, N, M, q, (const double *)ctx->W.p, Meff,
+                             (double *)ctx->scratch[2].p, (double *)ctx->scratch[1].p));
+    CHK(to_host(ctx, Pi, ctx->scratch[2], n * sizeof(double)));
+    return to_host(ctx, Pij, ctx->scratch[1], n * n * sizeof(double));
+}
+
+gdca_status gdca_add_pseudocount(gdca_ctx *ctx, const double *Pi_true, const double *Pij_true, int32_t N, int32_t q,
+                                 double pc, double *Pi, double *Pij)
+{
+    CHK(validate(ctx, N, 1, q));
+    if (!Pi_true || !Pij_true || !Pi || !Pij || !(pc >= 0.0 && pc <= 1.0)) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)N * (q - 1);
+    CHK(to_dev(ctx, ctx->scratch[1], Pij_true, n * n * sizeof(double)));
+    CHK(to_dev(ctx, ctx->scratch[2], Pi_true, n * sizeof(double)));
+    // elementwise: in place on the device
+    CHK(gdca_add_pseudocount_dev(ctx, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, N, q, pc,
+                                 (double *)ctx->scratch[2].p, (double *)ctx->scratch[1].p));
+    CHK(to_host(ctx, Pi, ctx->scratch[2], n * sizeof(double)));
+    return to_host(ctx, Pij, ctx->scratch[1], n * n * sizeof(double));
+}
+
+gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, int32_t n, double *C)
+{
+    if (!ctx || !Pi || !Pij || !C || n < 1 || n > 60000) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n;
+    CHK(to_dev(ctx, ctx->scratch[1], Pij, nn * nn * sizeof(double)));
+    CHK(to_dev(ctx, ctx->scratch[2], Pi, nn * sizeof(double)));
+    CHK(gdca_covariance_dev(ctx, (const double *)ctx->scratch[2].p, (const double *)ctx->scratch[1].p, n,
+                            (double *)ctx->scratch[1].p));
+    return to_host(ctx, C, ctx->scratch[1], nn * nn * sizeof(double));
+}
+
+gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
+{
+    if (!ctx || !A || n < 1 || n > 60000) return GDCA_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n;
+    CHK(to_dev(ctx, ctx->scratch[1], A, nn * nn * sizeof(double)));
+    CHK(gdca_spd_inverse_dev(ctx, (double *)ctx->scratch[1].p, n, info));
+    return to_host(ctx, A, ctx->scratch[1], nn * nn * sizeof(double));
 }
 
 gdca_status gdca_fn(gdca_ctx *ctx, const double *mJ, int32_t N, int32_t q, double *S)
 {
     CHK(validate(ctx, N, 1, q));
     if (!mJ || !S) return GDCA_EINVAL;
-    CHK(begin(ctx));
-    hipStream_t s = ctx->stream;
-    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
-    CHK(upload_neg_mJ(ctx, mJ, n, n_pad));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)N * (q - 1);
+    CHK(to_dev(ctx, ctx->scratch[1], mJ, n * n * sizeof(double)));
     CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
-    CHK(score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_FROB, 0, (double *)ctx->scratch[2].p));
-    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    CHK(gdca_fn_dev(ctx, (const double *)ctx->scratch[1].p, N, q, (double *)ctx->scratch[2].p));
+    return to_host(ctx, S, ctx->scratch[2], (size_t)N * N * sizeof(double));
 }
 
 gdca_status gdca_di(gdca_ctx *ctx, const double *mJ, const double *C, int32_t N, int32_t q, double *S)
 {
     CHK(validate(ctx, N, 1, q));
     if (!mJ || !C || !S) return GDCA_EINVAL;
-    CHK(begin(ctx));
-    hipStream_t s = ctx->stream;
-    const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
-    const size_t nn = (size_t)n;
-    // diagonal blocks of C -> Cholesky factors
-    CHK(ensure(ctx, ctx->scratch[1], nn * nn * sizeof(double)));
-    CHK(ensure(ctx, ctx->Dblk, (size_t)N * sdim * sdim * sizeof(double)));
-    CHK(ensure(ctx, ctx->Ld, (size_t)N * sdim * sdim * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, C, nn * nn * sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_save_diag_blocks(s, (const double *)ctx->scratch[1].p, nn, N, sdim, (double *)ctx->Dblk.p);
-    gdca_launch_diag_chol(s, (const double *)ctx->Dblk.p, N, sdim, (double *)ctx->Ld.p);
-    CHK(upload_neg_mJ(ctx, mJ, n, n_pad));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)N * (q - 1);
+    CHK(to_dev(ctx, ctx->scratch[1], mJ, n * n * sizeof(double)));
+    CHK(to_dev(ctx, ctx->scratch[4], C, n * n * sizeof(double)));
     CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
-    CHK(score_stage(ctx, N, sdim, n_pad, GDCA_SCORE_DI, 0, (double *)ctx->scratch[2].p));
-    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    CHK(gdca_di_dev(ctx, (const double *)ctx->scratch[1].p, (const double *)ctx->scratch[4].p, N, q,
+                    (double *)ctx->scratch[2].p));
+    return to_host(ctx, S, ctx->scratch[2], (size_t)N * N * sizeof(double));
 }
 
 gdca_status gdca_apc(gdca_ctx *ctx, double *S, int32_t N)
 {
     if (!ctx || !S || N < 1) return GDCA_EINVAL;
-    CHK(begin(ctx));
-    hipStream_t s = ctx->stream;
-    CHK(ensure(ctx, ctx->scratch[2], (size_t)N * N * sizeof(double)));
-    CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, S, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, s));
-    gdca_launch_apc(s, (double *)ctx->scratch[2].p, N, (double *)ctx->colsum.p);
-    CHK(check_launch(ctx, "apc"));
-    HIPCHK(hipMemcpyAsync(S, ctx->scratch[2].p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GDCA_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(to_dev(ctx, ctx->scratch[2], S, (size_t)N * N * sizeof(double)));
+    CHK(gdca_apc_dev(ctx, (double *)ctx->scratch[2].p, N));
+    return to_host(ctx, S, ctx->scratch[2], (size_t)N * N * sizeof(double));
 }
 
 gdca_status gdca_probe_mfma_f64(gdca_ctx *ctx, int32_t iters, double *tflops)

@@ -95,7 +95,10 @@ bool load_family(const Options &o, Family &f)
     gdca_fasta_close(h);
     if (o.remove_dups) {
         int32_t m = 0;
-        gdca_remove_duplicates(f.Z.data(), f.N, f.M, f.Z.data(), nullptr, &m);
+        if (gdca_remove_duplicates(f.Z.data(), f.N, f.M, f.Z.data(), nullptr, &m) != GDCA_OK) {
+            f.error = "duplicate removal failed for " + f.path;
+            return false;
+        }
         f.M = m;
         f.Z.resize((size_t)f.N * f.M);
     }
@@ -218,14 +221,18 @@ int run_batch(const Options &o)
     size_t next_job = 0, parsed_done = 0;
     const size_t cap = (size_t)std::max(2 * G * std::max(1, o.inflight), 4);
     std::atomic<int> failures{0};
+    // GPU workers still able to take families; when the last one is gone (every gdca_ctx_create failed) the parsers
+    // are told to stop: nobody would ever drain `ready`, and they would wait on cv_space for ever
+    int live_workers = 0;
+    bool abort_parsers = false;
 
     auto parser = [&]() {
         for (;;) {
             size_t idx;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_space.wait(lk, [&] { return ready.size() < cap || next_job >= jobs.size(); });
-                if (next_job >= jobs.size()) return;
+                cv_space.wait(lk, [&] { return abort_parsers || ready.size() < cap || next_job >= jobs.size(); });
+                if (abort_parsers || next_job >= jobs.size()) return;
                 idx = next_job++;
                 if (next_job >= jobs.size()) cv_space.notify_all();
             }
@@ -276,6 +283,12 @@ int run_batch(const Options &o)
         if (gdca_ctx_create(g, &ctx) != GDCA_OK) {
             fprintf(stderr, "ERROR: cannot create a context on GPU %d\n", g);
             ++failures;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--live_workers == 0) abort_parsers = true;
+            }
+            cv_space.notify_all();
+            cv_ready.notify_all();
             return;
         }
         for (;;) {
@@ -322,9 +335,10 @@ int run_batch(const Options &o)
         gdca_ctx_destroy(ctx);
     };
     std::vector<std::thread> threads, writers;
-    for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
     // --inflight contexts per GPU: while one family's latency-bound pivot chain runs, another family's kernels fill
     // the idle CUs (independent gdca_ctx objects on the same device, no ordering between them)
+    live_workers = std::max(1, o.inflight) * G;
+    for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
     for (int k = 0; k < std::max(1, o.inflight); ++k)
         for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
     for (int w = 0; w < std::max(2, 2 * G); ++w) writers.emplace_back(writer);
@@ -336,6 +350,7 @@ int run_batch(const Options &o)
     cv_out.notify_all();
     for (auto &t : writers) t.join();
     const double wall = now() - t0;
+    if (abort_parsers) fprintf(stderr, "ERROR: no GPU worker could start; %zu families not processed\n", jobs.size());
     fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
             (double)jobs.size() / wall, failures.load());
     for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", g, count[(size_t)g], busy[(size_t)g]);

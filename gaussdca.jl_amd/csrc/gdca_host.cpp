@@ -210,6 +210,26 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
                 misaligned = true;  // "inputs are not aligned"
                 return;
             }
+            // "inconsistent inputs": the match columns of every record (neither '.' nor lowercase) must be exactly
+            // those of the first one
+            if (r > 0) {
+                size_t nm = 0;
+                bool same = true;
+                for (size_t p = 0; p < sq.size(); ++p) {
+                    const char c = sq[p];
+                    if (c != '.' && !(c >= 'a' && c <= 'z')) {
+                        if (nm >= cols.size() || cols[nm] != (uint32_t)p) {
+                            same = false;
+                            break;
+                        }
+                        ++nm;
+                    }
+                }
+                if (!same || nm != cols.size()) {
+                    misaligned = true;
+                    return;
+                }
+            }
             int8_t *row = h->Z.data() + r * (size_t)n;
             int ngaps = 0;
             for (int32_t i = 0; i < n; ++i) {
@@ -256,13 +276,18 @@ gdca_status gdca_remove_duplicates(const int8_t *Z, int32_t N, int32_t M, int8_t
                                    int32_t *M_out)
 {
     if (!Z || !Z_out || !M_out || N < 1 || M < 0) return GDCA_EINVAL;
+    // The set's keys are views of the DESTINATION rows: row k is first copied to slot m of Z_out (m <= k, so with
+    // Z_out == Z only a row that has already been examined is overwritten), then a view of that slot is inserted and
+    // the slot is kept only if the insert succeeded.  Slots below m are never rewritten, so every key stays valid --
+    // also when Z_out aliases Z (keys that pointed into Z itself were destroyed by the in-place compaction).
     std::unordered_set<std::string_view> seen;
     seen.reserve((size_t)M * 2);
     int32_t m = 0;
     for (int32_t k = 0; k < M; ++k) {
-        const std::string_view key((const char *)Z + (size_t)k * N, (size_t)N);
-        if (seen.insert(key).second) {
-            if (Z_out + (size_t)m * N != Z + (size_t)k * N) memmove(Z_out + (size_t)m * N, Z + (size_t)k * N, (size_t)N);
+        int8_t *slot = Z_out + (size_t)m * N;
+        const int8_t *src = Z + (size_t)k * N;
+        if (slot != src) memmove(slot, src, (size_t)N);
+        if (seen.insert(std::string_view((const char *)slot, (size_t)N)).second) {
             if (keep_idx) keep_idx[m] = k + 1;  // 1-based, as Julia returns them
             ++m;
         }

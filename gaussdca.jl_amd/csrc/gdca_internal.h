@@ -17,6 +17,8 @@ struct gdca_dev_scalars {
     unsigned long long pair_sum;
     int thresh;
     int info;
+    int bad_symbol;  // bit 0: a byte of Z is outside 1..q; bit 1: a caller-given weight is outside [0, 1] (GDCA_EINVAL)
+    int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
 };
 
 // ---- k_theta.hip -------------------------------------------------------------------------
@@ -32,7 +34,9 @@ void gdca_launch_set_thresh(hipStream_t s, gdca_dev_scalars *sc, int thresh);
 // ---- k_hamming.hip -----------------------------------------------------------------------
 // bit-plane image: uint32 [Mt][5][NW][128], Mt = ceil(M/128), NW = ceil(N/32)
 size_t gdca_bitplane_bytes(int N, int M);
-void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M);
+// q: largest legal symbol (bytes outside 1..q set sc->bad_symbol)
+void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M, int q,
+                               gdca_dev_scalars *sc);
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
 void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
                          const gdca_dev_scalars *sc);
@@ -42,13 +46,14 @@ void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift
 // Meff = W[0] + W[1] + ... strictly left to right (one wave)
 void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc);
 // Wfix from caller-given W (operator-level gdca_frequencies)
-void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix);
+void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix,
+                             gdca_dev_scalars *sc);
 int gdca_fix_shift(int M);
 
 // ---- k_tally.hip -------------------------------------------------------------------------
 // Pifix: u64 [N][32] zeroed by the caller; adds sum_k Wfix[k] [Z[i,k]==a] at [i][a-1]
 void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const unsigned long long *Wfix,
-                          unsigned long long *Pifix, int N, int M);
+                          unsigned long long *Pifix, int N, int M, int q, gdca_dev_scalars *sc);
 // Pi_true[i*s+a] = Pifix * 2^-shift / Meff;  Pi_pc = (1-pc) Pi_true + pc/q
 void gdca_launch_pi_finalize(hipStream_t s, const unsigned long long *Pifix, int N, int q, int fix_shift,
                              const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc);
@@ -69,6 +74,8 @@ void gdca_launch_covariance(hipStream_t s, const double *Pi, const double *Pij, 
 void gdca_launch_pad_identity(hipStream_t s, double *A, int n, int n_pad);
 // copy a dense n x n (ld_src) into the padded buffer (ld_dst) / back, with optional negate+mirror
 void gdca_launch_copy_in(hipStream_t s, const double *src, int n, double *dst, int n_pad);
+// same with the real block negated (mJ -> the "-mJ" image the score kernels read)
+void gdca_launch_copy_in_neg(hipStream_t s, const double *src, int n, double *dst, int n_pad);
 // dst (n x n, ld n) = full symmetric  -lower(A)  (A holds -inverse in its lower triangle)
 void gdca_launch_copy_out_neg_sym(hipStream_t s, const double *A, int n_pad, double *dst, int n);
 // D[i] (s x s, packed) = diagonal block i of C (ld)
@@ -101,5 +108,5 @@ void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, doub
 // Tws: workspace of gdca_di_ws_bytes(N, sdim) bytes (tridiagonals of all site pairs)
 size_t gdca_di_ws_bytes(int N, int sdim);
 void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S,
-                    double *Tws);
+                    double *Tws, gdca_dev_scalars *sc);
 void gdca_launch_apc(hipStream_t s, double *S, int N, double *rowsum_ws);

@@ -64,6 +64,7 @@ void gdca_launch_pad_identity(hipStream_t s, double *A, int n, int n_pad)
     hipLaunchKernelGGL(k_pad_identity, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, A, n, n_pad);
 }
 
+template <bool NEG>
 __global__ __launch_bounds__(256) void k_copy_in(const double *__restrict__ src, int n, double *__restrict__ dst,
                                                   int n_pad)
 {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_copy_in(const double *__restrict__ src,
     if (r >= n_pad) return;
     double v;
     if (r < n && c < n)
-        v = src[(size_t)r + (size_t)c * n];
+        v = NEG ? -src[(size_t)r + (size_t)c * n] : src[(size_t)r + (size_t)c * n];
     else
         v = (r == c) ? 1.0 : 0.0;
     dst[(size_t)r + (size_t)c * n_pad] = v;
@@ -80,7 +81,12 @@ __global__ __launch_bounds__(256) void k_copy_in(const double *__restrict__ src,
 
 void gdca_launch_copy_in(hipStream_t s, const double *src, int n, double *dst, int n_pad)
 {
-    hipLaunchKernelGGL(k_copy_in, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, src, n, dst, n_pad);
+    hipLaunchKernelGGL(k_copy_in<false>, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, src, n, dst, n_pad);
+}
+
+void gdca_launch_copy_in_neg(hipStream_t s, const double *src, int n, double *dst, int n_pad)
+{
+    hipLaunchKernelGGL(k_copy_in<true>, dim3((n_pad + 255) / 256, n_pad), dim3(256), 0, s, src, n, dst, n_pad);
 }
 
 // dst[r][c] = dst[c][r] = -A[max(r,c)][min(r,c)]  through a 32 x 32 LDS tile so that both the

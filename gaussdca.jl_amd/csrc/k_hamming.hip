@@ -31,8 +31,10 @@ size_t gdca_bitplane_bytes(int N, int M)
 // ---- Z [M][N] bytes -> bit planes [Mt][5][NW][128] -------------------------------------------
 // thread <-> sequence, blockIdx.y <-> dword of 32 positions: 128 contiguous dwords per store.
 __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict__ Z, uint32_t *__restrict__ Zb,
-                                                        int N, int M, int NW)
+                                                        int N, int M, int NW, int q, gdca_dev_scalars *sc)
 {
+    uint32_t bad = 0;  // any byte outside 1..q (checked here because every weights computation passes through)
+    const uint32_t over = (0x7fu - (uint32_t)q) * 0x01010101u;
     const int tile = blockIdx.x, w = blockIdx.y, kl = threadIdx.x;
     const int k = tile * GDCA_HTILE + kl;
     uint32_t pl[NPLANES];
@@ -48,6 +50,11 @@ __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = s4[j];
 #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bad |= (d[j] - 0x01010101u) & ~d[j] & 0x80808080u;                      // a zero byte
+                bad |= (((d[j] & 0x7f7f7f7fu) + over) | d[j]) & 0x80808080u;           // a byte > q
+            }
+#pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int p = 0; p < NPLANES; ++p) {
@@ -56,7 +63,9 @@ __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict_
                 }
         } else {
             for (int b = 0; b < nb; ++b) {
-                const uint32_t z = (uint32_t)src[b] & 31u;
+                const uint32_t raw = (uint32_t)(uint8_t)src[b];
+                bad |= (raw - 1u) >= (uint32_t)q;
+                const uint32_t z = raw & 31u;
 #pragma unroll
                 for (int p = 0; p < NPLANES; ++p) pl[p] |= ((z >> p) & 1u) << b;
             }
@@ -65,12 +74,13 @@ __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict_
 #pragma unroll
     for (int p = 0; p < NPLANES; ++p)
         Zb[(((size_t)tile * NPLANES + p) * NW + w) * GDCA_HTILE + kl] = pl[p];
+    if (bad) atomicOr(&sc->bad_symbol, 1);
 }
 
-void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M)
+void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M, int q, gdca_dev_scalars *sc)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
-    hipLaunchKernelGGL(k_bitplane_pack, dim3(Mt, NW), dim3(128), 0, s, Z, Zb, N, M, NW);
+    hipLaunchKernelGGL(k_bitplane_pack, dim3(Mt, NW), dim3(128), 0, s, Z, Zb, N, M, NW, q, sc);
 }
 
 // ---- all-pairs distances, thresholded neighbour counts ----------------------------------------
@@ -247,15 +257,22 @@ void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift
 }
 
 __global__ __launch_bounds__(256) void k_fix_weights(const double *__restrict__ W, int M, int fix_shift,
-                                                      unsigned long long *__restrict__ Wfix)
+                                                      unsigned long long *__restrict__ Wfix, gdca_dev_scalars *sc)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < M) Wfix[k] = (unsigned long long)rint(ldexp(W[k], fix_shift));
+    if (k >= M) return;
+    const double w = W[k];
+    // a weight outside [0, 1] (or NaN) does not fit the 59-bit field of the tally's packed word: flagged (bit 1 of
+    // bad_symbol), staged as 0
+    const bool ok = w >= 0.0 && w <= 1.0;
+    if (!ok) atomicOr(&sc->bad_symbol, 2);
+    Wfix[k] = ok ? (unsigned long long)rint(ldexp(w, fix_shift)) : 0ull;
 }
 
-void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix)
+void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix,
+                             gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_fix_weights, dim3((M + 255) / 256), dim3(256), 0, s, W, M, fix_shift, Wfix);
+    hipLaunchKernelGGL(k_fix_weights, dim3((M + 255) / 256), dim3(256), 0, s, W, M, fix_shift, Wfix, sc);
 }
 
 // Meff = ((W[0] + W[1]) + W[2]) + ...  -- the strictly sequential f64 sum the oracle uses, so the

@@ -229,8 +229,9 @@ __device__ __forceinline__ double pythag(double a, double b)
 
 __global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, const double *__restrict__ Te,
                                                long long tstride, long long npairs, int N, int sdim,
-                                               double *__restrict__ S)
+                                               double *__restrict__ S, gdca_dev_scalars *sc)
 {
+    bool noconv = false;
     extern __shared__ __attribute__((aligned(16))) double qsm[];
     const int lane = threadIdx.x;
     double *d = qsm + lane;                 // d[t * 64]
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, con
         if (m != l) {
             double tst2;
             do {
-                if (++iter > 40) break;
+                if (++iter > 40) {  // tql1 gives up after 30; LAPACK's dsteqr would raise: reported, not swallowed
+                    noconv = true;
+                    break;
+                }
                 // form shift
                 const int l1 = l + 1;
                 double g = d[l * 64];
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, con
         }
         d[l * 64] = d[l * 64] + f;  // eigenvalue l (unordered)
     }
+    if (live && noconv) atomicAdd(&sc->di_noconv, 1);
     if (live) {
         double acc = 0.0;
         for (int t = 0; t < n; ++t) {
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, con
 }
 
 void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S,
-                    double *Tws)
+                    double *Tws, gdca_dev_scalars *sc)
 {
     (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
     const long long npairs = (long long)N * (N - 1) / 2;
@@ -323,7 +328,7 @@ void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld,
     const size_t lds1 = (size_t)(2 * sdim * sdim + 64) * sizeof(double);
     hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)npairs), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
     const size_t lds2 = (size_t)2 * sdim * 64 * sizeof(double);
-    hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S);
+    hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S, sc);
 }
 
 size_t gdca_di_ws_bytes(int N, int sdim)

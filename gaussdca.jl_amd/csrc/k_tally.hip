@@ -25,9 +25,11 @@ typedef unsigned long long u64;
 
 // ---- single-site sums -----------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, const u64 *__restrict__ Wfix,
-                                                   u64 *__restrict__ Pifix, int N, int M, int seq_per_block)
+                                                   u64 *__restrict__ Pifix, int N, int M, int seq_per_block, int q,
+                                                   gdca_dev_scalars *sc)
 {
     __shared__ u64 h[32][128];
+    unsigned bad = 0;  // any byte outside 1..q
     const int t = threadIdx.x;
     const int i = blockIdx.x * 128 + t;
 #pragma unroll
@@ -40,15 +42,22 @@ __global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, 
         for (; k + 16 <= kend; k += 16) {  // 16 strided byte loads in flight before the dependent LDS adds
             int z[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) z[u] = p[(size_t)u * N] & 31;
+            for (int u = 0; u < 16; ++u) {
+                const unsigned raw = (uint8_t)p[(size_t)u * N];
+                bad |= (raw - 1u) >= (unsigned)q;
+                z[u] = raw & 31;
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) h[z[u]][t] += Wfix[k + u];
             p += (size_t)16 * N;
         }
         for (; k < kend; ++k) {
-            h[p[0] & 31][t] += Wfix[k];
+            const unsigned raw = (uint8_t)p[0];
+            bad |= (raw - 1u) >= (unsigned)q;
+            h[raw & 31][t] += Wfix[k];
             p += N;
         }
+        if (bad) atomicOr(&sc->bad_symbol, 1);
 #pragma unroll
         for (int z = 0; z < 32; ++z) {
             const u64 v = h[z][t];
@@ -57,14 +66,15 @@ __global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, 
     }
 }
 
-void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const u64 *Wfix, u64 *Pifix, int N, int M)
+void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const u64 *Wfix, u64 *Pifix, int N, int M, int q,
+                          gdca_dev_scalars *sc)
 {
     const int cb = (N + 127) / 128;
     int chunks = (512 + cb - 1) / cb;  // every chunk ends in one global atomic per counter
     int spb = (M + chunks - 1) / chunks;
     if (spb < 64) spb = 64;
     chunks = (M + spb - 1) / spb;
-    hipLaunchKernelGGL(k_pi_tally, dim3(cb, chunks), dim3(128), 0, s, Z, Wfix, Pifix, N, M, spb);
+    hipLaunchKernelGGL(k_pi_tally, dim3(cb, chunks), dim3(128), 0, s, Z, Wfix, Pifix, N, M, spb, q, sc);
 }
 
 __global__ __launch_bounds__(256) void k_pi_finalize(const u64 *__restrict__ Pifix, int N, int q, int fix_shift,

@@ -47,59 +47,7 @@ def _theta_arg(theta) -> float:
 
 
 # ---- host I/O (reference: DCAUtils.read_fasta_alignment, src/GaussDCA.jl:20) -----------------------
-def read_fasta_alignment_py(filename: str, max_gap_fraction: float) -> np.ndarray:
-    """Pure-Python form of read_fasta_alignment (kept as the readable statement of the rules and as a
-    cross-check of the native reader in the tests).  FASTA (plain or .gz) -> Z::Matrix{Int8}, shape (N, M).  Columns kept = positions of the
-    first record that are neither '.' nor lowercase; sequences with more than
-    ``max_gap_fraction`` gaps ('-') are dropped; ACDEFGHIKLMNPQRSTVWY -> 1..20, else 21."""
-    opener = gzip.open if str(filename).endswith(".gz") else open
-    seqs: List[str] = []
-    cur = None
-    with opener(filename, "rt") as f:
-        for line in f:
-            line = line.strip()
-            if not line:
-                continue
-            if line[0] == ">":
-                if cur is not None:
-                    seqs.append("".join(cur))
-                cur = []
-            elif cur is not None:
-                cur.append(line)
-    if cur is not None:
-        seqs.append("".join(cur))
-    if not seqs:
-        raise ValueError("empty alignment")
-    first = seqs[0]
-    cols = np.asarray([p for p, c in enumerate(first) if c != "." and not c.islower()], dtype=np.int64)
-    N = cols.size
-    kept = []
-    for sq in seqs:
-        b = np.frombuffer(sq.encode("ascii"), dtype=np.uint8)
-        if b.size != len(first):
-            raise ValueError("inputs are not aligned")
-        b = b[cols]
-        if np.count_nonzero(b == ord("-")) / N <= max_gap_fraction:
-            kept.append(_L2N[b])
-    return np.asfortranarray(np.stack(kept, axis=1).astype(np.int8))
-
-
-def remove_duplicate_sequences_py(Z) -> Tuple[np.ndarray, np.ndarray]:
-    """-> (Z without repeated columns, 1-based indices kept); first occurrences, order kept
-    (reference call site src/GaussDCA.jl:21-23)."""
-    Zf = _zf(Z)
-    seen = set()
-    keep = []
-    for k in range(Zf.shape[1]):
-        key = Zf[:, k].tobytes()
-        if key not in seen:
-            seen.add(key)
-            keep.append(k)
-    keep_a = np.asarray(keep, dtype=np.int64)
-    return np.asfortranarray(Zf[:, keep_a]), keep_a + 1
-
-
-# ---- native host utilities (libgdca.so, plain C++; same results as the *_py forms above) -------------------
+# ---- native host utilities (libgdca.so, plain C++; pure-Python statements of the same rules: tests/host_mirrors.py) ----
 def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
     """read_fasta_alignment(filename, max_gap_fraction) -> Z::Matrix{Int8}, shape (N, M), Fortran order
     (reference call site src/GaussDCA.jl:20)."""
@@ -325,30 +273,6 @@ def correct_APC(S, ctx=None) -> np.ndarray:
     A = np.array(S, dtype=np.float64, order="C", copy=True)
     ctx.check(ctx.lib.gdca_apc(ctx.h, _lib._p(A), A.shape[0]))
     return A
-
-
-# ---- host ranking (reference: compute_ranking, src/GaussDCA.jl:88-99) ---------------------------------
-def compute_ranking_py(S, min_separation: int = 5) -> List[Tuple[int, int, float]]:
-    """[(i, j, S[j, i])] for 1 <= i, j = i + min_separation .. N, sorted by score descending with
-    a stable sort (exact ties keep generation order, as Julia's default sort! does)."""
-    S = np.asarray(S)
-    N = S.shape[0]
-    m = int(min_separation)
-    ii, jj = [], []
-    for i in range(N - m):
-        js = np.arange(i + m, N)
-        ii.append(np.full(js.size, i, dtype=np.int64))
-        jj.append(js)
-    if not ii:
-        return []
-    ii = np.concatenate(ii)
-    jj = np.concatenate(jj)
-    sc = S[jj, ii]
-    # Julia's isless, reversed: NaN first, then descending, 0.0 before -0.0; stable
-    nan = np.isnan(sc)
-    negzero = (sc == 0) & np.signbit(sc)
-    order = np.lexsort((negzero, np.where(nan, 0.0, -sc), ~nan))  # last key is the primary one; lexsort is stable
-    return [(int(ii[t]) + 1, int(jj[t]) + 1, float(sc[t])) for t in order]
 
 
 def printrank(io, R: Sequence[Tuple[int, int, float]] = None):

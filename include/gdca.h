@@ -39,19 +39,22 @@ extern "C" {
 #endif
 
 #define GDCA_VERSION_MAJOR 0
-#define GDCA_VERSION_MINOR 1
+#define GDCA_VERSION_MINOR 2
 
 typedef enum gdca_status {
     GDCA_OK = 0,
     GDCA_EINVAL = 1, /* bad argument: mirrors ArgumentError (src/GaussDCA.jl:50-62) and q >= 32 (:26) */
     GDCA_ENOTPD = 2, /* covariance not positive definite: mirrors PosDefException(info) from :34 */
     GDCA_EHIP = 3,   /* HIP runtime error; see gdca_last_error() */
-    GDCA_ENOMEM = 4  /* device or host allocation failed */
+    GDCA_ENOMEM = 4, /* device or host allocation failed */
+    GDCA_ENOCONV = 5 /* eigenvalue iteration inside compute_DI_gauss did not converge: mirrors the LAPACKException
+                        eigen()/eigvals() would raise inside DCAUtils (call site :37); stats.info = -(pairs affected) */
 } gdca_status;
 
 enum { GDCA_SCORE_FROB = 0, GDCA_SCORE_DI = 1 }; /* score = :frob | :DI (src/GaussDCA.jl:14) */
 
 typedef struct gdca_ctx gdca_ctx;
+typedef struct gdca_dbuf gdca_dbuf; /* an owned HBM allocation (see "device buffers" below) */
 
 /* Keyword arguments of gDCA() that reach the hot path (src/GaussDCA.jl:10-15). */
 typedef struct gdca_params {
@@ -67,7 +70,8 @@ typedef struct gdca_stats {
     double Meff;                /* effective number of sequences                            */
     uint64_t pair_identity_sum; /* sum_{k<l} #{i: Z[i,k]==Z[i,l]} (0 unless theta = :auto)  */
     int32_t thresh;             /* floor(theta * N)                                         */
-    int32_t info;               /* 0, or k>0: leading minor k of C not positive definite    */
+    int32_t info;               /* 0; k>0: leading minor k of C not positive definite;
+                                   k<0: -k site pairs whose DI eigenvalue iteration failed  */
     int32_t N, M, q, n, n_pad;  /* n = N(q-1); n_pad = n rounded up to the tile size        */
     int32_t update_launches;    /* launches of the dominant kernel (trailing sweep update)  */
     /* device time (HIP events on the ctx stream), milliseconds */
@@ -111,11 +115,51 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
                          const gdca_params *p, double *S_dev, gdca_stats *st);
 
 /* Split form for pipelining independent families over several contexts on one GPU: _async only
- * enqueues (no host synchronisation); gdca_run_collect waits for that run and fills *st.  One run
- * may be outstanding per ctx; the Z and S buffers must stay valid until it is collected. */
+ * enqueues (no host synchronisation); gdca_run_collect waits for that run, fills *st and returns the run's
+ * status.  One run may be outstanding per ctx (a second _async before the collect is GDCA_EINVAL); the Z and S
+ * buffers must stay valid until it is collected. */
 gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
                                const gdca_params *p, double *S_dev);
 gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st);
+
+/* ---- device buffers ---------------------------------------------------------------------- */
+/* For callers without a GPU array type of their own (the Julia shim): an owned allocation in the HBM of ctx's
+ * device.  gdca_dbuf_ptr() is the plain device pointer the `_dev` entry points take (any other device pointer of
+ * the same GPU, e.g. a torch tensor's data_ptr, is as good).  upload/download are synchronous. */
+gdca_status gdca_dbuf_alloc(gdca_ctx *ctx, uint64_t bytes, gdca_dbuf **out);
+gdca_status gdca_dbuf_free(gdca_dbuf *buf);
+void *gdca_dbuf_ptr(const gdca_dbuf *buf);
+uint64_t gdca_dbuf_bytes(const gdca_dbuf *buf);
+gdca_status gdca_dbuf_upload(gdca_ctx *ctx, gdca_dbuf *buf, uint64_t offset, const void *host, uint64_t bytes);
+gdca_status gdca_dbuf_download(gdca_ctx *ctx, const gdca_dbuf *buf, uint64_t offset, void *host, uint64_t bytes);
+
+/* ---- operator level, device-resident: the statements of src/GaussDCA.jl:28-42 one by one with every array in HBM --
+ * Same meaning as the host-pointer operators below (which are "upload, call the _dev form, download"); array
+ * arguments are device pointers, scalars come back through host pointers.  Dense matrices are n x n column-major
+ * with leading dimension n (n = N (q-1)).  A maintainer who keeps the reference's statement-by-statement gDCA()
+ * moves only Z in and S out over PCIe:
+ *     W, Meff           <- gdca_compute_weights_dev            (compute_weights inside :28)
+ *     Pi_true, Pij_true <- gdca_frequencies_dev                (:28)
+ *     Pi, Pij           <- gdca_add_pseudocount_dev            (:30; may run in place)
+ *     C                 <- gdca_covariance_dev                 (:32, :76; C may alias Pij)
+ *     mJ                <- gdca_spd_inverse_dev                (:34; in place)
+ *     S                 <- gdca_fn_dev | gdca_di_dev           (:37, :39)
+ *     S                 <- gdca_apc_dev                        (:42; in place)                                         */
+gdca_status gdca_pair_identity_sum_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, uint64_t *out);
+gdca_status gdca_compute_theta_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, double *theta);
+gdca_status gdca_neighbour_counts_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t thresh,
+                                      int32_t *n_dev);
+gdca_status gdca_compute_weights_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, double theta,
+                                     double *W_dev, double *Meff, double *theta_used, int32_t *thresh);
+gdca_status gdca_frequencies_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                                 const double *W_dev, double Meff, double *Pi_dev, double *Pij_dev);
+gdca_status gdca_add_pseudocount_dev(gdca_ctx *ctx, const double *Pi_true_dev, const double *Pij_true_dev, int32_t N,
+                                     int32_t q, double pc, double *Pi_dev, double *Pij_dev);
+gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const double *Pij_dev, int32_t n, double *C_dev);
+gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info);
+gdca_status gdca_fn_dev(gdca_ctx *ctx, const double *mJ_dev, int32_t N, int32_t q, double *S_dev);
+gdca_status gdca_di_dev(gdca_ctx *ctx, const double *mJ_dev, const double *C_dev, int32_t N, int32_t q, double *S_dev);
+gdca_status gdca_apc_dev(gdca_ctx *ctx, double *S_dev, int32_t N);
 
 /* ---- operator level (host pointers): what the DCAUtils-named wrappers bind -------------- */
 /* compute_theta's all-pairs identity sum (inside compute_weighted_frequencies, :28) */
@@ -130,7 +174,7 @@ gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int
 gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta,
                                  double *W, double *Meff, double *theta_used, int32_t *thresh);
 /* weighted one-/two-site frequencies (compute_weighted_frequencies' accumulation, :28):
- * Pi[n], Pij[n x n] full symmetric */
+ * Pi[n], Pij[n x n] full symmetric.  Every W[k] must lie in [0, 1] and every byte of Z in 1..q (GDCA_EINVAL). */
 gdca_status gdca_frequencies(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q,
                              const double *W, double Meff, double *Pi, double *Pij);
 /* add_pseudocount(Pi_true, Pij_true, pc, q) (:30) */

@@ -5,14 +5,21 @@
 # used by the reference (compute_weights, compute_weighted_frequencies, add_pseudocount,
 # compute_FN, compute_DI_gauss) are thin `ccall` wrappers over include/gdca.h.
 #
-# NOT EXECUTED in the build image (no Julia toolchain there); kept minimal and literal.
+# The host pieces of the reference that are NOT on the hot path are not restated here: argument checks, ranking and
+# printing are the reference's own functions (GaussDCA.check_arguments / compute_ranking / printrank,
+# src/GaussDCA.jl:49-65, :88-99, :67-74), FASTA reading and duplicate removal are DCAUtils'.
+#
+# NOT EXECUTED in the build image (no Julia toolchain there); kept minimal and literal.  The struct layouts and
+# status codes below are checked mechanically against include/gdca.h by
+# tests/test_cabi_cpu.py::test_struct_layouts_agree_across_c_ctypes_and_julia.
 module GaussDCAHip
 
-export gDCA, printrank, compute_weights, compute_weighted_frequencies, add_pseudocount,
+export gDCA, gDCA_stepwise, printrank, compute_weights, compute_weighted_frequencies, add_pseudocount,
        compute_FN, compute_DI_gauss
 
-using LinearAlgebra, Printf
-import DCAUtils  # host-side I/O only: read_fasta_alignment, remove_duplicate_sequences
+using LinearAlgebra
+import DCAUtils                                   # host-side I/O only: read_fasta_alignment, remove_duplicate_sequences
+import GaussDCA: check_arguments, compute_ranking, printrank   # unchanged host code of the reference
 
 const libgdca = get(ENV, "LIBGDCA", "libgdca.so")
 
@@ -49,6 +56,7 @@ function check(st::Integer, info::Integer = 0)
     st == 1 && throw(ArgumentError(msg))
     st == 2 && throw(PosDefException(info))
     st == 4 && throw(OutOfMemoryError())
+    st == 5 && throw(LinearAlgebra.LAPACKException(info))   # what eigvals() raises inside compute_DI_gauss (:37)
     error("libgdca: $msg")
 end
 
@@ -80,19 +88,6 @@ function gDCA(filename::AbstractString; pseudocount::Real = 0.8, θ = :auto, max
     q ≥ 32 && error("parameter q=$q is too big (max 31 is allowed)")
     S, _ = hot_path(Z, q, pseudocount, θ, score)
     return compute_ranking(S, min_separation)
-end
-
-function check_arguments(filename, pseudocount, θ, max_gap_fraction, score, min_separation)
-    aerror(s) = throw(ArgumentError(s))
-    0 <= pseudocount <= 1 || aerror("invalid pseudocount value: $pseudocount (must be between 0 and 1)")
-    θ == :auto || (θ isa Real && 0 <= θ <= 1) ||
-        aerror("invalid θ value: $θ (must be either :auto, or a number between 0 and 1)")
-    0 <= max_gap_fraction <= 1 ||
-        aerror("invalid max_gap_fraction value: $max_gap_fraction (must be between 0 and 1)")
-    score in [:DI, :frob] || aerror("invalid score value: $score (must be either :DI or :frob)")
-    min_separation >= 1 || aerror("invalid min_separation value: $min_separation (must be >= 1)")
-    isfile(filename) || aerror("cannot open file $filename")
-    return true
 end
 
 # ---- DCAUtils-named operators (call sites src/GaussDCA.jl:28,30,37,39) ----------------------
@@ -146,25 +141,65 @@ function compute_DI_gauss(mJ::Matrix{Float64}, C::Matrix{Float64}, q::Integer = 
     return S
 end
 
-# ---- unchanged host pieces of the reference (src/GaussDCA.jl:67-74, :88-99) ------------------
-function compute_ranking(S::Matrix{Float64}, min_separation::Integer = 5)
-    N = size(S, 1)
-    R = Array{Tuple{Int,Int,Float64}}(undef, ((N - min_separation) * (N - min_separation + 1)) ÷ 2)
-    counter = 0
-    for i = 1:N-min_separation, j = i+min_separation:N
-        counter += 1
-        R[counter] = (i, j, S[j, i])
+# ---- device-resident form of the reference's statement-by-statement pipeline ---------------------------------
+# src/GaussDCA.jl:28-42 kept as six statements, every array in HBM (gdca_dbuf handles; `_dev` entry points of
+# include/gdca.h): only Z goes in and S comes out over PCIe.
+mutable struct DBuf
+    h::Ptr{Cvoid}
+    function DBuf(bytes::Integer)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:gdca_dbuf_alloc, libgdca), Cint, (Ptr{Cvoid}, UInt64, Ref{Ptr{Cvoid}}), ctx(), bytes, r))
+        b = new(r[])
+        finalizer(x -> ccall((:gdca_dbuf_free, libgdca), Cint, (Ptr{Cvoid},), x.h), b)
+        return b
     end
-    sort!(R, by = x -> x[3], rev = true)
-    return R
 end
+dptr(b::DBuf) = ccall((:gdca_dbuf_ptr, libgdca), Ptr{Cvoid}, (Ptr{Cvoid},), b.h)
+upload!(b::DBuf, a::Array) = GC.@preserve a check(ccall((:gdca_dbuf_upload, libgdca), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ptr{Cvoid}, UInt64), ctx(), b.h, 0, a, sizeof(a)))
+download!(a::Array, b::DBuf) = GC.@preserve a check(ccall((:gdca_dbuf_download, libgdca), Cint,
+    (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ptr{Cvoid}, UInt64), ctx(), b.h, 0, a, sizeof(a)))
 
-function printrank(io::IO, R::Vector{Tuple{Int,Int,Float64}})
-    for I in R
-        @printf(io, "%i %i %e\n", I[1], I[2], I[3])
+function gDCA_stepwise(Z::Matrix{Int8}; pseudocount::Real = 0.8, θ = :auto, score::Symbol = :frob,
+                       min_separation::Integer = 5)
+    N, M = size(Z); q = Int(maximum(Z)); n = N * (q - 1)
+    q ≥ 32 && error("parameter q=$q is too big (max 31 is allowed)")
+    dZ = DBuf(N * M); upload!(dZ, Z)
+    dW = DBuf(8M); dPi = DBuf(8n); dPij = DBuf(8n * n); dS = DBuf(8N * N)
+    Meff = Ref{Cdouble}(0); th = Ref{Cdouble}(0); thr = Ref{Int32}(0); info = Ref{Int32}(0)
+    c = ctx()
+    # Pi_true, Pij_true, Meff, _ = compute_weighted_frequencies(Z, q, θ)                          (:28)
+    check(ccall((:gdca_compute_weights_dev, libgdca), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Cdouble, Ptr{Cvoid}, Ref{Cdouble}, Ref{Cdouble}, Ref{Int32}),
+        c, dptr(dZ), N, M, theta_arg(θ), dptr(dW), Meff, th, thr))
+    check(ccall((:gdca_frequencies_dev, libgdca), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}),
+        c, dptr(dZ), N, M, q, dptr(dW), Meff[], dptr(dPi), dptr(dPij)))
+    # Pi, Pij = add_pseudocount(Pi_true, Pij_true, Float64(pseudocount), q)   (in place)          (:30)
+    check(ccall((:gdca_add_pseudocount_dev, libgdca), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}),
+        c, dptr(dPi), dptr(dPij), N, q, Float64(pseudocount), dptr(dPi), dptr(dPij)))
+    # C = compute_C(Pi, Pij)                                                                       (:32)
+    dC = DBuf(8n * n)
+    check(ccall((:gdca_covariance_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+        c, dptr(dPi), dptr(dPij), n, dptr(dC)))
+    # mJ = inv(cholesky(C))        (dPij is reused for mJ; C itself is kept for compute_DI_gauss)  (:34)
+    check(ccall((:gdca_covariance_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}),
+        c, dptr(dPi), dptr(dPij), n, dptr(dPij)))
+    rc = ccall((:gdca_spd_inverse_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Int32}), c, dptr(dPij), n, info)
+    check(rc, info[])
+    # S = score == :DI ? compute_DI_gauss(mJ, C, q) : compute_FN(mJ, q)                            (:36-40)
+    if score == :DI
+        check(ccall((:gdca_di_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}),
+            c, dptr(dPij), dptr(dC), N, q, dptr(dS)))
+    else
+        check(ccall((:gdca_fn_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}),
+            c, dptr(dPij), N, q, dptr(dS)))
     end
+    # S = correct_APC(S)                                                                           (:42)
+    check(ccall((:gdca_apc_dev, libgdca), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), c, dptr(dS), N))
+    S = Matrix{Float64}(undef, N, N); download!(S, dS)
+    return compute_ranking(S, min_separation)                                                    # :44
 end
-printrank(R::Vector{Tuple{Int,Int,Float64}}) = printrank(stdout, R)
-printrank(outfile::AbstractString, R::Vector{Tuple{Int,Int,Float64}}) = open(f -> printrank(f, R), outfile, "w")
 
 end # module

@@ -141,6 +141,9 @@ def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
         b = np.frombuffer(sq.encode("ascii"), dtype=np.uint8)
         if b.size != len(first):
             raise ValueError("inputs are not aligned")
+        match = np.flatnonzero((b != ord(".")) & ~((b >= ord("a")) & (b <= ord("z"))))
+        if match.size != N or not np.array_equal(match, cols_a):
+            raise ValueError("inconsistent inputs")  # every record has the first record's match columns
         kept = b[cols_a]
         ngaps = int(np.count_nonzero(kept == ord("-")))
         if ngaps / N <= max_gap_fraction:

@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import host_mirrors as hm
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "gaussdca.jl_amd", "libgdca.so")
 
@@ -39,9 +41,64 @@ def test_python_binding_covers_the_header(lib_path):
 
     assert sorted(_lib.SYMBOLS) == _declared_symbols()
     lib = _lib.load()
-    assert lib.gdca_version() == 1
+    assert lib.gdca_version() == 2
     assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 8 + 8 * 9
     assert ctypes.sizeof(_lib.Params) == 24
+
+
+def _c_layout(tmp_path):
+    """sizeof/offsetof as gcc sees include/gdca.h (tests/abi/abi_layout.c)."""
+    exe = tmp_path / "abi_layout"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi", "abi_layout.c"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    lay = {}
+    for line in out.splitlines():
+        st, f, off, size = line.split()
+        lay.setdefault(st, []).append((f, int(off), int(size)))
+    return lay
+
+
+_JL_SIZES = {"Cdouble": 8, "Float64": 8, "UInt64": 8, "Int64": 8, "Int32": 4, "UInt32": 4, "Cint": 4}
+
+
+def _julia_struct(name):
+    """Field list of `struct name ... end` in julia/GaussDCAHip.jl with the offsets Julia's C-compatible
+    layout gives it (natural alignment, declaration order)."""
+    src = open(os.path.join(ROOT, "julia", "GaussDCAHip.jl")).read()
+    body = re.search(r"struct\s+" + name + r"\b(.*?)\n\s*end", src, flags=re.S).group(1)
+    body = re.sub(r"#.*", "", body)
+    fields, off = [], 0
+    for fname, ftype in re.findall(r"(\w+)::(\w+)", body):
+        size = _JL_SIZES[ftype]
+        off = (off + size - 1) // size * size
+        fields.append((fname, off, size))
+        off += size
+    total = (off + 7) // 8 * 8
+    return fields, total
+
+
+def test_struct_layouts_agree_across_c_ctypes_and_julia(tmp_path):
+    """gdca_params / gdca_stats: the compiler's layout == the ctypes mirror == the Julia mirror, field for
+    field; status codes as the Julia `check` and the Python `Context.check` decode them."""
+    from gaussdca.jl_amd import _lib
+
+    lay = _c_layout(tmp_path)
+    for cname, ct, jl in (("gdca_params", _lib.Params, "GdcaParams"), ("gdca_stats", _lib.Stats, "GdcaStats")):
+        rows = lay[cname]
+        assert rows[0][0] == "." and rows[0][2] == ctypes.sizeof(ct)
+        c_fields = rows[1:]
+        py_fields = [(n, getattr(ct, n).offset, getattr(ct, n).size) for n, _ in ct._fields_]
+        assert py_fields == c_fields, cname
+        jl_fields, jl_total = _julia_struct(jl)
+        assert jl_fields == c_fields, jl
+        assert jl_total == rows[0][2]
+    codes = {f: off for f, off, _ in lay["status"]}
+    assert codes == dict(GDCA_OK=_lib.GDCA_OK, GDCA_EINVAL=_lib.GDCA_EINVAL, GDCA_ENOTPD=_lib.GDCA_ENOTPD,
+                         GDCA_EHIP=_lib.GDCA_EHIP, GDCA_ENOMEM=_lib.GDCA_ENOMEM, GDCA_ENOCONV=_lib.GDCA_ENOCONV)
+    jl = open(os.path.join(ROOT, "julia", "GaussDCAHip.jl")).read()
+    for code, exc in ((1, "ArgumentError"), (2, "PosDefException"), (4, "OutOfMemoryError"), (5, r"LinearAlgebra\.LAPACKException")):
+        assert re.search(r"st == %d && throw\(%s" % (code, exc), jl), (code, exc)
 
 
 def test_no_cpu_fallback(lib_path):
@@ -98,11 +155,11 @@ def test_host_fasta_dedup_ranking_match_oracle(refdata, tmp_path):
         Zo = o.read_fasta_alignment(p, mgf)          # (M, N), C order
         assert Z.flags.f_contiguous and Z.dtype == np.int8
         assert np.array_equal(Z.T, Zo)
-        assert np.array_equal(g.read_fasta_alignment_py(p, mgf), Z)
+        assert np.array_equal(hm.read_fasta_alignment_py(p, mgf), Z)
         Zu, idx = g.remove_duplicate_sequences(Z)
         Zou, idxo = o.remove_duplicate_sequences(Zo)
         assert np.array_equal(Zu.T, Zou) and np.array_equal(idx, idxo + 1)
-        Zp, idxp = g.remove_duplicate_sequences_py(Z)
+        Zp, idxp = hm.remove_duplicate_sequences_py(Z)
         assert np.array_equal(Zp, Zu) and np.array_equal(idxp, idx)
     # 102 -> 97 sequences at 0.9 (five all-gap sequences), 94 after dedup
     Zl = g.read_fasta_alignment(os.path.join(refdata, "large.fasta.gz"), 0.9)
@@ -111,10 +168,10 @@ def test_host_fasta_dedup_ranking_match_oracle(refdata, tmp_path):
     # untested-by-the-reference corners, pinned to the restated rules: insert columns ('.' / lowercase) of the
     # first record are dropped, letters BJOUXZ and '*' map to 21, CRLF and wrapped lines, gap filter with '<='
     fa = tmp_path / "odd.fasta"
-    fa.write_bytes(b">s1 first\r\nAC.dE-\r\nGH\r\n>s2\nBJxyOU\nXZ\n>s3\n--.--A\n--\n\n>s4\nacgtac\ngt\n")
+    fa.write_bytes(b">s1 first\r\nAC.dE-\r\nGH\r\n>s2\nBJxyOU\nXZ\n>s3\n--.a-A\n--\n\n>s4\nWY.tAC\nGT\n")
     for mgf in (0.9, 0.5, 0.49):
         Zn = g.read_fasta_alignment(str(fa), mgf)
-        assert np.array_equal(Zn, g.read_fasta_alignment_py(str(fa), mgf))
+        assert np.array_equal(Zn, hm.read_fasta_alignment_py(str(fa), mgf))
         assert np.array_equal(Zn.T, o.read_fasta_alignment(str(fa), mgf))
     Zn = g.read_fasta_alignment(str(fa), 0.9)
     assert Zn.shape[0] == 6 and Zn[:, 0].tolist() == [1, 2, 4, 21, 6, 7] and Zn[:, 1].tolist() == [21] * 6
@@ -124,13 +181,50 @@ def test_host_fasta_dedup_ranking_match_oracle(refdata, tmp_path):
     bad.write_text(">a\nACD\n>b\nAC\n")
     with pytest.raises(ValueError):
         g.read_fasta_alignment(str(bad), 0.9)
+    # "inconsistent inputs": a later record whose match columns (neither '.' nor lowercase) differ from the first
+    # record's -- same length, so only the per-record column check catches it (DCAUtils errors here too)
+    for body in ("AC.dE\nAC.DE\n", "AC.dE\nac.dE\n", "ACDE\nAC.E\n"):
+        a, b = body.split("\n")[:2]
+        inc = tmp_path / "inconsistent.fasta"
+        inc.write_text(">a\n%s\n>b\n%s\n" % (a, b))
+        for reader in (g.read_fasta_alignment, hm.read_fasta_alignment_py, o.read_fasta_alignment):
+            with pytest.raises(ValueError):
+                reader(str(inc), 0.9)
+    ok = tmp_path / "consistent.fasta"
+    ok.write_text(">a\nAC.dE\n>b\nWY.-K\n")   # '.' <-> lowercase may differ between records?  No: position 3 is a match
+    with pytest.raises(ValueError):               # column in b ('-' is neither '.' nor lowercase) but not in a
+        g.read_fasta_alignment(str(ok), 0.9)
+    ok.write_text(">a\nAC.dE\n>b\nWYk.K\n")     # '.' and lowercase are interchangeable in insert columns
+    assert g.read_fasta_alignment(str(ok), 0.9).T.tolist() == [[1, 2, 4], [19, 20, 9]]
+    assert np.array_equal(g.read_fasta_alignment(str(ok), 0.9), hm.read_fasta_alignment_py(str(ok), 0.9))
+
+    # duplicate removal with NON-ADJACENT duplicates, out of place and in place (Z_out aliasing Z): the in-place
+    # compaction must not invalidate the keys of rows it has already kept
+    Zd = np.asfortranarray(np.array([list(b"AABCBCD")], dtype=np.int8).repeat(4, axis=0))   # rows A A B C B C D
+    Zu, idx = g.remove_duplicate_sequences(Zd)
+    assert Zu.shape == (4, 4) and idx.tolist() == [1, 3, 4, 7] and Zu[0].tolist() == list(b"ABCD")
+    lib = g.load()
+    rng2 = np.random.default_rng(11)
+    for trial in range(20):
+        M0, N0 = int(rng2.integers(1, 200)), int(rng2.integers(1, 9))
+        Zr = np.ascontiguousarray(rng2.integers(1, 4, size=(M0, N0)).astype(np.int8))      # many repeats
+        want, keep = o.remove_duplicate_sequences(Zr)
+        for alias in (False, True):
+            src = Zr.copy()
+            dst = src if alias else np.zeros_like(src)
+            m = ctypes.c_int32()
+            kidx = np.zeros(M0, dtype=np.int32)
+            assert lib.gdca_remove_duplicates(src.ctypes.data, N0, M0, dst.ctypes.data, kidx.ctypes.data,
+                                              ctypes.byref(m)) == 0
+            assert m.value == want.shape[0] and np.array_equal(dst[:m.value], want), (trial, alias)
+            assert np.array_equal(kidx[:m.value], keep + 1)
 
     rng = np.random.default_rng(0)
     S = rng.random((30, 30))
     S = S + S.T
     S[3, 20] = S[20, 3] = S[4, 25] = S[25, 4] = 0.123  # an exact tie: generation order must be kept
     for sep in (1, 4, 5, 29, 30, 31):
-        assert g.compute_ranking(S, sep) == o.compute_ranking(S, sep) == g.compute_ranking_py(S, sep)
+        assert g.compute_ranking(S, sep) == o.compute_ranking(S, sep) == hm.compute_ranking_py(S, sep)
     buf = io.StringIO()
     R = [(11, 35, 3.649475), (9, 46, -0.6752293), (1, 2, 1e-300), (3, 4, 123456789.0)]
     g.printrank(buf, R)
@@ -156,7 +250,7 @@ def test_ranking_order_is_julias_isless_reversed():
     S[20:25, 40:48] = 0.5
     S[40:48, 20:25] = 0.5
     R = g.compute_ranking(S, 5)
-    Rp = g.compute_ranking_py(S, 5)
+    Rp = hm.compute_ranking_py(S, 5)
     Ro = o.compute_ranking(S, 5)
     same = lambda x, y: x == y or (x != x and y != y)  # noqa: E731
     assert len(R) == len(Rp) == len(Ro) == (N - 5) * (N - 4) // 2
@@ -171,7 +265,7 @@ def test_ranking_order_is_julias_isless_reversed():
     assert isinstance(R[2:5], list) and R[2:5] == [R[2], R[3], R[4]] == Rp[2:5]      # (NaN != NaN: skip the first two)
     assert R[5] == tuple(R[5]) and len(list(iter(R))) == len(R)
     Rf = g.compute_ranking(np.where(np.isnan(S), 1.0, S), 5)
-    assert Rf == list(Rf) and list(Rf) == g.compute_ranking_py(np.where(np.isnan(S), 1.0, S), 5)
+    assert Rf == list(Rf) and list(Rf) == hm.compute_ranking_py(np.where(np.isnan(S), 1.0, S), 5)
     assert g.compute_ranking(S, N) == [] and len(g.compute_ranking(S, N - 1)) == 1
 
 

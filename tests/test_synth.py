@@ -11,13 +11,14 @@ sys.path.insert(0, ROOT)
 
 from gaussdca.jl_amd import dcautils, synth  # noqa: E402
 from oracle import gdca_oracle as o  # noqa: E402
+import host_mirrors as hm  # noqa: E402
 
 
 @pytest.mark.parametrize("N,M,q,seed", [(53, 100, 21, 1), (128, 3000, 21, 0xB128), (37, 999, 5, 7), (10, 26, 21, 0),
                                         (1, 1, 2, 3), (300, 1500, 21, 2**63 + 5)])
 def test_native_matches_numpy_statement(N, M, q, seed):
     a = synth.synth_family(N, M, q, seed)
-    b = synth.synth_family_py(N, M, q, seed)
+    b = hm.synth_family_py(N, M, q, seed)
     assert a.dtype == np.int8 and a.shape == (M, N)
     assert np.array_equal(a, b)
     assert a.min() >= 1 and a.max() <= q
@@ -54,7 +55,7 @@ def test_fasta_round_trip(tmp_path, suffix):
     Z = synth.synth_family(61, 240, 21, 99)
     path = str(tmp_path / ("fam" + suffix))
     synth.write_fasta(path, Z)
-    for reader in (dcautils.read_fasta_alignment, dcautils.read_fasta_alignment_py, ):
+    for reader in (dcautils.read_fasta_alignment, hm.read_fasta_alignment_py, ):
         back = reader(path, 1.0)                                           # (N, M) Fortran order
         assert back.shape == (61, 240)
         assert np.array_equal(np.ascontiguousarray(back.T), Z)
