@@ -1,18 +1,30 @@
 """bench.py -- the gDCA hot path on MI355X, BASELINE.json's headline configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--score frob|DI] [--N 500 --M 50000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C|B|D|E] [--score frob|DI]
 
 One "step" = one pass of the hot path (src/GaussDCA.jl:28-42 of the reference: reweighting ->
-Pi/Pij -> covariance -> SPD inverse -> FN/DI -> APC) over one synthetic protein family whose
-int8 alignment is already resident in HBM; the N x N score matrix is left in HBM.  With N > 1
-GPUs every rank processes its own independent family per step (weak scaling, no collective on
-the data path; torch.distributed is used only for the timing barrier).
+Pi/Pij -> covariance -> SPD inverse -> FN/DI -> APC) over one batch of synthetic input whose
+int8 alignments are already resident in HBM; the N x N score matrices are left in HBM.
+
+  --config C (default)  one family N=500, M=50k per rank per step          (BASELINE.json configs[2], the headline)
+  --config B / D        one family N=128, M=10k (theta=0.2) / N=1000, M=100k per rank per step
+  --config E            the 256-family Pfam-like batch (N in [100,600], M in [5k,80k]) sharded over the ranks by
+                        the deterministic LPT rule of gaussdca.jl_amd/batch.py; one step = the whole batch once
+                        (strong scaling: the batch is fixed, the ranks split it)
+
+Multi-GPU: the path shards only across independent families -- one process and one gdca context per GPU, no
+collective on the data path; torch.distributed (RCCL) is used for the timing barrier and the max-over-ranks
+clock only.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child
+`python -m torch.distributed.run`, before anything in this process touches a GPU) and exits with the child's code;
+under an external launcher (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line (rank 0).  `value` = families per second over all ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,6 +34,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
+PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_update_traffic.json")
+
+CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
+    "B": dict(N=128, M=10000, theta=0.2, seed=0xB128, ref="BASELINE.json configs[1]"),
+    "C": dict(N=500, M=50000, theta=-1.0, seed=0xC500, ref="BASELINE.json configs[2]"),
+    "D": dict(N=1000, M=100000, theta=-1.0, seed=0xD1000, ref="BASELINE.json configs[3]"),
+    "E": dict(N=None, M=None, theta=-1.0, seed=0xE000, ref="BASELINE.json configs[4]"),
+}
 
 
 def synth_family(N, M, q, seed):
@@ -32,13 +52,31 @@ def synth_family(N, M, q, seed):
     return gen(N, M, q, seed)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/r01_pmc_update_traffic.json: FETCH_SIZE and WRITE_SIZE, separate passes);
-    None when the file is absent or the workload differs from the profiled one."""
+def workload(cfg, args, rank, world):
+    """The families this rank processes per step: list of (family_id, N, M, seed)."""
+    from gaussdca.jl_amd.batch import batch_sizes, shard_families
+
+    c = CONFIGS[cfg]
+    if cfg == "E":
+        sizes = batch_sizes(args.families, c["seed"])
+        mine = shard_families(sizes, world)[rank]
+        return [(f, sizes[f][0], sizes[f][1], c["seed"] + f) for f in mine]
+    N = args.N or c["N"]
+    M = args.M or c["M"]
+    return [(rank, N, M, c["seed"] + rank)]  # weak scaling: every rank its own family of the same size
+
+
+def pmc_traffic(N, M, score):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes, corrected with the factor measured on a copy kernel with the
+    update kernel's load mix: profiles/r02_fetch_calibration.json); None unless the workload is the profiled one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_update_traffic.json")) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+        with open(PROFILED_TRAFFIC) as f:
+            d = json.load(f)
+        w = d.get("workload", {})
+        if (w.get("N"), w.get("M"), w.get("score")) != (N, M, score):
+            return None
+        return float(d["hbm_bytes_per_launch"])
     except Exception:  # noqa: BLE001
         return None
 
@@ -71,13 +109,13 @@ def end_to_end(Zh, q, score_name, pc, ctx):
         os.unlink(path)
 
 
-def cpu_baseline(N, M, q, pc, budget_s=40.0):
-    """The oracle ("port": numpy + OpenMP/AVX2 C loops + OpenBLAS dpotrf/dpotri) timed on all host
-    cores on a bounded sample of the same workload (about `budget_s` seconds of CPU work): the
-    all-pairs Hamming pass on a sequence subsample sized from a probe (cost scaled by the pair
-    count), the tallies on a sequence subsample (cost linear in M), the SPD inverse at the full n
-    when a probe says it fits the budget (else at reduced n, cost scaled by n^3), pseudocount /
-    covariance / FN / APC in full.  Returns an estimate of seconds per family."""
+def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=45.0):
+    """The oracle ("port": numpy + OpenMP/AVX2 C loops + OpenBLAS dpotrf/dpotri) timed on all host cores on the SAME
+    family the GPU was timed on.  A probe (all-pairs pass on 3000 sequences, potrf+potri at n/4) estimates the cost;
+    if the whole family fits the budget it is run IN FULL and every stage second below is measured, not scaled
+    (config C: about 14 s on the GPU box's host).  Otherwise the two super-linear stages are run on a bounded
+    sample and scaled, and the `sample` string says so.  A 1-thread run of the two OpenMP loops on a small sample
+    gives the thread-scaling sanity ratios."""
     import numpy as np
 
     from oracle import gdca_oracle as o
@@ -87,50 +125,112 @@ def cpu_baseline(N, M, q, pc, budget_s=40.0):
     s = q - 1
     n = N * s
     t_all = time.time()
-    Zfull = synth_family(N, M, q, 0xC500)
-    theta = o.compute_theta(Zfull)
-    thr = o.hamming_threshold(theta, N)
-    # Hamming: probe on 3000 sequences, then a sample sized for ~35 % of the budget
+    Z = synth_family(N, M, q, seed)
+    th = o.compute_theta(Z) if theta < 0 else float(theta)
+    thr = o.hamming_threshold(th, N)
+
+    # probes
     Mp = min(M, 3000)
     t = time.time()
-    o.neighbour_counts(Zfull[:Mp], thr)
-    rate = (Mp * (Mp - 1.0) / 2) / max(1e-6, time.time() - t)          # pairs per second
-    Ms = int(min(M, max(Mp, (2 * 0.35 * budget_s * rate) ** 0.5)))
-    t = time.time()
-    n_k = o.neighbour_counts(Zfull[:Ms], thr)
-    t_ham = (time.time() - t) * (M * (M - 1.0)) / (Ms * (Ms - 1.0))
-    W, Meff = o.weights_from_counts(n_k)
-    # tallies: linear in M
-    Mt = min(Ms, 4000)
-    t = time.time()
-    Pi, Pij = o.compute_frequencies(Zfull[:Mt], q, W[:Mt], float(W[:Mt].sum()))
-    t_freq = (time.time() - t) * (M / Mt)
-    t = time.time()
-    Pi2, Pij2 = o.add_pseudocount(Pi, Pij, pc, q)
-    C = o.compute_C(Pi2, Pij2)
-    t_cov = time.time() - t
-    # SPD inverse: probe at n/4, then full size if it fits
+    o.neighbour_counts(Z[:Mp], thr)
+    ham_rate = (Mp * (Mp - 1.0) / 2) / max(1e-6, time.time() - t)  # pairs per second, all threads
+    est_ham = (M * (M - 1.0) / 2) / ham_rate
+    rng = np.random.default_rng(0)
     npb = max(256, n // 4)
+    Bp = rng.standard_normal((npb, 64))
+    Cp = Bp @ Bp.T / 64 + np.eye(npb)
     t = time.time()
-    o.spd_inverse(np.ascontiguousarray(C[:npb, :npb]))
-    est_full = (time.time() - t) * (n / npb) ** 3
-    ns = n if est_full < 0.4 * budget_s else max(npb, int(n * (0.4 * budget_s / est_full) ** (1 / 3)))
-    Cs = np.ascontiguousarray(C[:ns, :ns])
+    o.spd_inverse(Cp)
+    est_inv = (time.time() - t) * (n / npb) ** 3
+    # thread-scaling sanity: the same two loops on one thread
+    Ms = min(M, 1500)
+    o.set_threads(1)
     t = time.time()
-    mJs = o.spd_inverse(Cs)
-    t_inv = (time.time() - t) * (n / ns) ** 3
-    mJ = mJs if ns == n else C  # FN cost does not depend on the values
+    o.neighbour_counts(Z[:Ms], thr)
+    ham_rate_1 = (Ms * (Ms - 1.0) / 2) / max(1e-6, time.time() - t)
+    Mf = min(M, 400)
     t = time.time()
-    o.correct_APC(o.compute_FN(mJ, q))
-    t_fn = time.time() - t
-    est = t_ham + t_freq + t_cov + t_inv + t_fn
-    return dict(value=1.0 / est, unit="families/s", cores=cores, kind="port",
-                sec_per_family_est=est,
-                sample=("oracle (numpy + OpenMP/AVX2 C + OpenBLAS potrf/potri) on %d host threads: Hamming on %d of %d "
-                        "sequences (x pairs ratio), tallies on %d sequences (x M ratio), potrf+potri at n=%d of %d "
-                        "(x n^3 ratio), pseudocount/covariance/FN/APC in full; stage seconds (scaled to the full "
-                        "family) ham=%.2f freq=%.2f cov=%.2f inv=%.2f fn=%.2f; sample wall %.1fs"
-                        % (cores, Ms, M, Mt, ns, n, t_ham, t_freq, t_cov, t_inv, t_fn, time.time() - t_all)))
+    o.compute_frequencies(Z[:Mf], q, np.ones(Mf), float(Mf))
+    freq_1 = (time.time() - t) / Mf
+    o.set_threads(cores)
+    t = time.time()
+    o.compute_frequencies(Z[:Mf], q, np.ones(Mf), float(Mf))
+    freq_all = (time.time() - t) / Mf
+
+    full = est_ham + est_inv + freq_all * M * 1.2 < budget_s
+    stage = {}
+    if full:
+        t = time.time()
+        n_k = o.neighbour_counts(Z, thr)
+        stage["ham"] = time.time() - t
+        W, Meff = o.weights_from_counts(n_k)
+        t = time.time()
+        Pi, Pij = o.compute_frequencies(Z, q, W, Meff)
+        stage["freq"] = time.time() - t
+        t = time.time()
+        Pi2, Pij2 = o.add_pseudocount(Pi, Pij, pc, q)
+        C = o.compute_C(Pi2, Pij2)
+        stage["cov"] = time.time() - t
+        del Pi, Pij, Pij2
+        t = time.time()
+        mJ = o.spd_inverse(C)
+        stage["inv"] = time.time() - t
+        t = time.time()
+        S = o.compute_DI_gauss(mJ, C, q) if score_name == "DI" else o.compute_FN(mJ, q)
+        o.correct_APC(S)
+        stage["score"] = time.time() - t
+        how = "the whole family, every stage measured in full"
+    else:
+        f_h = min(1.0, (0.4 * budget_s / est_ham) ** 0.5)
+        Mh = max(Mp, int(M * f_h))
+        t = time.time()
+        n_k = o.neighbour_counts(Z[:Mh], thr)
+        stage["ham"] = (time.time() - t) * (M * (M - 1.0)) / (Mh * (Mh - 1.0))
+        W, Meff = o.weights_from_counts(n_k)
+        Mt = min(Mh, max(4000, int(0.15 * budget_s / max(freq_all, 1e-9))))
+        t = time.time()
+        Pi, Pij = o.compute_frequencies(Z[:Mt], q, W[:Mt], float(W[:Mt].sum()))
+        stage["freq"] = (time.time() - t) * (M / Mt)
+        t = time.time()
+        Pi2, Pij2 = o.add_pseudocount(Pi, Pij, pc, q)
+        C = o.compute_C(Pi2, Pij2)
+        stage["cov"] = time.time() - t
+        ns = n if est_inv < 0.4 * budget_s else max(npb, int(n * (0.4 * budget_s / est_inv) ** (1 / 3)))
+        t = time.time()
+        mJs = o.spd_inverse(np.ascontiguousarray(C[:ns, :ns]))
+        stage["inv"] = (time.time() - t) * (n / ns) ** 3
+        mJ = mJs if ns == n else C
+        t = time.time()
+        o.correct_APC(o.compute_FN(mJ, q))
+        stage["score"] = time.time() - t
+        how = ("bounded sample, the two super-linear stages SCALED: Hamming on %d of %d sequences (x pair ratio), "
+               "tallies on %d (x M ratio), potrf+potri at n=%d of %d (x n^3 ratio)" % (Mh, M, Mt, ns, n))
+    sec = sum(stage.values())
+    return dict(value=1.0 / sec, unit="families/s", cores=cores, kind="port", measured_in_full=bool(full),
+                sec_per_family=sec, stage_sec={k: round(v, 4) for k, v in stage.items()},
+                thread_scaling={"hamming_pairs_per_s_1_thread": ham_rate_1, "hamming_pairs_per_s_all": ham_rate,
+                                "hamming_speedup": ham_rate / ham_rate_1,
+                                "tally_s_per_seq_1_thread": freq_1, "tally_s_per_seq_all": freq_all,
+                                "tally_speedup": freq_1 / max(freq_all, 1e-12)},
+                sample=("oracle (numpy + OpenMP/AVX2 C + OpenBLAS potrf/potri; NOT the Julia reference, which cannot run "
+                        "here) on %d host threads, N=%d M=%d q=%d score=%s: %s; wall incl. probes %.1fs"
+                        % (cores, N, M, q, score_name, how, time.time() - t_all)))
+
+
+def launch_ranks(n):
+    """`--gpus n` without an external launcher: start the n ranks as a child torch.distributed.run and hand back
+    its exit code.  Called before this process has imported torch or touched a GPU (a process that has initialised
+    the GPU must never replace itself or fork workers)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["GDCA_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -138,32 +238,66 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C", choices=sorted(CONFIGS))
     ap.add_argument("--score", default="frob")
-    ap.add_argument("--N", type=int, default=500)
-    ap.add_argument("--M", type=int, default=50000)
+    ap.add_argument("--N", type=int, default=0, help="override the config's N (configs B, C, D)")
+    ap.add_argument("--M", type=int, default=0)
     ap.add_argument("--q", type=int, default=21)
+    ap.add_argument("--families", type=int, default=256, help="--config E: families in the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: every rank derives its shard, the ranks meet at the (gloo) barrier and rank 0 prints "
+                         "the JSON line with the shards instead of timings (used by the CPU tests of the N > 1 path)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="independent families in flight per GPU (one gdca context each): family f+1's "
-                         "reweighting/tallies (VALU, LDS) overlap family f's SPD inverse (MFMA); 1 = strictly serial "
-                         "(default: clean per-kernel timings; 2 gives +5-10 %% families/s at N=500 and +70 %% at N=128)")
+                         "reweighting/tallies (VALU, LDS) overlap family f's SPD inverse (MFMA); 1 = strictly serial")
     ap.add_argument("--gate", action="store_true",
                     help="with --pipeline > 1: let the SPD-inverse stages of the families in flight take turns")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-
-    import gaussdca.jl_amd as g
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    q = args.q
+    score = 1 if args.score == "DI" else 0
+    pc = 0.2 if score == 1 else 0.8
+    cfg = CONFIGS[args.config]
+    fams = workload(args.config, args, rank, world)
+
+    import numpy as np
+    import torch
+
+    dist = None
+    if args.dry_run:
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            gathered = [None] * world
+            dist.all_gather_object(gathered, [f[0] for f in fams])
+            tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tmax = float(tt.item())
+            dist.destroy_process_group()
+        else:
+            gathered, tmax = [[f[0] for f in fams]], 1.0
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "config": {"workload": args.config},
+                              "shards": gathered, "max_over_ranks": tmax,
+                              "scaling": "strong" if args.config == "E" else "weak"}))
+        return
+
+    import gaussdca.jl_amd as g
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the gDCA hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -176,27 +310,34 @@ def main():
         except Exception:  # noqa: BLE001
             dist.init_process_group("gloo")
 
-    N, M, q = args.N, args.M, args.q
-    score = 1 if args.score == "DI" else 0
-    pc = 0.2 if score == 1 else 0.8
-    Zh = synth_family(N, M, q, 0xC500 + rank)                 # (M, N) == Julia's N x M column-major bytes
-    Zd = torch.from_numpy(Zh).to(dev)                          # resident in HBM before the timed region
+    # synthetic families, resident in HBM before the timed region ((M, N) int8 == Julia's N x M column-major bytes)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        Zh = list(ex.map(lambda f: synth_family(f[1], f[2], q, f[3]), fams))
+    Zd = [torch.from_numpy(z).to(dev) for z in Zh]
+    if args.config == "E":
+        Zh = Zh[:1]
     P = max(1, args.pipeline)
-    Sd = [torch.empty((N, N), dtype=torch.float64, device=dev) for _ in range(P)]  # stay in HBM
+    nmax = max(f[1] for f in fams)
+    Sd = [torch.empty((nmax, nmax), dtype=torch.float64, device=dev) for _ in range(P)]  # stay in HBM
     ctxs = [g.Context(local)]
     for _ in range(P - 1):
         ctxs.append(ctxs[0].peer() if args.gate else g.Context(local))
     busy = [False] * P
 
     def run_steps(count, sink):
-        """`count` hot-path passes, round-robin over the P contexts; a context's previous pass is
-        collected (stream sync + stats) right before it is given the next one."""
-        for sidx in range(count):
-            c = sidx % P
-            if busy[c]:
-                sink.append(ctxs[c].collect())
-            ctxs[c].run_dev_async(Zd.data_ptr(), N, M, q, pc, -1.0, score, Sd[c].data_ptr())
-            busy[c] = True
+        """`count` steps; inside a step the rank's families go round-robin over the P contexts; a context's previous
+        pass is collected (stream sync + stats) right before it is given the next one."""
+        t = 0
+        for _ in range(count):
+            for fi, (_, N, M, _) in enumerate(fams):
+                c = t % P
+                t += 1
+                if busy[c]:
+                    sink.append(ctxs[c].collect())
+                ctxs[c].run_dev_async(Zd[fi].data_ptr(), N, M, q, pc, cfg["theta"], score, Sd[c].data_ptr())
+                busy[c] = True
         for c in range(P):
             if busy[c]:
                 sink.append(ctxs[c].collect())
@@ -209,7 +350,7 @@ def main():
         for c in ctxs:
             c.synchronize()
 
-    warm = max(args.warmup, P)  # every context is warmed (workspace allocation) before the clock starts
+    warm = max(args.warmup, 1)  # every context is warmed (workspace allocation) before the clock starts
     run_steps(warm, [])
     barrier()
     t0 = time.perf_counter()
@@ -217,62 +358,80 @@ def main():
     run_steps(args.steps, stats)
     barrier()
     dt = time.perf_counter() - t0
+    nfam_local = len(fams) * args.steps
+    nfam = nfam_local
+    flops_local = float(sum(s["inverse_flops"] for s in stats))
+    flops = flops_local
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        on = dev if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=on)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        cnt = torch.tensor([float(nfam_local), flops_local], dtype=torch.float64, device=on)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        nfam, flops = int(round(float(cnt[0].item()))), float(cnt[1].item())
 
     if rank == 0:
         K = args.steps
         ms_step = dt / K * 1e3
-        upd_ms = float(np.mean([s["ms_inverse_update"] for s in stats]))
-        upd_launch = stats[-1]["update_launches"]
-        upd_flops = stats[-1]["update_flops"]
-        inv_ms = float(np.mean([s["ms_inverse"] for s in stats]))
+        upd_ms = float(np.sum([s["ms_inverse_update"] for s in stats]))
+        upd_launch = int(np.sum([s["update_launches"] for s in stats]))
+        upd_flops = float(np.sum([s["update_flops"] for s in stats]))
+        inv_ms = float(np.sum([s["ms_inverse"] for s in stats]))
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        N0, M0 = fams[0][1], fams[0][2]
+        if args.config == "E":
+            wl = ("batch of %d synthetic Pfam-like families, N in [100,600], M in [5k,80k], q=%d, score=:%s, "
+                  "theta=:auto, pseudocount=%.1f, LPT-sharded over %d rank(s) (%s)"
+                  % (args.families, q, args.score, pc, world, cfg["ref"]))
+        else:
+            wl = ("synthetic Pfam-like MSA N=%d M=%d q=%d, score=:%s, theta=%s, pseudocount=%.1f (%s)"
+                  % (N0, M0, q, args.score, ":auto" if cfg["theta"] < 0 else repr(cfg["theta"]), pc, cfg["ref"]))
         out = {
             "metric": METRIC,
-            "value": world * K / dt,
+            "value": nfam / dt,
             "unit": "families/s",
             "n_gpus": world,
             "steps": K,
             "warmup": warm,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.config == "E" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic Pfam-like MSA N=%d M=%d q=%d, score=:%s, theta=:auto, pseudocount=%.1f "
-                                   "(BASELINE.json configs[2])" % (N, M, q, args.score, pc),
-                       "N": N, "M": M, "q": q, "n": N * (q - 1), "families_per_step_per_gpu": 1,
+            "config": {"workload": wl, "name": args.config, "q": q,
+                       "families_per_step": nfam // K, "families_per_step_rank0": len(fams),
                        "families_in_flight_per_gpu": P},
-            "sec_per_family": ms_step * 1e-3,
+            "sec_per_family": dt / (nfam / world) if args.config != "E" else dt / nfam,
+            "aggregate_inverse_tflops": flops / dt / 1e12,
             "latency_ms_per_family": float(np.mean([s["ms_total"] for s in stats])),
-            "spd_inverse_tflops": stats[-1]["inverse_flops"] / (inv_ms * 1e-3) / 1e12,
+            "spd_inverse_tflops": float(np.sum([s["inverse_flops"] for s in stats])) / (inv_ms * 1e-3) / 1e12,
             "stage_ms": {k: float(np.mean([s[k] for s in stats])) for k in
                          ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
                           "ms_score")},
-            "theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"],
             "roofline": {
-                "kernel": "k_group_update<false,true>: trailing update of the SPD inverse, f64 MFMA 128x128 tiles, three "
-                          "pivots per launch at this size (K=384; a shorter last group adds one smaller launch)",
+                "kernel": "k_group_update<false,true> (big trailing update of the SPD inverse: f64 MFMA 128x128 tiles, "
+                          "several pivots per launch)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": pmc_traffic(),
-                "launches_per_step": upd_launch,
+                "traffic": pmc_traffic(N0, M0, args.score) if args.config != "E" else None,
+                "launches_per_step": upd_launch / K,
                 "flops_per_launch": upd_flops / max(1, upd_launch),
                 "avg_launch_ms": upd_ms / max(1, upd_launch),
             },
         }
-        if world == 1:
-            out["end_to_end_gdca_sec"] = end_to_end(Zh, q, args.score, pc, ctxs[0])
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config != "E":
+            out["config"].update({"N": N0, "M": M0, "n": N0 * (q - 1)})
+            out.update({"theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"]})
+        if world == 1 and args.config != "E":
+            out["end_to_end_gdca_sec"] = end_to_end(Zh[0], q, args.score, pc, ctxs[0])
+        if world == 1 and not args.no_cpu_baseline and args.config != "E":
             try:
-                out["cpu_baseline"] = cpu_baseline(N, M, q, pc)
+                out["cpu_baseline"] = cpu_baseline(N0, M0, q, pc, cfg["theta"], args.score, fams[0][3])
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}

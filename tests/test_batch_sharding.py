@@ -69,3 +69,53 @@ def test_lpt_balance_and_determinism():
         assert max(loads) / (sum(loads) / world) < 1.05
     with pytest.raises(ValueError):
         shard_families(sizes, 0)
+
+
+def _run_bench(args, timeout=300):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must itself start two ranks: the JSON's n_gpus is 2, the
+    two ranks hold disjoint, complete shards of the batch (config E), the max-over-ranks reduction ran (gloo on CPU
+    for this dry run; the real run uses RCCL for exactly the same two calls)."""
+    from gaussdca.jl_amd.batch import batch_sizes, shard_families
+
+    out = _run_bench(["--gpus", "2", "--dry-run", "--config", "E", "--families", "40"])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["scaling"] == "strong"
+    a, b = out["shards"]
+    assert sorted(a + b) == list(range(40)) and not (set(a) & set(b))
+    assert [a, b] == shard_families(batch_sizes(40), 2)
+    assert out["max_over_ranks"] == 2.0
+    # the headline config: weak scaling, one family per rank, different seeds (family id == rank)
+    out = _run_bench(["--gpus", "2", "--dry-run"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["shards"] == [[0], [1]]
+    out = _run_bench(["--gpus", "1", "--dry-run"])
+    assert out["n_gpus"] == 1 and out["shards"] == [[0]]
+
+
+def test_bench_under_an_external_launcher_is_one_rank():
+    """The driver's form: torch.distributed.run around `bench.py --gpus N`: the ranks come from the launcher's
+    environment, bench.py must not start further processes."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+           "--config", "E", "--families", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and sorted(sum(out["shards"], [])) == list(range(16))

@@ -1,0 +1,319 @@
+"""GPU parity tests at BASELINE.json's own configurations (run with `-m gpu` on the MI355X box), all through the
+C-ABI (libgdca.so via ctypes) against the CPU oracle:
+
+  B  N=128,  M=10k,  theta=0.2, :frob              full oracle comparison
+  C  N=500,  M=50k,  theta=:auto, :frob AND :DI    full oracle comparison at the headline size (one oracle pass)
+  D  N=1000, M=100k, :frob                         properties that need no full CPU inverse
+  E  16 families of the 256-family batch through `gdca_cli --batch`, byte-equal to the single-family path
+
+Bars (north_star): Hamming counts / thresholds / identity sums / ranking indices bit-exact, FN / DI scores within
+1e-6 relative.  Tolerances are written at each assert.  Seeds are SURVEY.md 8d's (0xB128, 0xC500, 0xD1000, 0xE000+f).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gdca_testutil import score_close
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gaussdca.jl_amd", "gdca_cli")
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gaussdca.jl_amd as g
+
+    assert os.path.exists(g._lib.LIB_PATH), "libgdca.so missing: the GPU tests never fall back to the CPU"
+    assert g.load().gdca_device_count() > 0, "no HIP device"
+    return g
+
+
+@pytest.fixture(scope="module")
+def ctx(g):
+    c = g.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def o():
+    from oracle import gdca_oracle as o
+
+    o.set_threads(os.cpu_count() or 1)
+    return o
+
+
+def _synth(N, M, seed):
+    from gaussdca.jl_amd import synth
+
+    return synth.synth_family(N, M, 21, seed)
+
+
+def _top_order_equal(g, o, S, S_o, top=200):
+    R, R_o = g.compute_ranking(S, 5), o.compute_ranking(S_o, 5)
+    return [t[:2] for t in R[:top]] == [t[:2] for t in R_o[:top]]
+
+
+# ---- B -------------------------------------------------------------------------------------------------------------
+def test_config_B_full_oracle_comparison(g, ctx, o):
+    """BASELINE.json configs[1]: N=128, M=10k, q=21, :frob, theta=0.2 (fixed), pseudocount 0.8; 2560 x 2560 covariance
+    (20 pivot blocks: the single-pivot look-ahead schedule)."""
+    N, M, q, theta, pc = 128, 10000, 21, 0.2, 0.8
+    Zo = _synth(N, M, 0xB128)
+    Z = np.asfortranarray(Zo.T)
+    W_o, Meff_o, th_o, thr_o = o.compute_weights(Zo, theta)
+    assert thr_o == 25
+    assert np.array_equal(g.neighbour_counts(Z, thr_o, ctx=ctx), o.neighbour_counts(Zo, thr_o))   # bit-exact
+    S, st = ctx.run(Z, q, pc, theta, 0)
+    assert st["theta"] == theta and st["thresh"] == thr_o and st["Meff"] == Meff_o and st["info"] == 0
+    S_o = o.scores_from_Z(Zo, q, pc, theta, "frob")
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
+    assert ok, (max_rel, max_abs)
+    assert np.array_equal(S, S.T)
+    R, R_o = g.compute_ranking(S, 5), o.compute_ranking(S_o, 5)
+    assert [t[:2] for t in R] == [t[:2] for t in R_o] or _top_order_equal(g, o, S, S_o, 500)
+    # the statement-by-statement device-resident chain gives the same bits as the fused call
+    from gaussdca.jl_amd import devops
+
+    S2, info = devops.scores_stepwise(Z, q, pc, theta, "frob", ctx=ctx)
+    assert np.array_equal(S2, S) and info["Meff"] == Meff_o and info["thresh"] == thr_o
+
+
+# ---- C: the headline configuration, compared with the oracle at its own size -----------------------------------------
+@pytest.fixture(scope="module")
+def headline(o):
+    """One oracle pass over the headline family shared by the :frob and :DI comparisons (they differ only from the
+    pseudocount on): theta, threshold, neighbour counts, W, Meff, Pi_true, Pij_true."""
+    N, M, q = 500, 50000, 21
+    Zo = _synth(N, M, 0xC500)
+    theta = o.compute_theta(Zo)
+    thr = o.hamming_threshold(theta, N)
+    n_k = o.neighbour_counts(Zo, thr)
+    W, Meff = o.weights_from_counts(n_k)
+    Pi_t, Pij_t = o.compute_frequencies(Zo, q, W, Meff)
+    return dict(N=N, M=M, q=q, Zo=Zo, theta=theta, thr=thr, n_k=n_k, W=W, Meff=Meff, Pi_t=Pi_t, Pij_t=Pij_t,
+                pair_sum=o.pair_identity_sum(Zo))
+
+
+def test_config_C_integers_bit_exact_at_full_size(g, ctx, headline):
+    h = headline
+    Z = np.asfortranarray(h["Zo"].T)
+    assert g.pair_identity_sum(Z, ctx=ctx) == h["pair_sum"]
+    assert np.array_equal(g.neighbour_counts(Z, h["thr"], ctx=ctx), h["n_k"])        # all 50 000 counts, bit-exact
+    W, Meff, th, thr = g.compute_weights(Z, h["q"], "auto", ctx=ctx, return_theta=True)
+    assert th == h["theta"] and thr == h["thr"] and Meff == h["Meff"] and np.array_equal(W, h["W"])
+
+
+@pytest.mark.parametrize("score,pc", [("frob", 0.8), ("DI", 0.2)])
+def test_config_C_scores_match_oracle_at_full_size(g, ctx, o, headline, score, pc):
+    """BASELINE.json configs[2], both scores: N=500, M=50k, theta=:auto; 10 000 x 10 000 covariance, 79 pivot
+    blocks (groups of three pivots, K=384 trailing updates): S within 1e-6 relative of the oracle's (LAPACK
+    potrf+potri inverse), top-200 contact order identical."""
+    h = headline
+    N, q = h["N"], h["q"]
+    Z = np.asfortranarray(h["Zo"].T)
+    S, st = ctx.run(Z, q, pc, -1.0, 1 if score == "DI" else 0)
+    assert st["theta"] == h["theta"] and st["thresh"] == h["thr"] and st["Meff"] == h["Meff"] and st["info"] == 0
+    assert st["pair_identity_sum"] == h["pair_sum"]
+    Pi, Pij = o.add_pseudocount(h["Pi_t"], h["Pij_t"], pc, q)
+    C = o.compute_C(Pi, Pij)
+    del Pij
+    mJ = o.spd_inverse(C)
+    S_o = o.compute_DI_gauss(mJ, C, q) if score == "DI" else o.compute_FN(mJ, q)
+    S_o = o.correct_APC(S_o)
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
+    assert ok, (score, max_rel, max_abs)
+    assert _top_order_equal(g, o, S, S_o, 200)
+    assert np.array_equal(S, S.T)
+
+
+# ---- D -------------------------------------------------------------------------------------------------------------
+def test_config_D_properties_at_full_size(g, ctx, o):
+    """BASELINE.json configs[3]: N=1000, M=100k, q=21, :frob, theta=:auto: n = 20 000 (157 pivot blocks: groups of four
+    pivots).  A full CPU potrf+potri at this size is out of a test's budget, so the device results are checked
+    through the arrays of the statement-by-statement (`_dev`) pipeline, which must give the same bits as the fused
+    call:
+      - theta / threshold from the closed form, 32 sampled neighbour counts by brute force (bit-exact)
+      - 24 sampled 20 x 20 blocks of the device covariance against the oracle's formula for those site pairs
+      - C X v == v on random probes with the device's own C and X = mJ
+      - the oracle's compute_FN + correct_APC applied to the DEVICE mJ against the device scores."""
+    from gaussdca.jl_amd import devops
+
+    N, M, q, pc = 1000, 100000, 21, 0.8
+    s, n = q - 1, N * (q - 1)
+    Zo = _synth(N, M, 0xD1000)
+    Z = np.asfortranarray(Zo.T)
+    S, st = ctx.run(Z, q, pc, -1.0, 0)
+    assert st["info"] == 0 and np.isfinite(S).all() and np.array_equal(S, S.T) and st["n"] == n
+    tot = o.pair_identity_sum(Zo)
+    theta = min(0.5, 0.38 * 0.32 / (tot / (N * (0.5 * M * (M - 1)))))
+    assert st["pair_identity_sum"] == tot and st["theta"] == theta and st["thresh"] == int(np.floor(theta * N))
+    thr = st["thresh"]
+
+    n_gpu = g.neighbour_counts(Z, thr, ctx=ctx)
+    rng = np.random.default_rng(0xD)
+    for k in rng.choice(M, size=32, replace=False):
+        d = np.count_nonzero(Zo != Zo[k], axis=1)
+        assert n_gpu[k] == int(np.count_nonzero(d < thr))                   # includes k itself (d = 0): bit-exact
+    W = 1.0 / n_gpu
+    Meff = float(np.cumsum(W)[-1])
+    assert st["Meff"] == Meff
+
+    # the device-resident statement chain, keeping C and mJ
+    dZ = g.DeviceBuffer.from_array(ctx, Z)
+    dW, Meff_d, th_d, thr_d = devops.compute_weights_dev(ctx, dZ, N, M, "auto")
+    assert (Meff_d, th_d, thr_d) == (Meff, theta, thr)
+    dPi, dPij = devops.compute_weighted_frequencies_dev(ctx, dZ, N, M, q, dW, Meff_d)
+    Pi_true = dPi.download((n,))
+    devops.add_pseudocount_dev(ctx, dPi, dPij, N, q, pc)
+    Pi_pc = dPi.download((n,))
+    devops.compute_C_dev(ctx, dPi, dPij, n, dC=dPij)
+    C_dev = dPij.download((n, n))
+    assert np.array_equal(C_dev, C_dev.T)
+
+    # sampled covariance blocks against the oracle's formula (rules 5-7 of SURVEY 4.3) for those site pairs
+    Pi_o = np.zeros(n)
+    for i in rng.choice(N, size=8, replace=False):
+        a = Zo[:, i].astype(np.int64)
+        m = a < q
+        Pi_o[i * s:(i + 1) * s] = np.bincount(a[m] - 1, weights=W[m], minlength=s) / Meff
+        assert np.max(np.abs(Pi_true[i * s:(i + 1) * s] - Pi_o[i * s:(i + 1) * s])) <= 1e-12
+    assert np.max(np.abs(Pi_pc - ((1.0 - pc) * Pi_true + pc / q))) == 0.0     # elementwise, contraction off: exact
+    cmax = np.max(np.abs(C_dev))
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, N, size=(20, 2))] + [(int(i), int(i)) for i in
+                                                                                 rng.integers(0, N, size=4)]
+    for i, j in pairs:
+        a, b = Zo[:, i].astype(np.int64), Zo[:, j].astype(np.int64)
+        m = (a < q) & (b < q)
+        blk = np.bincount((a[m] - 1) * s + (b[m] - 1), weights=W[m], minlength=s * s).reshape(s, s) / Meff
+        if i == j:
+            blk = (1.0 - pc) * blk + (pc / q) * np.eye(s)
+        else:
+            blk = (1.0 - pc) * blk + pc / q / q
+        blk = blk - np.outer(Pi_pc[i * s:(i + 1) * s], Pi_pc[j * s:(j + 1) * s])
+        got = C_dev[i * s:(i + 1) * s, j * s:(j + 1) * s]
+        assert np.max(np.abs(got - blk)) <= 1e-12 * cmax, (i, j)            # fixed-point tallies vs f64 sums
+
+    devops.inv_cholesky_dev(ctx, dPij, n)
+    mJ_dev = dPij.download((n, n))
+    assert np.array_equal(mJ_dev, mJ_dev.T)
+    V = rng.standard_normal((n, 6))
+    Rv = C_dev @ (mJ_dev @ V) - V
+    assert np.max(np.abs(Rv)) <= 1e-8 * np.max(np.abs(V))                    # cond(C) ~ 1e4
+    del C_dev
+
+    dS = devops.compute_FN_dev(ctx, dPij, N, q)
+    devops.correct_APC_dev(ctx, dS, N)
+    S_step = dS.download((N, N))
+    assert np.array_equal(S_step, S)                                         # chain == fused call, bit for bit
+    S_o = o.correct_APC(o.compute_FN(mJ_dev, q))                             # oracle scores from the device's mJ
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-9, atol_frac=1e-12)
+    assert ok, (max_rel, max_abs)
+    for b in (dZ, dW, dPi, dPij, dS):
+        b.free()
+    R = g.compute_ranking(S, 5)
+    assert len(R) == (N - 5) * (N - 4) // 2 and all(R[t][2] >= R[t + 1][2] for t in range(len(R) - 1))
+
+
+# ---- E -------------------------------------------------------------------------------------------------------------
+def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
+    """BASELINE.json configs[4]: 16 families of the 256-family batch (every 16th, at their real sizes N in [134, 507],
+    M in [8k, 78k]) written as FASTA files and run through `gdca_cli --batch` (parser threads -> queue -> one worker
+    per GPU context -> writer threads).  Every ranking file must be byte-identical to the single-family path
+    (gDCA(file) + printrank through the Python mirror of the same C-ABI)."""
+    from gaussdca.jl_amd import synth
+    from gaussdca.jl_amd.batch import batch_sizes
+
+    sizes = batch_sizes(256)
+    fams = list(range(0, 256, 16))
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    for f in fams:
+        N, M = sizes[f]
+        synth.write_fasta(str(indir / ("fam%03d.fasta" % f)), synth.synth_family(N, M, 21, 0xE000 + f))
+    r = subprocess.run([CLI, "--batch", str(indir), "--out", str(outdir), "--parsers", "4"], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "16 families" in r.stderr and "(0 failed)" in r.stderr
+    want = tmp_path / "want.txt"
+    for f in fams:
+        N, M = sizes[f]
+        R = g.gDCA(str(indir / ("fam%03d.fasta" % f)), ctx=ctx)
+        st = g.gdca.last_stats
+        assert (st["N"], st["M"]) == (N, M) and st["info"] == 0
+        g.printrank(str(want), R)
+        got = (outdir / ("fam%03d.rank.txt" % f)).read_bytes()
+        assert got == want.read_bytes(), f
+
+
+# ---- boundary behaviour added with the device-resident operators ----------------------------------------------------
+def test_out_of_range_symbols_and_weights_are_rejected(g, ctx):
+    """A byte of Z outside 1..q (q < max(Z), 0, negative) gives ArgumentError (GDCA_EINVAL) from every entry that
+    consumes Z instead of a silently inconsistent covariance; caller-given weights must lie in [0, 1]."""
+    rng = np.random.default_rng(3)
+    Z = np.asfortranarray(rng.integers(1, 22, size=(40, 300)).astype(np.int8))
+    S, st = ctx.run(Z, 21, 0.8, 0.3, 0)                    # fine
+    with pytest.raises(g.ArgumentError):
+        ctx.run(Z, 20, 0.8, 0.3, 0)                        # q smaller than the largest symbol
+    for bad in (0, -3, 33):
+        Zb = Z.copy(order="F")
+        Zb[7, 123] = bad
+        with pytest.raises(g.ArgumentError):
+            ctx.run(Zb, 21, 0.8, 0.3, 0)
+        with pytest.raises(g.ArgumentError):
+            g.compute_weights(Zb, 21, 0.3, ctx=ctx)
+        with pytest.raises(g.ArgumentError):
+            g.compute_weighted_frequencies(Zb, np.full(300, 0.5), 150.0, ctx=ctx)
+    Zo = np.asfortranarray(rng.integers(1, 22, size=(37, 300)).astype(np.int8))   # N not a multiple of 4: slow pack path
+    Zo[36, 299] = 0
+    with pytest.raises(g.ArgumentError):
+        g.neighbour_counts(Zo, 5, ctx=ctx)
+    for w in (1.5, -0.1, np.nan):
+        W = np.full(300, 0.5)
+        W[17] = w
+        with pytest.raises(g.ArgumentError):
+            g.compute_weighted_frequencies(Z, W, 150.0, ctx=ctx)
+    S2, _ = ctx.run(Z, 21, 0.8, 0.3, 0)                    # the context is still usable and deterministic
+    assert np.array_equal(S, S2)
+
+
+def test_second_async_run_before_collect_is_an_error(g, ctx):
+    import torch
+
+    Zo = _synth(40, 300, 5)
+    Zd = torch.from_numpy(Zo).cuda()
+    S = torch.empty((40, 40), dtype=torch.float64, device="cuda")
+    c = g.Context(0)
+    c.run_dev_async(Zd.data_ptr(), 40, 300, 21, 0.8, -1.0, 0, S.data_ptr())
+    with pytest.raises(g.ArgumentError):
+        c.run_dev_async(Zd.data_ptr(), 40, 300, 21, 0.8, -1.0, 0, S.data_ptr())   # one run outstanding per ctx
+    st = c.collect()
+    assert st["info"] == 0
+    c.run_dev_async(Zd.data_ptr(), 40, 300, 21, 0.0, -1.0, 0, S.data_ptr())       # pc = 0: singular covariance
+    with pytest.raises(g.PosDefException):
+        c.collect()                                                                 # the status reaches the caller
+    c.close()
+
+
+@pytest.mark.parametrize("score", ["frob", "DI"])
+def test_device_resident_chain_equals_fused_run(g, ctx, o, score):
+    """The reference's six statements (src/GaussDCA.jl:28-42) through the `_dev` operators, arrays in gdca_dbuf
+    buffers, give the same bits as gdca_run and match the oracle."""
+    from gaussdca.jl_amd import devops
+
+    pc = 0.2 if score == "DI" else 0.8
+    for (N, M, q) in ((75, 900, 21), (33, 400, 5), (130, 2000, 21)):
+        Zo = _synth(N, M, 77 + N) if q == 21 else np.ascontiguousarray(
+            np.random.default_rng(N).integers(1, q + 1, size=(M, N)).astype(np.int8))
+        Z = np.asfortranarray(Zo.T)
+        S, st = ctx.run(Z, q, pc, -1.0, 1 if score == "DI" else 0)
+        S2, info = devops.scores_stepwise(Z, q, pc, "auto", score, ctx=ctx)
+        assert np.array_equal(S, S2), (N, M, q)
+        assert info["Meff"] == st["Meff"] and info["thresh"] == st["thresh"] and info["theta"] == st["theta"]
+        S_o = o.scores_from_Z(Zo, q, pc, "auto", score)
+        ok, max_rel, _ = score_close(S2, S_o, rtol=1e-6, atol_frac=1e-9)
+        assert ok, max_rel

@@ -20,9 +20,8 @@ def env():
     ctx.close()
 
 
-@settings(max_examples=15, derandomize=True, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=250, derandomize=True, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), M=st.integers(2, 300), N=st.integers(3, 40),  # N = 2: APC cancels the only score to 0/0
-      
        q=st.sampled_from([3, 5, 21, 24]), theta=st.one_of(st.just("auto"), st.floats(0.0, 0.6)),
        pc=st.floats(0.05, 1.0), score=st.sampled_from(["frob", "DI"]))
 def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
