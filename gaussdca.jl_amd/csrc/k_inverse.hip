@@ -30,116 +30,262 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define LDS_LD (T + 16)  // f64 elements per k-row in LDS (128-byte pad)
 
 // -------------------------------------------------------------------------------------------------
-// Pivot: P = inverse of the 128 x 128 SPD block at (k0, k0) by a scalar symmetric sweep on its
-// LOWER TRIANGLE held in registers: 528 threads (9 waves, spread over the 4 SIMDs) each own one
-// 4 x 4 patch (pr >= pc) of the 32 x 32 patch grid.  Per pivot j the column j of the symmetric
-// block (rows >= j from column j, rows < j from row j) and p = 1/d are broadcast through LDS
-// (double-buffered: one barrier per pivot), then every element is one FMA:
-//       D[r][c] <- D[r][c] - u[r] * w[c],   u = g,  w = g * p,
-// with the pivot row/column handled by the vectors alone (u[j] = -1, w[j] = -p, old row/column j
-// zeroed):  row j -> g[c] p,  column j -> g[r] p,  (j,j) -> -p.  The j loop is unrolled by 4 so
-// every register index is static.  1/d is v_rcp_f64 + two Newton steps (the pivot is a positive,
-// normal number; the full IEEE division sequence would sit on the critical path of every step).
-// Writes P (full symmetric) and A_KK <- -P (full tile).  A non-positive pivot (the same test dpotrf
-// makes) is reported through sc->info.
+// Pivot: P = inverse of a 128 x 128 SPD block by a BLOCKED symmetric sweep, one workgroup, the block's lower
+// triangle resident in MFMA accumulators for the whole kernel.
+//
+// The block is cut into 8 x 8 micro-blocks of 16 x 16; the 36 lower-triangular tiles live in the accumulators of
+// 12 waves (3 tiles each; waves 0..7 own one diagonal tile and two others).  Sweeping micro-block K
+//       D_ij <- D_ij - G_i Pm G_j^T   (i, j != K),   D_iK <- G_i Pm,   D_KK <- -Pm,      G = D_{.,K},  Pm = D_KK^-1
+// is, for EVERY tile, four v_mfma_f64_16x16x4_f64 on two operand images in LDS:
+//       Gs = the old column block K (128 x 16), with the rows of micro-block K replaced by -I
+//       Ns = -(G Pm)               (128 x 16), with the rows of micro-block K replaced by +Pm
+//       tile(rb, cb) <- [rb == K or cb == K ? 0 : tile] + Gs[rb] Ns[cb]^T
+// (the same -1 / -p device the scalar sweep uses for its pivot row and column), so the three kinds of tiles need
+// no special code.  The only serial part is Pm = (16 x 16 diagonal tile)^-1: a 16-step scalar sweep inside ONE
+// wave's registers (the tile is already there in accumulator layout; the pivot column travels by cross-lane
+// shuffles, no LDS round trip, no barrier), and it runs one micro-block AHEAD: in the update phase of micro-block
+// K the owner of tile (K+1, K+1) updates that tile first and inverts it at once, beside the other waves' MFMAs.
+// Per micro-block: three barriers, 12 MFMAs per wave -- 24 barrier-separated phases for the whole block instead
+// of the 128 of the element-wise sweep (measured 84 us there).
+//
+// Operand images are [kk][row] with a swizzled row offset (pv_off): the MFMA operand reads (16 consecutive rows of
+// two adjacent kk per 32 lanes) and the transposed stores of the tiles left of the diagonal (16 different kk, one
+// row) are both (nearly) conflict-free.
+// 1/d is v_rcp_f64 + two Newton steps.  A non-positive pivot (the same test dpotrf makes) is reported through
+// sc->info.  Writes P (full symmetric, ld = pld) and A_KK <- -P (full tile).
 // -------------------------------------------------------------------------------------------------
-#define PB 4                      // patch edge
-#define PGRID (T / PB)            // 32 patches per side
-#define PIVOT_THREADS 576         // >= PGRID * (PGRID + 1) / 2 = 528, multiple of 64
-__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ A, size_t ld, int k0,
-                                                          double *__restrict__ P, gdca_dev_scalars *sc, int n_real)
-{
-    __shared__ __attribute__((aligned(16))) double g[2][T];
-    __shared__ double pinv[2];
-    __shared__ int badj;
-    const int tid = threadIdx.x;
-    if (tid == 0) badj = 0;
-    const bool active = tid < PGRID * (PGRID + 1) / 2;
-    int pr = 0, pc = 0;
-    if (active) {
-        pr = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
-        while (pr * (pr + 1) / 2 > tid) --pr;
-        while ((pr + 1) * (pr + 2) / 2 <= tid) ++pr;
-        pc = tid - pr * (pr + 1) / 2;
-    }
-    const int r0 = pr * PB, c0 = pc * PB;
-    double *Akk = A + (size_t)k0 + (size_t)k0 * ld;
-    double D[PB][PB];
-#pragma unroll
-    for (int b = 0; b < PB; ++b)
-#pragma unroll
-        for (int a = 0; a < PB; ++a) {
-            const int r = r0 + a, c = c0 + b;
-            const int rr = r >= c ? r : c, cc = r >= c ? c : r;  // lower triangle is authoritative
-            D[a][b] = active ? Akk[(size_t)rr + (size_t)cc * ld] : 0.0;
-        }
-    __syncthreads();
+#define MB 16                      // micro-block edge
+#define NMB (T / MB)               // micro-blocks per side
+#define PIVOT_THREADS 768          // 12 waves
+#define PV_ROW 160                 // doubles per kk-row of an operand image
 
-    for (int jb = 0; jb < PGRID; ++jb) {
-        const bool inrow = active && (pr == jb);  // my patch holds rows of the pivot quad
-        const bool incol = active && (pc == jb);  // my patch holds columns of the pivot quad
+__device__ __forceinline__ int pv_off(int kk)
+{
+    return kk * PV_ROW + 16 * (kk & 1) + 2 * (kk >> 1);
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Broadcast, inside every row of 16 lanes, the value lane J of that row holds (DPP row_newbcast: VALU speed, no LDS).
+template <int J>
+__device__ __forceinline__ double row_bcast_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int L>
+__device__ __forceinline__ double read_lane_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), L);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), L);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// One step of the 16 x 16 sweep on v[reg] = D[i = lane & 15][j = (lane >> 4) + 4 reg] (full storage).  The pivot
+// column reaches lane (i, .) by one cross-row shuffle (ds_bpermute, address colsrc[JJ & 3] = lane (JJ & 3) * 16 + i),
+// the pivot row's entries D[JJ][j] by DPP broadcasts inside the lane's own row of 16, the pivot itself by v_readlane.
+template <int JJ>
+struct MicroStep {
+    static __device__ __forceinline__ void run(double (&v)[4], int l15, int lq, const int (&colsrc)[4], int index_base,
+                                               int *badj)
+    {
+        const double col = v[JJ >> 2];
+        const double ui = shfl_f64(col, colsrc[JJ & 3]);
+        const double d = read_lane_f64<(JJ & 3) * 16 + JJ>(col);
+        if (!(d > 0.0) && *badj == 0) *badj = index_base + JJ + 1;
+        double p = __builtin_amdgcn_rcp(d);
+        p = fma(p, fma(-d, p, 1.0), p);
+        p = fma(p, fma(-d, p, 1.0), p);
+        const double u = (l15 == JJ) ? -1.0 : ui;
 #pragma unroll
-        for (int jj = 0; jj < PB; ++jj) {
-            const int par = jj & 1;
-            if (incol) {
-#pragma unroll
-                for (int a = 0; a < PB; ++a)
-                    if (pr > jb || a >= jj) g[par][r0 + a] = D[a][jj];  // (r, j), r >= j
-            }
-            if (inrow) {
-#pragma unroll
-                for (int b = 0; b < PB; ++b)
-                    if (pc < jb || b < jj) g[par][c0 + b] = D[jj][b];   // (j, c), c < j
-            }
-            if (inrow && incol) {
-                const double d = D[jj][jj];
-                double rp = __builtin_amdgcn_rcp(d);
-                rp = fma(rp, fma(-d, rp, 1.0), rp);
-                rp = fma(rp, fma(-d, rp, 1.0), rp);
-                pinv[par] = rp;
-                if (!(d > 0.0) && badj == 0) badj = jb * PB + jj + 1;
-            }
-            __syncthreads();
-            const double p = pinv[par];
-            double u[PB], w[PB];
-#pragma unroll
-            for (int a = 0; a < PB; ++a) u[a] = g[par][r0 + a];
-#pragma unroll
-            for (int b = 0; b < PB; ++b) w[b] = g[par][c0 + b] * p;
-            // branch-free specials (selects, not predicated moves: keeps one live copy of D)
-            u[jj] = inrow ? -1.0 : u[jj];
-            w[jj] = incol ? -p : w[jj];
-#pragma unroll
-            for (int b = 0; b < PB; ++b) D[jj][b] = inrow ? 0.0 : D[jj][b];
-#pragma unroll
-            for (int a = 0; a < PB; ++a) D[a][jj] = incol ? 0.0 : D[a][jj];
-#pragma unroll
-            for (int a = 0; a < PB; ++a)
-#pragma unroll
-                for (int b = 0; b < PB; ++b) D[a][b] = fma(-u[a], w[b], D[a][b]);
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = lq + 4 * reg;
+            const double uj = row_bcast_f64<JJ>(v[reg]);  // D[JJ][j]
+            const double w = (j == JJ) ? -p : uj * p;
+            const double base = (l15 == JJ || j == JJ) ? 0.0 : v[reg];
+            v[reg] = fma(-u, w, base);
         }
+        if constexpr (JJ + 1 < MB) MicroStep<JJ + 1>::run(v, l15, lq, colsrc, index_base, badj);
     }
-    // D = -inverse (lower triangle valid).  P = -D;  A_KK = D, both written as full symmetric tiles
-    if (active) {
+};
+
+// Inverse of the 16 x 16 SPD tile held by one wave as v[reg] = D[i = lane & 15][j = (lane >> 4) + 4 reg] (lower
+// triangle authoritative): on return v = -D^-1 (full storage, equal to its transpose up to rounding).
+__device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_base, int *badj)
+{
+    const int l15 = lane & 15, lq = lane >> 4;
+    {
+        // upper triangle := mirror of the lower: element (j, i) sits in lane (i & 3) * 16 + j, register i >> 2
+        double s[4];
 #pragma unroll
-        for (int b = 0; b < PB; ++b)
+        for (int reg = 0; reg < 4; ++reg) s[reg] = v[reg];
 #pragma unroll
-            for (int a = 0; a < PB; ++a) {
-                const int r = r0 + a, c = c0 + b;
-                if (r >= c) {
-                    const double v = D[a][b];
-                    P[(size_t)r + (size_t)c * T] = -v;
-                    Akk[(size_t)r + (size_t)c * ld] = v;
-                    if (r > c) {
-                        P[(size_t)c + (size_t)r * T] = -v;
-                        Akk[(size_t)c + (size_t)r * ld] = v;
-                    }
+        for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double cand = shfl_f64(v[r2], (l15 & 3) * 16 + lq + 4 * reg);
+                if ((l15 >> 2) == r2) s[reg] = cand;
+            }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            if (l15 < lq + 4 * reg) v[reg] = s[reg];
+    }
+    int colsrc[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) colsrc[h] = h * 16 + l15;
+    MicroStep<0>::run(v, l15, lq, colsrc, index_base, badj);
+}
+
+__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Akk, size_t ld, double *__restrict__ P,
+                                                          size_t pld, gdca_dev_scalars *sc, int index0, int n_real)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];  // -Pm of micro-block K in Pms[K & 1]
+    __shared__ int badj;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) badj = 0;
+
+    // tile ownership: waves 0..7: (w, w) + off-diagonal tiles 2w, 2w+1; waves 8..11: off-diagonal tiles 16 + 3 (w-8) + {0,1,2}
+    // (off-diagonal tile e <-> (rb, cb), rb > cb, e = rb (rb-1) / 2 + cb)
+    int trb[3], tcb[3];
+    auto offdiag = [](int e, int &rb, int &cb) {
+        int r = 1;
+        while ((r + 1) * r / 2 <= e) ++r;
+        rb = r;
+        cb = e - r * (r - 1) / 2;
+    };
+    if (wv < NMB) {
+        trb[0] = tcb[0] = wv;
+        offdiag(2 * wv, trb[1], tcb[1]);
+        offdiag(2 * wv + 1, trb[2], tcb[2]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) offdiag(16 + 3 * (wv - NMB) + t, trb[t], tcb[t]);
+    }
+
+    // load: acc[t][reg] = D[16 rb + l15][16 cb + lq + 4 reg]; diagonal tiles mirror their lower triangle
+    double acc[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
+            if (r < c) {
+                const int x = r;
+                r = c;
+                c = x;
+            }
+            acc[t][reg] = Akk[(size_t)r + (size_t)c * ld];
+        }
+    __syncthreads();  // badj initialised
+    if (wv == 0) {
+        // Pm of micro-block 0 (no update precedes it)
+        double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+        micro_pivot(v, lane, 0, &badj);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Pms[0][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
+    }
+
+#pragma unroll 1
+    for (int K = 0; K < NMB; ++K) {
+        // ---- phase A: the old column block K into Gs ([kk][row]); rows of micro-block K of both images ----
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (tcb[t] == K && trb[t] > K) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Gs[pv_off(lq + 4 * reg) + MB * trb[t] + l15] = acc[t][reg];
+            } else if (trb[t] == K && tcb[t] < K) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Gs[pv_off(l15) + MB * tcb[t] + lq + 4 * reg] = acc[t][reg];
+            }
+        }
+        __syncthreads();  // Gs complete; Pms[K & 1] (written in the previous update phase) visible
+        // ---- phase B: Ns = -(G Pm) for the row blocks != K (waves 0..7, one row block each); specials by waves 8, 9 ----
+        if (wv < NMB && wv != K) {
+            double4_t g = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int kk = 4 * t4 + lq;
+                const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
+                const double a = Pms[K & 1][lo][hi];                       // -Pm(l15, kk), lower triangle authoritative
+                const double b = Gs[pv_off(kk) + MB * wv + l15];           // G(16 wv + l15, kk)
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, g, 0, 0, 0);
+            }
+            // lane holds -(G Pm)(16 wv + l15, lq + 4 reg)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ns[pv_off(lq + 4 * reg) + MB * wv + l15] = g[reg];
+        } else if (wv == NMB) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                Gs[pv_off(lq + 4 * reg) + MB * K + l15] = (l15 == lq + 4 * reg) ? -1.0 : 0.0;
+        } else if (wv == NMB + 1) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int kk = lq + 4 * reg;
+                const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
+                Ns[pv_off(kk) + MB * K + l15] = -Pms[K & 1][lo][hi];       // +Pm(l15, kk)
+            }
+        }
+        __syncthreads();
+        // ---- phase C: every tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T ----
+        auto update_tile = [&](int t) {
+            double4_t c4;
+            const bool fresh = trb[t] == K || tcb[t] == K;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) c4[reg] = fresh ? 0.0 : acc[t][reg];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int kk = 4 * t4 + lq;
+                const double a = Ns[pv_off(kk) + MB * tcb[t] + l15];
+                const double b = Gs[pv_off(kk) + MB * trb[t] + l15];
+                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[t][reg] = c4[reg];
+        };
+        update_tile(0);
+        if (K + 1 < NMB && wv == K + 1) {
+            // look-ahead: the next micro-pivot, beside the other waves' updates
+            double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+            micro_pivot(v, lane, MB * (K + 1), &badj);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];
+        }
+        update_tile(1);
+        update_tile(2);
+        __syncthreads();
+    }
+
+    // D = -inverse (lower-triangular tiles).  P = -D and A_KK = D, both as full symmetric matrices
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
+            if (r >= c) {
+                const double v = acc[t][reg];
+                P[(size_t)r + (size_t)c * pld] = -v;
+                Akk[(size_t)r + (size_t)c * ld] = v;
+                if (r > c) {
+                    P[(size_t)c + (size_t)r * pld] = -v;
+                    Akk[(size_t)c + (size_t)r * ld] = v;
                 }
             }
-    }
-    __syncthreads();
-    if (tid == 0 && badj != 0 && (k0 + badj) <= n_real) {
-        if (sc->info == 0) sc->info = k0 + badj;
+        }
+    if (tid == 0 && badj != 0 && (index0 + badj) <= n_real) {
+        if (sc->info == 0) sc->info = index0 + badj;
     }
 }
 
@@ -685,7 +831,8 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
                                H2, ld, wb_col, wbH, col2, ns1);
     };
     auto pivot = [&](int k) {
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A, ld, k * T, ws.P, sc, n_real);
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A + (size_t)k * T + (size_t)k * T * ld, ld, ws.P, (size_t)T,
+                           sc, k * T, n_real);
     };
     auto panel = [&](int k, double *G, double *H) {
         hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, G, H, ld);

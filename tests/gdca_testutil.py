@@ -61,8 +61,8 @@ def compare_with_golden(R, golden_path):
     return rep
 
 
-def score_close(S, S_ref, rtol=1e-6, atol_frac=1e-9):
-    """Elementwise |S - S_ref| <= rtol |S_ref| + atol_frac max|S_ref| on the off-diagonal.
+def score_close(S, S_ref, rtol=1e-6, atol_frac=1e-9, atol_abs=0.0):
+    """Elementwise |S - S_ref| <= rtol |S_ref| + atol_frac max|S_ref| + atol_abs on the off-diagonal.
 
     rtol = 1e-6 is north_star's bar for FN/DI scores; the small absolute term only covers
     APC-corrected scores that cross zero (their relative error is unbounded by construction).
@@ -73,7 +73,7 @@ def score_close(S, S_ref, rtol=1e-6, atol_frac=1e-9):
     # magnitude reference: all entries, diagonal included (the APC-corrected diagonal is -S_i.^2 / Sa, i.e. the
     # size of the raw scores; with few sequences every off-diagonal entry can cancel to rounding noise)
     scale = np.max(np.abs(S_ref))
-    ok = bool(np.all(np.abs(a - b) <= rtol * np.abs(b) + atol_frac * scale))
+    ok = bool(np.all(np.abs(a - b) <= rtol * np.abs(b) + atol_frac * scale + atol_abs))
     big = np.abs(b) > 1e-3 * scale
     max_rel = float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big]))) if np.any(big) else 0.0
     return ok, max_rel, float(np.max(np.abs(a - b)))

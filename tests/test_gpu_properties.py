@@ -53,5 +53,9 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
         # O(1) inverse-covariance entries they were computed from
         assert np.max(np.abs(S)) < 1e-10
         return
-    ok, max_rel, _ = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)
-    assert ok, max_rel
+    # DI = s/2 log(1/2) + 1/2 sum_k log(1 + sqrt(1 + 4 gamma_k)) is a difference of O(s) quantities: with a pseudocount
+    # near 1 the couplings vanish, the scores drop to ~1e-10 and BOTH implementations (and DCAUtils, which evaluates the
+    # same expression) carry s * 2^-53-sized rounding noise in them; that floor is not a parity error
+    atol_abs = 4.0 * (q - 1) * 2.0 ** -53 * 16 if score == "DI" else 0.0
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9, atol_abs=atol_abs)
+    assert ok, (max_rel, max_abs)

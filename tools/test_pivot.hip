@@ -1,0 +1,110 @@
+// Stand-alone check of k_pivot (csrc/k_inverse.hip) against a host Gauss-Jordan inverse, for several leading
+// dimensions and block positions.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -I gaussdca.jl_amd/csrc tools/test_pivot.hip
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "../gaussdca.jl_amd/csrc/k_inverse.hip"
+
+static void host_inverse(const std::vector<double> &A, std::vector<double> &X, int n)
+{
+    std::vector<long double> M((size_t)n * 2 * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            M[(size_t)i * 2 * n + j] = A[(size_t)i + (size_t)j * n];
+            M[(size_t)i * 2 * n + n + j] = i == j;
+        }
+    for (int k = 0; k < n; ++k) {
+        const long double p = 1.0L / M[(size_t)k * 2 * n + k];
+        for (int j = 0; j < 2 * n; ++j) M[(size_t)k * 2 * n + j] *= p;
+        for (int i = 0; i < n; ++i)
+            if (i != k) {
+                const long double f = M[(size_t)i * 2 * n + k];
+                for (int j = 0; j < 2 * n; ++j) M[(size_t)i * 2 * n + j] -= f * M[(size_t)k * 2 * n + j];
+            }
+    }
+    X.resize((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) X[(size_t)i + (size_t)j * n] = (double)M[(size_t)i * 2 * n + n + j];
+}
+
+int main()
+{
+    const int n = 128;
+    std::mt19937_64 rng(1);
+    std::normal_distribution<double> nd;
+    std::vector<double> B((size_t)n * 300), A0((size_t)n * n), Xr;
+    for (auto &x : B) x = nd(rng);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0;
+            for (int k = 0; k < 300; ++k) s += B[(size_t)i * 300 + k] * B[(size_t)j * 300 + k];
+            A0[(size_t)i + (size_t)j * n] = s / 300 + (i == j ? 0.3 : 0.0);
+        }
+    host_inverse(A0, Xr, n);
+    double xmax = 0;
+    for (double x : Xr) xmax = std::fmax(xmax, std::fabs(x));
+    gdca_dev_scalars *sc;
+    hipMalloc(&sc, sizeof(*sc));
+    for (int ld : {128, 256, 384})
+        for (int k = 0; k * 128 + 128 <= ld; ++k) {
+            std::vector<double> A((size_t)ld * ld, 7.0), P((size_t)n * n, -3.0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= i; ++j) A[(size_t)(k * n + i) + (size_t)(k * n + j) * ld] = A0[(size_t)i + (size_t)j * n];  // lower only
+            double *dA, *dP;
+            hipMalloc(&dA, A.size() * 8);
+            hipMalloc(&dP, P.size() * 8);
+            hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+            hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice);
+            hipMemset(sc, 0, sizeof(*sc));
+            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA + (size_t)k * n + (size_t)k * n * ld, (size_t)ld, dP,
+                               (size_t)n, sc, k * n, ld);
+            hipError_t e = hipDeviceSynchronize();
+            gdca_dev_scalars h;
+            hipMemcpy(&h, sc, sizeof(h), hipMemcpyDeviceToHost);
+            hipMemcpy(A.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
+            hipMemcpy(P.data(), dP, P.size() * 8, hipMemcpyDeviceToHost);
+            double eA = 0, eP = 0, outside = 0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    eA = std::fmax(eA, std::fabs(-A[(size_t)(k * n + i) + (size_t)(k * n + j) * ld] - Xr[(size_t)i + (size_t)j * n]));
+                    eP = std::fmax(eP, std::fabs(P[(size_t)i + (size_t)j * n] - Xr[(size_t)i + (size_t)j * n]));
+                }
+            for (int i = 0; i < ld; ++i)
+                for (int j = 0; j < ld; ++j)
+                    if (i / n != k || j / n != k) outside = std::fmax(outside, std::fabs(A[(size_t)i + (size_t)j * ld] - 7.0));
+            printf("ld %d k %d: err %s info %d  relerr Akk %.2e  P %.2e  touched outside %.1e\n", ld, k, hipGetErrorString(e), h.info,
+                   eA / xmax, eP / xmax, outside);
+            hipFree(dA);
+            hipFree(dP);
+        }
+    {
+        // not positive definite: leading minor 38 fails; and the launch time on an idle chip
+        std::vector<double> A(A0);
+        A[37 + 37 * (size_t)n] = -1.0;
+        double *dA, *dP;
+        hipMalloc(&dA, A.size() * 8);
+        hipMalloc(&dP, A.size() * 8);
+        hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+        hipMemset(sc, 0, sizeof(*sc));
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA, (size_t)n, dP, (size_t)n, sc, 256, 100000);
+        gdca_dev_scalars h;
+        hipMemcpy(&h, sc, sizeof(h), hipMemcpyDeviceToHost);
+        printf("non-PD at local index 38, index0 256: info %d (want 294)\n", h.info);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < 50; ++it)  // the block is overwritten by -inverse: values stay finite under repetition? use fresh copies
+                hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA, (size_t)n, dP, (size_t)n, sc, 0, 0);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("k_pivot: %.1f us per launch (50 back-to-back launches, idle chip)\n", ms * 1000 / 50);
+        }
+    }
+    return 0;
+}
