@@ -32,8 +32,8 @@ struct gdca_ctx {
     bool timing;
     char err[512];
     // named device buffers (grow-only)
-    gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, G2, H2, P, Dblk, Ld, Tws, colsum, sc;
-    hipStream_t side;          // look-ahead stream of the SPD inverse
+    gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
+    hipStream_t side;          // side stream of the SPD inverse: the big trailing updates
     bool lookahead;
     hipEvent_t sev[MAX_EV];    // cross-stream ordering events
     int n_sev;
@@ -127,23 +127,26 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     ctx->lookahead = getenv("GDCA_NO_LOOKAHEAD") == nullptr;
-    // The side stream carries the big trailing updates of the SPD inverse.  Its CU mask leaves ONE compute unit
-    // out, so the single-workgroup pivot kernel of the look-ahead chain (main stream) always finds an idle CU
-    // instead of waiting for register space beside two 256-VGPR update workgroups (0.4 % of the chip for a
-    // pivot that runs at its stand-alone speed).  GDCA_RESERVE_CU=0 turns it off.
+    // The side stream carries the big trailing updates of the SPD inverse.  Its CU mask leaves a few compute units out, so the small, latency-bound kernels of the pivot chain on
+    // the main stream (the single-workgroup pivot, the tile jobs on a group's diagonal super-block) always find idle CUs
+    // instead of waiting for a register-hungry update workgroup to retire.  A workgroup is bound to an XCD round-robin at
+    // dispatch and then looks for a CU with room INSIDE that XCD, so every XCD needs its own idle CU: the reserved set is
+    // one CU per XCD (measured: a small high-priority kernel beside a chip-filling one starts in 7.5 us with it, 15-45 us
+    // without, tools/ubench_cumap.hip).  Mask bit i is XCD i % 8, shader engine (i / 8) % 4, CU i / 32 of that engine
+    // (measured, same tool).  GDCA_RESERVE_CU=k reserves k CUs per XCD (default 1; 0 = no mask).
     ctx->side = nullptr;
-    if (!(getenv("GDCA_RESERVE_CU") && atoi(getenv("GDCA_RESERVE_CU")) == 0)) {
+    const int reserve = getenv("GDCA_RESERVE_CU") ? atoi(getenv("GDCA_RESERVE_CU")) : 1;
+    if (reserve > 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount >= 64) {
-            const int ncu = prop.multiProcessorCount;
-            uint32_t mask[16];
-            const int words = (ncu + 31) / 32;
-            for (int w = 0; w < words && w < 16; ++w) {
-                const int bits = ncu - 32 * w >= 32 ? 32 : ncu - 32 * w;
-                mask[w] = bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
-            }
-            mask[0] &= ~1u;
-            if (hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask) != hipSuccess) {
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount == 256) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) mask[w] = 0xFFFFFFFFu;
+            for (int r = 0; r < reserve && r < 16; ++r)
+                for (int x = 0; x < 8; ++x) {
+                    const int bit = 8 * r + x;  // k-th CU of XCD x: shader engines first (bits 8 r + x, r = 0 .. 3), then CU 1 ...
+                    mask[bit / 32] &= ~(1u << (bit % 32));
+                }
+            if (hipExtStreamCreateWithCUMask(&ctx->side, 8, mask) != hipSuccess) {
                 (void)hipGetLastError();
                 ctx->side = nullptr;
             }
@@ -212,7 +215,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
-                        &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->G2, &ctx->H2, &ctx->P, &ctx->Dblk, &ctx->Ld,
+                        &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
                         &ctx->Tws, &ctx->colsum, &ctx->sc};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -362,27 +365,27 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
 {
     hipStream_t s = ctx->stream;
     const size_t pbytes = (size_t)n_pad * GDCA_TILE * sizeof(double);
-    CHK(ensure(ctx, ctx->G, pbytes));
-    CHK(ensure(ctx, ctx->H, pbytes));
-    CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
     const int nblk = n_pad / GDCA_TILE;
     const bool la = ctx->lookahead && nblk >= 3;
+    // 2 x 4 panels G and H (pivot groups of up to four blocks, double-buffered by group parity; without look-ahead one
+    // set), one 128 x 128 pivot inverse, three 512 x 512 scratch matrices for a group's diagonal super-block
+    const int npan = la ? 8 : 4;
+    const size_t sg = (size_t)4 * GDCA_TILE * 4 * GDCA_TILE * sizeof(double);
+    CHK(ensure(ctx, ctx->G, (size_t)npan * pbytes));
+    CHK(ensure(ctx, ctx->H, (size_t)npan * pbytes));
+    CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
+    CHK(ensure(ctx, ctx->Sg, 3 * sg + (size_t)2 * nblk * sizeof(unsigned)));
     gdca_inverse_ws ws;
-    ws.G[0] = ws.G[1] = (double *)ctx->G.p;
-    ws.H[0] = ws.H[1] = (double *)ctx->H.p;
-    for (int w = 2; w < 8; ++w) ws.G[w] = ws.H[w] = nullptr;
-    ws.P = (double *)ctx->P.p;
-    if (la) {
-        // eight G and eight H panels carved from two buffers
-        const int npan = 8;  // 2 x 4 panels: pivot groups of up to four, double-buffered by group parity (pairs use 2 x 2)
-        CHK(ensure(ctx, ctx->G2, (size_t)(npan - 1) * pbytes));
-        CHK(ensure(ctx, ctx->H2, (size_t)(npan - 1) * pbytes));
-        for (int w = 1; w < npan; ++w) {
-            ws.G[w] = (double *)((char *)ctx->G2.p + (size_t)(w - 1) * pbytes);
-            ws.H[w] = (double *)((char *)ctx->H2.p + (size_t)(w - 1) * pbytes);
-        }
-        CHK(need_sync_events(ctx, 2 * nblk));
+    for (int w = 0; w < 8; ++w) {
+        ws.G[w] = (double *)((char *)ctx->G.p + (size_t)(w % npan) * pbytes);
+        ws.H[w] = (double *)((char *)ctx->H.p + (size_t)(w % npan) * pbytes);
     }
+    ws.P = (double *)ctx->P.p;
+    ws.Sg[0] = (double *)ctx->Sg.p;
+    ws.Sg[1] = (double *)((char *)ctx->Sg.p + sg);
+    ws.Pg = (double *)((char *)ctx->Sg.p + 2 * sg);
+    ws.cnt = (unsigned *)((char *)ctx->Sg.p + 3 * sg);
+    if (la) CHK(need_sync_events(ctx, 2 * nblk));
     hipEvent_t *uev = nullptr;
     int max_ev = 0;
     if (timed) {
@@ -390,8 +393,8 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
         uev = ctx->ev + 16;
         max_ev = ctx->n_ev - 16;
     }
-    gdca_launch_spd_inverse(s, la ? ctx->side : nullptr, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n,
-                            ctx->sev, uev, max_ev, n_upd, upd_flops);
+    gdca_launch_spd_inverse(s, la ? ctx->side : nullptr, (double *)ctx->A.p, n_pad, ws,
+                            (gdca_dev_scalars *)ctx->sc.p, n, ctx->sev, uev, max_ev, n_upd, upd_flops);
     return check_launch(ctx, "spd_inverse");
 }
 

@@ -83,18 +83,18 @@ void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int
 
 // ---- k_inverse.hip -------------------------------------------------------------------------
 struct gdca_inverse_ws {
-    double *G[8];  // n_pad x 128 panels (column k of the swept matrix): [0], [1] double-buffered by step parity for
-                   // the single-pivot look-ahead; [2 (p & 1) + {0, 1}] = the two panels of pivot pair p; [4 (p & 1) + w] =
-                   // panel w of pivot group p (G[2] / G[4] may be nullptr: no pair / group schedule)
-    double *H[8];  // n_pad x 128 panels, -G * P
-    double *P;     // 128 x 128 inverse of the pivot block
+    double *G[8];   // n_pad x 128 panels: [4 (p & 1) + w] = column block w of pivot group p (double-buffered by group parity)
+    double *H[8];   // n_pad x 128 panels, -G * Pg
+    double *P;      // 128 x 128 inverse of one pivot block
+    double *Sg[2];  // 512 x 512 dense scratch copies of a group's diagonal super-block (ping-pong)
+    double *Pg;     // 512 x 512: inverse of the group's diagonal super-block
+    unsigned *cnt;  // 2 counters per pivot group: ticks of the head workgroups of the group's update launch
 };
 // In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles
 // authoritative): A <- -inverse(A) by the block symmetric sweep.  info (device) gets the
 // 1-based index of the first non-positive pivot, if any.
 // s1 == nullptr: serial schedule on s0.  Otherwise look-ahead over two streams; sync_ev must hold
-// 2 * (n_pad / 128) events.  upd_ev (optional, 2 per big update launch) are recorded on the stream
-// the launch runs on.
+// 2 * (n_pad / 128) events.  upd_ev (optional, 2 per update launch) are recorded on the stream the launch runs on.
 void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
                              gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev,
                              int max_upd_ev, int *n_upd_launch, double *upd_flops);

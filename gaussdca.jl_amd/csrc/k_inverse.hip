@@ -1,16 +1,17 @@
 // Dense SPD inverse  mJ = inv(cholesky(C))  (reference call site src/GaussDCA.jl:34; there:
 // LAPACK dpotrf + dpotri, n^3 flops).
 //
-// MI355X design: a BLOCK SYMMETRIC SWEEP (block Gauss-Jordan on an SPD matrix) with 128-wide
-// pivots.  For pivot block K with D = A_KK (the Schur complement at that point -- the same
-// matrix Cholesky would factor, so the positive-definiteness test and the `info` index are the
-// same as dpotrf's), P = D^-1, G = A_{.,K}:
+// MI355X design: a BLOCK SYMMETRIC SWEEP (block Gauss-Jordan on an SPD matrix).  For a pivot block (group) K with
+// D = A_KK (the Schur complement at that point -- the same matrix Cholesky would factor, so the
+// positive-definiteness test and the `info` index are the same as dpotrf's), P = D^-1, G = A_{.,K}:
 //       A_ij <- A_ij - G_i P G_j^T   (i, j != K),   A_{.,K} <- G P,   A_KK <- -P.
-// After all pivots A = -C^-1.  Same n^3 flop count as dpotrf+dpotri, but every step is ONE
-// launch of ~(n/128)^2/2 identical 128x128x128 tile products over the whole lower triangle:
-// no shrinking trailing matrix, no trtri/lauum dependency chains, no tail of tiny launches --
-// the shape a 256-CU chip wants.  The matrix stays symmetric throughout, only the lower
-// triangle (with full diagonal tiles) is touched.
+// After all pivots A = -C^-1.  Same n^3 flop count as dpotrf+dpotri, but every step is ONE launch of
+// ~(n/128)^2/2 identical 128x128 tile products over the whole lower triangle: no shrinking trailing matrix, no
+// trtri/lauum dependency chains, no tail of tiny launches -- the shape a 256-CU chip wants.  The matrix stays
+// symmetric throughout, only the lower triangle (with full diagonal tiles) is touched.  Pivots are taken in groups
+// of up to four 128-blocks (one update launch of depth K = 128 g per group); the serial part of a group -- the
+// inverse of its 128 g x 128 g diagonal super-block -- runs on a small dense scratch copy while the bulk of the
+// look-ahead work proceeds beside it (see the driver at the end of this file).
 //
 // Tile product: 256 threads = 4 waves in 2 x 2, each wave a 64 x 64 sub-tile as 4 x 4
 // v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  The f64 C/D fragment is
@@ -52,7 +53,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // two adjacent kk per 32 lanes) and the transposed stores of the tiles left of the diagonal (16 different kk, one
 // row) are both (nearly) conflict-free.
 // 1/d is v_rcp_f64 + two Newton steps.  A non-positive pivot (the same test dpotrf makes) is reported through
-// sc->info.  Writes P (full symmetric, ld = pld) and A_KK <- -P (full tile).
+// sc->info.  Writes P (full symmetric, ld = pld) and -P (full tile) to the output tile.
 // -------------------------------------------------------------------------------------------------
 #define MB 16                      // micro-block edge
 #define NMB (T / MB)               // micro-blocks per side
@@ -146,8 +147,10 @@ __device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_
     MicroStep<0>::run(v, l15, lq, colsrc, index_base, badj);
 }
 
-__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Akk, size_t ld, double *__restrict__ P,
-                                                          size_t pld, gdca_dev_scalars *sc, int index0, int n_real)
+// Ain (ld = ldin) is read, Aout (ld = ldout) receives -P; the two may be the same tile.
+__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout,
+                                                          double *__restrict__ P, size_t pld, gdca_dev_scalars *sc, int index0,
+                                                          int n_real)
 {
     __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
     __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
@@ -187,19 +190,16 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Ak
                 r = c;
                 c = x;
             }
-            acc[t][reg] = Akk[(size_t)r + (size_t)c * ld];
+            acc[t][reg] = Ain[(size_t)r + (size_t)c * ldin];
         }
     __syncthreads();  // badj initialised
-    if (wv == 0) {
-        // Pm of micro-block 0 (no update precedes it)
-        double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
-        micro_pivot(v, lane, 0, &badj);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Pms[0][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
-    }
 
+    // K = -1 is the prologue: only the micro-pivot of micro-block 0 (no update precedes it); the same code as the
+    // look-ahead micro-pivots of the loop, so that the kernel carries ONE copy of the unrolled 16-step sweep (the pivot
+    // is launched once per block with other kernels in between: its instructions are fetched cold every time)
 #pragma unroll 1
-    for (int K = 0; K < NMB; ++K) {
+    for (int K = -1; K < NMB; ++K) {
+      if (K >= 0) {
         // ---- phase A: the old column block K into Gs ([kk][row]); rows of micro-block K of both images ----
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Ak
             }
         }
         __syncthreads();
+      }
         // ---- phase C: every tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T ----
         auto update_tile = [&](int t) {
             double4_t c4;
@@ -255,17 +256,19 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Ak
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) acc[t][reg] = c4[reg];
         };
-        update_tile(0);
+        if (K >= 0) update_tile(0);
         if (K + 1 < NMB && wv == K + 1) {
             // look-ahead: the next micro-pivot, beside the other waves' updates
             double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
             micro_pivot(v, lane, MB * (K + 1), &badj);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];
+            for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
         }
-        update_tile(1);
-        update_tile(2);
-        __syncthreads();
+        if (K >= 0) {
+            update_tile(1);
+            update_tile(2);
+            __syncthreads();
+        }
     }
 
     // D = -inverse (lower-triangular tiles).  P = -D and A_KK = D, both as full symmetric matrices
@@ -277,10 +280,10 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(double *__restrict__ Ak
             if (r >= c) {
                 const double v = acc[t][reg];
                 P[(size_t)r + (size_t)c * pld] = -v;
-                Akk[(size_t)r + (size_t)c * ld] = v;
+                Aout[(size_t)r + (size_t)c * ldout] = v;
                 if (r > c) {
                     P[(size_t)c + (size_t)r * pld] = -v;
-                    Akk[(size_t)c + (size_t)r * ld] = v;
+                    Aout[(size_t)c + (size_t)r * ldout] = v;
                 }
             }
         }
@@ -457,9 +460,9 @@ __device__ __forceinline__ void cpiece_add(double4_t (&acc)[4][4], const double 
         for (int reg = 0; reg < 4; ++reg) acc[tm][2 * (CI % 2) + h][reg] += cp[h * 4 + reg];
 }
 
-// DUAL: two pivots fused in one pass -- the k loop runs over (G, H) of the first pivot (these unrolled chunks,
-// which also bring in the C tile) and then over (G2, H2) of the second (a plain rolled loop in the kernel), K = 256:
-// the C tile is read and written once per TWO rank-128 updates.
+// DUAL: more pivots follow in the same pass -- the k loop runs over (G, H) of the first pivot (these unrolled chunks,
+// which also bring in the C tile) and then over the panels of the other pivots of the group (a plain rolled loop in the
+// kernel): the C tile is read and written once per group of rank-128 updates.
 // The operand chunks are double-buffered in LDS (chunk c in buffer c & 1): while chunk c is multiplied, chunk c+1
 // goes registers -> LDS (after the first quarter of the MFMAs, so its global loads have had more than a chunk to
 // land) and chunk c+2's global loads are issued; ONE barrier per chunk.
@@ -493,51 +496,6 @@ struct UpdateChunks {
             cpiece_add<CI>(acc, cp);
     }
 };
-
-// Panel: for every row block i != k:  G_i = column block k of the symmetric matrix (read from the
-// lower triangle: A[i,k] for i > k, A[k,i]^T for i < k);  GP = G_i P;  writes
-//   Gbuf[i] = G_i,  Hbuf[i] = -GP,  and the new column block  A[i,k] = GP  (A[k,i] = GP^T for i < k).
-// Two workgroups per row block (64 columns of GP each): the panel sits on the critical path of the
-// look-ahead chain, so it is cut finer than the throughput-bound update.
-__global__ __launch_bounds__(256, 2) void k_panel(double *__restrict__ A, size_t ld, int kblk,
-                                                   const double *__restrict__ P, double *__restrict__ Gbuf,
-                                                   double *__restrict__ Hbuf, size_t pld)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
-    int i = blockIdx.x;
-    if (i >= kblk) ++i;  // skip the pivot block itself
-    const int ch = blockIdx.y;  // which 64-column half of GP
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double4_t acc[2][4];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    double *gcopy = (ch == 0) ? Gbuf + (size_t)i * T : nullptr;
-    const double *hsrc = P + (size_t)ch * 64;  // rows (= columns, P symmetric) ch*64 .. ch*64+63 of P
-    if (i > kblk) {
-        const double *gsrc = A + (size_t)i * T + (size_t)kblk * T * ld;
-        tile_product<false, 2>(acc, gsrc, ld, hsrc, T, Gs, Hs, gcopy, pld);
-    } else {
-        const double *gsrc = A + (size_t)kblk * T + (size_t)i * T * ld;
-        tile_product<true, 2>(acc, gsrc, ld, hsrc, T, Gs, Hs, gcopy, pld);
-    }
-    // acc[tm][tn][reg] = GP(r, c):  r = wr*64 + tn*16 + l15,  c = ch*64 + wc*32 + tm*16 + lq + 4*reg
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                const double v = acc[tm][tn][reg];
-                Hbuf[(size_t)i * T + r + (size_t)c * pld] = -v;
-            }
-}
 
 // Write-back of the new column block: A[i,k] = G_i P = -H_i  (A[k,i] = (G_i P)^T for i < k).  Not done by
 // the panel kernel because the two panel workgroups of a row block both read the OLD A[i,k] as their G
@@ -581,214 +539,317 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
     }
 }
 
-__global__ __launch_bounds__(256) void k_panel_writeback(double *__restrict__ A, size_t ld, int kblk,
-                                                          const double *__restrict__ Hbuf, size_t pld)
-{
-    __shared__ __attribute__((aligned(16))) double Ts[KC][LDS_LD];
-    int i = blockIdx.x;
-    if (i >= kblk) ++i;
-    panel_writeback_tile(A, ld, kblk, i, Hbuf, pld, Ts);
-}
-
-// Update: lower-triangle tiles  A_IJ += G_I H_J^T (+ G2_I H2_J^T when G2 != nullptr),  H = -G P, in one of two tile
-// sets; blocks in the contiguous range [skip_lo, skip_lo + skip_n) never take part:
-//   colblk <  0 : every tile (I >= J) over the remaining blocks
-//   SLICE       : the tiles that involve block `colblk` as row or column (nslice1 = nblk - skip_n of them) and,
-//                 when colblk2 >= 0, those that involve colblk2 = skip_lo + skip_n + 1 (nslice - nslice1 more) --
-//                 look-ahead slices; workgroups past nslice do the write-back of the pivot column block wb_col
-//                 from wbH (see panel_writeback_tile) when wb_col >= 0.
-// SLICE is a template parameter so that the big trailing-update launches are their own kernel symbol
-// (k_sweep_update<DUAL, false>): profiler summaries then report them apart from the small look-ahead launches.
-template <bool DUAL, bool SLICE>
-__global__ __launch_bounds__(256, 2) void k_sweep_update(double *__restrict__ A, size_t ld, int skip_lo, int skip_n,
-                                                          int colblk, int nslice, const double *__restrict__ Gbuf,
-                                                          const double *__restrict__ Hbuf,
-                                                          const double *__restrict__ G2buf,
-                                                          const double *__restrict__ H2buf, size_t pld, int wb_col,
-                                                          const double *__restrict__ wbH, int colblk2, int nslice1)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
-    const int t = blockIdx.x;
-    int I, J;
-    if constexpr (SLICE) {
-        if (t >= nslice) {
-            int b = t - nslice;
-            if (b >= wb_col) ++b;
-            panel_writeback_tile(A, ld, wb_col, b, wbH, pld, Gs[0]);
-            return;
-        }
-    }
-    if constexpr (SLICE) {
-        // tiles [0, nslice1) involve block colblk; tiles [nslice1, nslice) involve block colblk2, whose skip range
-        // is one longer (it also leaves out colblk = skip_lo + skip_n: that tile belongs to the first set)
-        const bool second = t >= nslice1;
-        int b = second ? t - nslice1 : t;
-        if (b >= skip_lo) b += skip_n + (second ? 1 : 0);
-        const int cb = second ? colblk2 : colblk;
-        I = b > cb ? b : cb;
-        J = b > cb ? cb : b;
-    } else {
-        int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((long long)ii * (ii + 1) / 2 > t) --ii;
-        while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
-        int jj = t - (int)((long long)ii * (ii + 1) / 2);
-        if (ii >= skip_lo) ii += skip_n;
-        if (jj >= skip_lo) jj += skip_n;
-        I = ii;
-        J = jj;
-    }
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double *At = A + (size_t)I * T + (size_t)J * T * ld;
-    double4_t acc[4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    {
-        StageRegs<4> R;
-        double cp[8];
-        const double *g1 = Gbuf + (size_t)I * T, *h1 = Hbuf + (size_t)J * T;
-        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
-        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
-        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
-        __syncthreads();
-        if constexpr (DUAL) {
-            const double *g2 = G2buf + (size_t)I * T, *h2 = H2buf + (size_t)J * T;
-            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
-            // second pivot of the pair: chunk c of it is chunk 8 + c of the pass (buffer c & 1); on entry chunk 0 is
-            // in LDS buffer 0 and chunk 1 in R
-#pragma unroll 1
-            for (int c = 0; c < T / KC; ++c) {
-                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                if (c + 1 < T / KC) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
-                if (c + 2 < T / KC) stage_load<false, 4>(R, g2, pld, h2, pld, (c + 2) * KC, tid);
-                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                __syncthreads();
-            }
-        } else {
-            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
-            }
-}
-
-// ---- groups of up to four pivots per trailing update ----------------------------------------------------------------
-// Generalisation of the pair kernel above for large matrices: one launch applies the rank-128 updates of nop <= 4
-// pivots (K = 128 nop) -- the C tile is read and written once per nop updates and a workgroup's launch / first-chunk /
-// store-drain overhead is paid once per nop times the work.  Big mode: every tile outside [skip_lo, skip_lo + skip_n).
-// Slice mode: the tiles that involve one of up to four column blocks col[m], the other index running over all blocks
-// outside that column's own contiguous skip range [cskip_lo[m], cskip_lo[m] + cskip_n[m]) (first[m] .. first[m+1]-1
-// are column m's tiles); workgroups from first[ncol] on write pivot column wb_col back from wbH.
+// ---- trailing update: up to four pivots per launch -------------------------------------------------------------
+// One launch applies the rank-128 updates of the nop <= 4 pivots of a group (K = 128 nop): lower-triangle tiles
+//       A_IJ += sum_w G_w[I] H_w[J]^T,     H_w = -(G Pg)_w,
+// so the C tile is read and written once per nop updates and a workgroup's launch / first-chunk / store-drain
+// overhead is paid once per nop times the work (with one pivot per launch the update is HBM-bound).
+//
+// The launch covers every tile outside the group's own blocks, in an ORDER that serves the look-ahead: workgroups are
+// dispatched by ascending block index, and the HEAD of the grid holds what the pivot chain of the NEXT group waits for,
+//   1. the tiles inside the next group's diagonal super-block              -> counter cnt[0] (one tick per workgroup)
+//   2. the write-back of this group's new columns (A[., g] <- -H)           -> counter cnt[1]
+//   3. the other tiles in the next group's columns (all remaining rows)     -> counter cnt[1]
+// followed by the big remainder (every tile over the blocks outside [skip_lo, skip_lo + skip_n) = this group and the
+// next).  A head workgroup makes its stores visible device-wide (agent-scope release) and ticks its counter; the main
+// stream waits on the counter VALUES (hipStreamWaitValue32) -- the next group's pivot chain starts ~one tile time after
+// the launch does, its panel when the head is through, both while the remainder keeps the chip busy: no separate
+// look-ahead launches competing with the update for compute units, no kernel boundary between look-ahead and bulk.
+// Head part: up to 8 pseudo-columns; entry m covers the tiles (b, col[m]) for n1[m] blocks b from lo1[m] and then
+// blocks from lo2[m] on; first[m] .. first[m+1]-1 are its workgroups; entries below ndiag_cols are the diagonal
+// super-block.
 struct GroupUpd {
     const double *G[4];
     const double *H[4];
     int nop;
-    int skip_lo, skip_n;
-    int ncol;
-    int col[4], first[5], cskip_lo[4], cskip_n[4];
-    int wb_col;
-    const double *wbH;
+    int skip_lo, skip_n;                           // remainder
+    int ncol, ndiag;                               // head: entries; workgroups of kind 1
+    int col[8], first[9], lo1[8], n1[8], lo2[8];
+    int wb_first, wb_rows, wb_b0, wb_sz, nhead;    // kind 2: workgroups [wb_first, nhead): (row block, column w of the group)
+    const double *wbH;                             // H panels of the group (panel w at wbH + w * wb_stride)
+    size_t wb_stride;
+    unsigned *cnt;                                 // cnt[0], cnt[1]; nullptr: no signalling (serial schedule)
 };
 
-template <bool SLICE, bool MULTI>
+template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A, size_t ld, size_t pld, const GroupUpd P)
 {
     __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
     __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
     const int t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool head = t < P.nhead;
     int I, J;
-    if constexpr (SLICE) {
-        if (t >= P.first[P.ncol]) {
-            int b = t - P.first[P.ncol];
-            if (b >= P.wb_col) ++b;
-            panel_writeback_tile(A, ld, P.wb_col, b, P.wbH, pld, Gs[0]);
-            return;
-        }
+    if (head && t >= P.wb_first) {
+        // write-back of one tile of the group's new columns
+        const int e = t - P.wb_first;
+        int i = e % P.wb_rows;
+        const int w = e / P.wb_rows;
+        if (i >= P.wb_b0) i += P.wb_sz;
+        panel_writeback_tile(A, ld, P.wb_b0 + w, i, P.wbH + (size_t)w * P.wb_stride, pld, Gs[0]);
+        I = J = -1;
+    } else if (head) {
         int m = 0;
         while (m + 1 < P.ncol && t >= P.first[m + 1]) ++m;
-        int b = t - P.first[m];
-        if (b >= P.cskip_lo[m]) b += P.cskip_n[m];
+        const int local = t - P.first[m];
+        const int b = local < P.n1[m] ? P.lo1[m] + local : P.lo2[m] + (local - P.n1[m]);
         const int cb = P.col[m];
         I = b > cb ? b : cb;
         J = b > cb ? cb : b;
     } else {
-        int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((long long)ii * (ii + 1) / 2 > t) --ii;
-        while ((long long)(ii + 1) * (ii + 2) / 2 <= t) ++ii;
-        int jj = t - (int)((long long)ii * (ii + 1) / 2);
+        const int tt = t - P.nhead;
+        int ii = (int)((sqrt(8.0 * (double)tt + 1.0) - 1.0) * 0.5);
+        while ((long long)ii * (ii + 1) / 2 > tt) --ii;
+        while ((long long)(ii + 1) * (ii + 2) / 2 <= tt) ++ii;
+        int jj = tt - (int)((long long)ii * (ii + 1) / 2);
         if (ii >= P.skip_lo) ii += P.skip_n;
         if (jj >= P.skip_lo) jj += P.skip_n;
         I = ii;
         J = jj;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double *At = A + (size_t)I * T + (size_t)J * T * ld;
-    double4_t acc[4][4];
+    if (I >= 0) {
+        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+        double *At = A + (size_t)I * T + (size_t)J * T * ld;
+        double4_t acc[4][4];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    {
-        StageRegs<4> R;
-        double cp[8];
-        const size_t go = (size_t)I * T, ho = (size_t)J * T;
-        const double *g1 = P.G[0] + go, *h1 = P.H[0] + ho;
-        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
-        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
-        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
-        __syncthreads();
-        if constexpr (MULTI) {
-            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, P.G[1] + go, P.H[1] + ho, pld, Gs, Hs, At, ld);
-            // pivots 2 .. nop of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
-            // chunk 0 is in LDS buffer 0 and chunk 1 in R
-            const int total = (T / KC) * (P.nop - 1);
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        {
+            StageRegs<4> R;
+            double cp[8];
+            const size_t go = (size_t)I * T, ho = (size_t)J * T;
+            const double *g1 = P.G[0] + go, *h1 = P.H[0] + ho;
+            stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
+            stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+            stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
+            __syncthreads();
+            if constexpr (MULTI) {
+                UpdateChunks<0, true>::run(acc, R, cp, g1, h1, P.G[1] + go, P.H[1] + ho, pld, Gs, Hs, At, ld);
+                // pivots 2 .. nop of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
+                // chunk 0 is in LDS buffer 0 and chunk 1 in R
+                const int total = (T / KC) * (P.nop - 1);
 #pragma unroll 1
-            for (int c = 0; c < total; ++c) {
-                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
-                if (c + 2 < total) {
-                    const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
-                    stage_load<false, 4>(R, P.G[op] + go, pld, P.H[op] + ho, pld, kc, tid);
+                for (int c = 0; c < total; ++c) {
+                    chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                    if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+                    if (c + 2 < total) {
+                        const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
+                        stage_load<false, 4>(R, P.G[op] + go, pld, P.H[op] + ho, pld, kc, tid);
+                    }
+                    chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                    __syncthreads();
                 }
-                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                __syncthreads();
+            } else {
+                UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
             }
-        } else {
-            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = wr * 64 + tn * 16 + l15;
+                    const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                    At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
+                }
+    }
+    if (head && P.cnt) {
+        // publish: every wave's stores have left the CU, then one agent-scope release and the tick
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(P.cnt + (t < P.ndiag ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+// ---- the look-ahead chain of a pivot GROUP ------------------------------------------------------------------------
+// A group of sz <= 4 consecutive pivot blocks (m = 128 sz columns) is swept as ONE pivot of width m:
+//       Pg = (A_gg)^-1 (m x m),   G = A_{.,g},   H = -G Pg,   A_ij += H_i G_j^T  (the launches above),   A_{.,g} <- -H,   A_gg <- -Pg.
+// Only Pg is serial work, and it is small: the m x m diagonal super-block is copied to a dense scratch matrix
+// (k_gather_diag) and swept there block by block -- k_pivot for the 128 x 128 pivot, then two tiny launches of tile
+// products (k_tile_jobs) for the other blocks of the scratch matrix -- while the bulk of the group's look-ahead work
+// (the previous group's update applied to this group's columns, all rows) runs beside it on another stream.  One
+// launch then forms H for every row block (k_group_panel, K = m) and one writes the new columns back
+// (k_group_writeback).  Per group: no per-pivot panel / slice launches over the whole matrix any more.
+
+// Sg (m x m, ld = m, full storage) <- the diagonal super-block of A at block b0 (lower triangle authoritative)
+__global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ A, size_t ld, int b0, int m,
+                                                      double *__restrict__ Sg)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * m) return;
+    const int r = e % m, c = e / m;
+    const double *Agg = A + (size_t)b0 * T + (size_t)b0 * T * ld;
+    Sg[e] = r >= c ? Agg[(size_t)r + (size_t)c * ld] : Agg[(size_t)c + (size_t)r * ld];
+}
+
+// Sg holds -Pg: A_gg <- Sg (lower-triangle tiles, diagonal tiles in full), Pg <- -Sg, exactly symmetric (from the lower
+// triangle)
+__global__ __launch_bounds__(256) void k_scatter_diag(double *__restrict__ A, size_t ld, int b0, int m,
+                                                       const double *__restrict__ Sg, double *__restrict__ Pg)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * m) return;
+    const int r = e % m, c = e / m;
+    if (r < c) return;
+    double *Agg = A + (size_t)b0 * T + (size_t)b0 * T * ld;
+    const double v = Sg[e];
+    Agg[(size_t)r + (size_t)c * ld] = v;
+    Pg[(size_t)r + (size_t)c * m] = -v;
+    if (r > c) {
+        Pg[(size_t)c + (size_t)r * m] = -v;
+        if (r / T == c / T) Agg[(size_t)c + (size_t)r * ld] = v;
+    }
+}
+
+// A handful of independent 128 x 128 x 128 tile products on the scratch matrix, two workgroups (64 columns each) per
+// job:   X = g h^T;   out = cin ? cin - X : X;   outT (optional) = out^T.
+struct TileJob {
+    const double *g, *h, *cin;
+    double *out, *outT;
+};
+struct TileJobs {
+    TileJob j[9];
+    size_t gld, hld, cld;
+};
+
+// The jobs run beside the big update, when a dependent global load takes several microseconds: all of a job's operands
+// (K = 128: 8 chunks) are requested up front and the chunks then pass through a double-buffered LDS stage, one barrier
+// each -- one memory round trip per job instead of one per chunk.
+__global__ __launch_bounds__(256, 1) void k_tile_jobs(const TileJobs J)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
+    const TileJob job = J.j[blockIdx.x >> 1];
+    const int ch = blockIdx.x & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    constexpr int NCH = T / KC;
+    StageRegs<2> R[NCH];
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int c = 0; c < NCH; ++c) stage_load<false, 2>(R[c], job.g, J.gld, job.h + (size_t)ch * 64, J.hld, c * KC, tid);
+    // the tile of cin this thread will combine with, requested now as well
+    double cin[2][4][4];
+    if (job.cin) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = wr * 64 + tn * 16 + l15;
+                    const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                    cin[tm][tn][reg] = job.cin[(size_t)r + (size_t)c * J.cld];
+                }
+    }
+    double4_t acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    stage_store<false, 2>(R[0], Gs[0], Hs[0], tid);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) stage_store<false, 2>(R[c + 1], Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+        chunk_mma<2>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
+                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                double v = acc[tm][tn][reg];
+                if (job.cin) v = cin[tm][tn][reg] - v;
+                job.out[(size_t)r + (size_t)c * J.cld] = v;
+                if (job.outT) job.outT[(size_t)c + (size_t)r * J.cld] = v;
             }
 }
 
-// Host driver of the block sweep.  With a side stream (s1 != nullptr) it runs with look-ahead, by default in
-// PAIRS of pivots: the big trailing update of pivots (2p, 2p+1) is ONE launch with K = 256 on the side stream
-// (half the C-tile traffic per flop of two K = 128 launches -- the trailing update is HBM-bound otherwise), while
-// the main (high-priority) stream runs the chain of the next pair: the slices of the pair update that touch
-// blocks 2p+2 and 2p+3, pivot/panel of 2p+2, its rank-128 update of column 2p+3, pivot/panel of 2p+3 and that
-// pivot's update of column 2p+2.  Panels are double-buffered by pair parity.  The single-pivot look-ahead
-// (GDCA_PAIRS=0) and the serial schedule (s1 == nullptr) are kept for small matrices and for comparison.
+struct GroupPanels {
+    double *G0, *H0;  // panel w of the group = G0 + w * stride (the panels of a group are carved from one buffer)
+    size_t stride;
+};
+
+// Panel of a group: for every row block i outside the group, G_i = the group's m columns of row block i (read from the
+// lower triangle: A[i, k] for i below the group, A[k, i]^T for i above it) and H_i = -G_i Pg.  Workgroup = (row block i,
+// 64 of the m columns of H_i), K = m; the workgroups of the first 64 columns also keep the untransposed G_i for the
+// update launches.
+__global__ __launch_bounds__(256, 2) void k_group_panel(const double *__restrict__ A, size_t ld, int b0, int sz,
+                                                         const double *__restrict__ Pg, size_t pgld, const GroupPanels gp,
+                                                         size_t pld)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
+    int i = blockIdx.x;
+    if (i >= b0) i += sz;
+    const int w = blockIdx.y >> 1, ch = blockIdx.y & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    double4_t acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
+    const double *hsrc0 = Pg + (size_t)w * T + (size_t)ch * 64;
+    double *gcopy0 = (blockIdx.y == 0) ? gp.G0 + (size_t)i * T : nullptr;
+    if (i > b0) {  // below the group: G_i = A[i, k]
+#pragma unroll 1
+        for (int v = 0; v < sz; ++v)
+            tile_product<false, 2>(acc, A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs, Hs,
+                                   gcopy0 ? gcopy0 + (size_t)v * gp.stride : nullptr, pld);
+    } else {       // above the group: G_i = A[k, i]^T
+#pragma unroll 1
+        for (int v = 0; v < sz; ++v)
+            tile_product<true, 2>(acc, A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs, Hs,
+                                  gcopy0 ? gcopy0 + (size_t)v * gp.stride : nullptr, pld);
+    }
+    double *Hw = gp.H0 + (size_t)w * gp.stride + (size_t)i * T;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = wr * 64 + tn * 16 + l15;
+                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                Hw[(size_t)r + (size_t)c * pld] = -acc[tm][tn][reg];
+            }
+}
+
+// The group's new column blocks: A[i, b0 + w] <- -H_w[i] for every row block i outside the group (transposed into
+// A[b0 + w, i] for the row blocks above it).  A launch of its own, after the panel: every panel workgroup reads the OLD
+// columns as its G operand.
+__global__ __launch_bounds__(256) void k_group_writeback(double *__restrict__ A, size_t ld, int b0, int sz,
+                                                          const GroupPanels gp, size_t pld)
+{
+    __shared__ __attribute__((aligned(16))) double Ts[KC][LDS_LD];
+    int i = blockIdx.x;
+    if (i >= b0) i += sz;
+    const int w = blockIdx.y;
+    panel_writeback_tile(A, ld, b0 + w, i, gp.H0 + (size_t)w * gp.stride, pld, Ts);
+}
+
+// Host driver of the block sweep: pivot groups of g blocks (g = 1 .. 4 by matrix size; GDCA_GROUP=g forces).
+// With a side stream (s1) it runs with look-ahead over two streams:
+//     side stream   U(p): ONE launch per group -- every tile outside group p, head first (k_group_update)
+//     main stream   the chain of group p+1 (high priority; a few CUs are kept free of U's workgroups for it):
+//                     wait for U(p)'s first counter (the next diagonal super-block carries update p)
+//                     M   Pg = inverse of the super-block: gather, sz x (k_pivot, two tile-job launches), scatter
+//                     wait for U(p)'s second counter (group p's columns written back, group p+1's columns updated)
+//                     Pn  G, H = -G Pg for every row block (k_group_panel)
+//                   then U(p+1) may start as soon as U(p) has drained.
+// Panels are double-buffered by group parity.  Without a side stream everything runs on s0 in order.
 void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
                              gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev, int max_upd_ev,
                              int *n_upd_launch, double *upd_flops)
@@ -798,237 +859,178 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     const double tile_flops = 2.0 * T * T * T;
     int nl = 0;
     double fl = 0.0;
-    // big launch over all blocks outside [skip_lo, skip_lo + skip_n)
-    auto timed_update = [&](hipStream_t st, int skip_lo, int skip_n, const double *G, const double *H, const double *G2,
-                            const double *H2) {
-        const int m = nblk - skip_n;
-        if (m <= 0) return;
-        const unsigned ntile = (unsigned)((long long)m * (m + 1) / 2);
+    const bool la = s1 != nullptr && nblk >= 3;
+    // pivots per group: more pivots per launch raise the update's arithmetic intensity (K = 128 g) and amortise its
+    // per-tile overheads; the group's chain grows with g and must stay shorter than the update it hides behind
+    static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 48 ? 3 : (nblk >= 24 ? 2 : 1)));
+    if (nblk < 2 * g) g = 1;
+    const int ng = (nblk + g - 1) / g;
+    hipEvent_t *Ep = sync_ev, *Eb = sync_ev + ng;
+    const size_t pstride = (size_t)(ws.G[1] - ws.G[0]);
+    auto base = [&](int p) { return p * g; };
+    auto size = [&](int p) { return std::min(g, nblk - p * g); };
+    auto panels = [&](int p) {
+        GroupPanels gp{};
+        gp.G0 = ws.G[4 * (p & 1)];
+        gp.H0 = ws.H[4 * (p & 1)];
+        gp.stride = pstride;
+        return gp;
+    };
+    // M: Pg of group p (and A_gg <- -Pg)
+    auto super_pivot = [&](int p) {
+        const int b0 = base(p), sz = size(p), m = sz * T;
+        if (sz == 1) {
+            double *Akk = A + (size_t)b0 * T + (size_t)b0 * T * ld;
+            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, (const double *)Akk, ld, Akk, ld, ws.Pg, (size_t)T, sc,
+                               b0 * T, n_real);
+            return;
+        }
+        const unsigned eg = (unsigned)((m * m + 255) / 256);
+        hipLaunchKernelGGL(k_gather_diag, dim3(eg), dim3(256), 0, s0, (const double *)A, ld, b0, m, ws.Sg[0]);
+        int cur = 0;
+        for (int w = 0; w < sz; ++w) {
+            const double *Sin = ws.Sg[cur];
+            double *Sout = ws.Sg[cur ^ 1];
+            const size_t dd = (size_t)w * T + (size_t)w * T * m;
+            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, Sin + dd, (size_t)m, Sout + dd, (size_t)m, ws.P,
+                               (size_t)T, sc, (b0 + w) * T, n_real);
+            // the other blocks of the scratch matrix:  S_iw <- S_iw Pw (and its mirror S_wi),  S_ij <- S_ij - (S_iw Pw) S_jw^T
+            TileJobs J1{}, J2{};
+            int n1 = 0, n2 = 0;
+            for (int i = 0; i < sz; ++i) {
+                if (i == w) continue;
+                TileJob &a = J1.j[n1++];
+                a.g = Sin + (size_t)i * T + (size_t)w * T * m;
+                a.h = ws.P;
+                a.cin = nullptr;
+                a.out = Sout + (size_t)i * T + (size_t)w * T * m;
+                a.outT = Sout + (size_t)w * T + (size_t)i * T * m;
+                for (int j = 0; j < sz; ++j) {
+                    if (j == w) continue;
+                    TileJob &b = J2.j[n2++];
+                    b.g = Sout + (size_t)i * T + (size_t)w * T * m;
+                    b.h = Sin + (size_t)j * T + (size_t)w * T * m;
+                    b.cin = Sin + (size_t)i * T + (size_t)j * T * m;
+                    b.out = Sout + (size_t)i * T + (size_t)j * T * m;
+                    b.outT = nullptr;
+                }
+            }
+            J1.gld = (size_t)m;
+            J1.hld = (size_t)T;
+            J1.cld = (size_t)m;
+            J2.gld = J2.hld = J2.cld = (size_t)m;
+            hipLaunchKernelGGL(k_tile_jobs, dim3(2 * n1), dim3(256), 0, s0, J1);
+            hipLaunchKernelGGL(k_tile_jobs, dim3(2 * n2), dim3(256), 0, s0, J2);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_scatter_diag, dim3(eg), dim3(256), 0, s0, A, ld, b0, m, (const double *)ws.Sg[cur], ws.Pg);
+    };
+    auto group_panel = [&](int p) {
+        const int b0 = base(p), sz = size(p);
+        if (nblk - sz <= 0) return;
+        hipLaunchKernelGGL(k_group_panel, dim3(nblk - sz, 2 * sz), dim3(256), 0, s0, (const double *)A, ld, b0, sz,
+                           (const double *)ws.Pg, (size_t)(sz * T), panels(p), ld);
+    };
+    // U(p).  ordered = with the look-ahead head (diagonal super-block of group p+1, write-back of group p, the other rows
+    // of group p+1's columns) and its two counters; otherwise the plain update of everything outside group p.
+    unsigned nA = 0, nB = 0;
+    auto update = [&](hipStream_t st, int p, bool ordered) {
+        const int b0 = base(p), sz = size(p);
+        const int nsz = (ordered && p + 1 < ng) ? size(p + 1) : 0, c0 = b0 + sz;
+        GroupUpd P{};
+        for (int w = 0; w < 4; ++w) {
+            P.G[w] = ws.G[4 * (p & 1) + std::min(w, sz - 1)];
+            P.H[w] = ws.H[4 * (p & 1) + std::min(w, sz - 1)];
+        }
+        P.nop = sz;
+        int first = 0, mcol = 0;
+        for (int mm = 0; mm < nsz; ++mm, ++mcol) {  // diagonal super-block of the next group: rows mm .. nsz-1 of column mm
+            P.col[mcol] = c0 + mm;
+            P.first[mcol] = first;
+            P.lo1[mcol] = c0 + mm;
+            P.n1[mcol] = nsz - mm;
+            P.lo2[mcol] = 0;
+            first += nsz - mm;
+        }
+        P.ndiag = first;
+        const int nrest = nblk - sz - nsz;
+        int ncol_rest = 0;
+        for (int mm = 0; mm < nsz && nrest > 0; ++mm, ++ncol_rest) {  // the other rows: above group p, then below group p+1
+            const int e = nsz + mm;
+            P.col[e] = c0 + mm;
+            P.lo1[e] = 0;
+            P.n1[e] = b0;
+            P.lo2[e] = c0 + nsz;
+        }
+        // workgroup order of the head: diagonal entries, rest entries, write-back
+        P.ncol = nsz + ncol_rest;
+        P.wb_rows = nblk - sz;
+        P.wb_b0 = b0;
+        P.wb_sz = sz;
+        const int nwb = ordered ? (nblk - sz) * sz : 0;
+        for (int mm = 0; mm < ncol_rest; ++mm) {
+            P.first[nsz + mm] = first;
+            first += nrest;
+        }
+        P.first[P.ncol] = first;
+        P.wb_first = first;
+        P.nhead = first + nwb;
+        P.wbH = ws.H[4 * (p & 1)];
+        P.wb_stride = pstride;
+        P.cnt = ordered ? ws.cnt + 2 * p : nullptr;
+        nA = (unsigned)P.ndiag;
+        nB = (unsigned)(P.nhead - P.ndiag);
+        P.skip_lo = b0;
+        P.skip_n = sz + nsz;
+        const int mrem = nblk - P.skip_n;
+        const long long nbig = mrem > 0 ? (long long)mrem * (mrem + 1) / 2 : 0;
+        const unsigned grid = (unsigned)(P.nhead + nbig);
+        if (grid == 0) return;
         const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
         if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
-        if (G2)
-            hipLaunchKernelGGL((k_sweep_update<true, false>), dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G, H,
-                               G2, H2, ld, -1, (const double *)nullptr, -1, 0);
+        if (sz > 1)
+            hipLaunchKernelGGL((k_group_update<true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
         else
-            hipLaunchKernelGGL((k_sweep_update<false, false>), dim3(ntile), dim3(256), 0, st, A, ld, skip_lo, skip_n, -1, 0, G,
-                               H, G2, H2, ld, -1, (const double *)nullptr, -1, 0);
+            hipLaunchKernelGGL((k_group_update<false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
         if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
         ++nl;
-        fl += tile_flops * (double)ntile * (G2 ? 2.0 : 1.0);
+        fl += tile_flops * (double)(first + nbig) * (double)sz;
     };
-    // slice: the tiles that involve block col (other index outside the skip range), plus, when wb_col >= 0, the
-    // write-back of pivot column wb_col from wbH
-    auto slice = [&](hipStream_t st, int col, int skip_lo, int skip_n, const double *G, const double *H, const double *G2,
-                     const double *H2, int wb_col, const double *wbH, int col2 = -1) {
-        const int ns1 = nblk - skip_n;
-        const int ns = ns1 + (col2 >= 0 ? nblk - skip_n - 1 : 0);
-        const dim3 grid(ns + (wb_col >= 0 ? nblk - 1 : 0));
-        if (G2)
-            hipLaunchKernelGGL((k_sweep_update<true, true>), grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2,
-                               H2, ld, wb_col, wbH, col2, ns1);
-        else
-            hipLaunchKernelGGL((k_sweep_update<false, true>), grid, dim3(256), 0, st, A, ld, skip_lo, skip_n, col, ns, G, H, G2,
-                               H2, ld, wb_col, wbH, col2, ns1);
-    };
-    auto pivot = [&](int k) {
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, A + (size_t)k * T + (size_t)k * T * ld, ld, ws.P, (size_t)T,
-                           sc, k * T, n_real);
-    };
-    auto panel = [&](int k, double *G, double *H) {
-        hipLaunchKernelGGL(k_panel, dim3(nblk - 1, 2), dim3(256), 0, s0, A, ld, k, ws.P, G, H, ld);
-    };
-    // pairs pay off once the trailing update dominates (measured crossover on MI355X at 66 blocks = n ~ 8400;
-    // below that the longer chain per pivot costs more than the halved C-tile traffic saves); GDCA_PAIRS=0/1 forces
-    static const int pairs_env = getenv("GDCA_PAIRS") ? atoi(getenv("GDCA_PAIRS")) : -1;
-    const bool pairs_on = pairs_env < 0 ? nblk >= 66 : pairs_env != 0;
-    // groups of 3-4 pivots per trailing update (k_group_update) once the matrix is large enough for the longer chain of
-    // a group to stay hidden (measured: 3 from 66 blocks, 4 from 90); GDCA_GROUP=g forces (0..2: pairs / single pivots)
-    static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    const int group_g = group_env >= 0 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 66 ? 3 : 0));
 
-    pivot(0);
-    if (nblk > 1) {
-        if (!s1) {
-            // serial schedule: pivot -> panel -> write-back -> full update, one stream
-            for (int k = 0; k < nblk; ++k) {
-                if (k > 0) pivot(k);
-                panel(k, ws.G[0], ws.H[0]);
-                hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, ws.H[0], ld);
-                timed_update(s0, k, 1, ws.G[0], ws.H[0], nullptr, nullptr);
+    if (la) (void)hipMemsetAsync(ws.cnt, 0, (size_t)2 * ng * sizeof(unsigned), s0);
+    super_pivot(0);
+    if (nblk == size(0)) {  // a single group: nothing to update
+        if (n_upd_launch) *n_upd_launch = 0;
+        if (upd_flops) *upd_flops = 0.0;
+        return;
+    }
+    group_panel(0);
+    if (!la) {
+        // serial schedule on s0
+        for (int p = 0; p < ng; ++p) {
+            if (p > 0) {
+                super_pivot(p);
+                group_panel(p);
             }
-        } else if (group_g >= 3 && nblk >= 2 * group_g && ws.G[4]) {
-            // ---- groups of group_g pivots (large matrices) ----
-            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
-            const int g = group_g, ng = (nblk + g - 1) / g;
-            auto base = [&](int p) { return p * g; };
-            auto size = [&](int p) { return std::min(g, nblk - p * g); };
-            auto GG = [&](int p, int w) { return ws.G[4 * (p & 1) + w]; };
-            auto HH = [&](int p, int w) { return ws.H[4 * (p & 1) + w]; };
-            auto launch_group = [&](hipStream_t st, bool slice_mode, unsigned grid, const GroupUpd &P) {
-                if (slice_mode) {
-                    if (P.nop > 1)
-                        hipLaunchKernelGGL((k_group_update<true, true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
-                    else
-                        hipLaunchKernelGGL((k_group_update<true, false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
-                } else {
-                    if (P.nop > 1)
-                        hipLaunchKernelGGL((k_group_update<false, true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
-                    else
-                        hipLaunchKernelGGL((k_group_update<false, false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
-                }
-            };
-            auto set_ops = [&](GroupUpd &P, int p, int first_op, int nop) {
-                for (int w = 0; w < 4; ++w) {
-                    P.G[w] = GG(p, std::min(first_op + w, 3));
-                    P.H[w] = HH(p, std::min(first_op + w, 3));
-                }
-                P.nop = nop;
-            };
-            // the chain of group p: pivots one after the other, each applied at once to the other columns of the group
-            auto chain = [&](int p) {
-                const int b0 = base(p), sz = size(p);
-                for (int i = 0; i < sz; ++i) {
-                    const int k = b0 + i;
-                    if (k > 0) pivot(k);  // pivot 0 was launched above, before the schedules branch
-                    panel(k, GG(p, i), HH(p, i));
-                    GroupUpd P{};
-                    set_ops(P, p, i, 1);
-                    P.wb_col = k;
-                    P.wbH = HH(p, i);
-                    int m = 0, first = 0;
-                    for (int c = k + 1; c < b0 + sz; ++c, ++m) {  // later columns of the group: skip [k, c)
-                        P.col[m] = c;
-                        P.cskip_lo[m] = k;
-                        P.cskip_n[m] = c - k;
-                        P.first[m] = first;
-                        first += nblk - P.cskip_n[m];
-                    }
-                    for (int c = k - 1; c >= b0; --c, ++m) {  // earlier columns: skip (c, b0 + sz)
-                        P.col[m] = c;
-                        P.cskip_lo[m] = c + 1;
-                        P.cskip_n[m] = b0 + sz - (c + 1);
-                        P.first[m] = first;
-                        first += nblk - P.cskip_n[m];
-                    }
-                    P.ncol = m;
-                    P.first[m] = first;
-                    launch_group(s0, true, (unsigned)(first + nblk - 1), P);
-                }
-            };
-            chain(0);
-            (void)hipEventRecord(Ep[0], s0);
-            for (int p = 0; p < ng; ++p) {
-                const int b0 = base(p), sz = size(p);
-                const bool has_next = p + 1 < ng;
-                const int nsz = has_next ? size(p + 1) : 0;
-                // side stream: the group's update of everything outside its own and the next group's blocks
-                (void)hipStreamWaitEvent(s1, Ep[p], 0);
-                {
-                    GroupUpd P{};
-                    set_ops(P, p, 0, sz);
-                    P.skip_lo = b0;
-                    P.skip_n = sz + nsz;
-                    const int m = nblk - P.skip_n;
-                    if (m > 0) {
-                        const unsigned ntile = (unsigned)((long long)m * (m + 1) / 2);
-                        const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
-                        if (tm) (void)hipEventRecord(upd_ev[2 * nl], s1);
-                        launch_group(s1, false, ntile, P);
-                        if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], s1);
-                        ++nl;
-                        fl += tile_flops * (double)ntile * (double)sz;
-                    }
-                }
-                (void)hipEventRecord(Eb[p], s1);
-                if (!has_next) break;
-                if (p >= 1) (void)hipStreamWaitEvent(s0, Eb[p - 1], 0);  // the next group's columns carry update p-1
-                {
-                    // the tiles of group p's update that involve the next group's blocks, one launch
-                    GroupUpd P{};
-                    set_ops(P, p, 0, sz);
-                    P.wb_col = -1;
-                    int first = 0;
-                    for (int m = 0; m < nsz; ++m) {
-                        P.col[m] = b0 + sz + m;
-                        P.cskip_lo[m] = b0;
-                        P.cskip_n[m] = sz + m;
-                        P.first[m] = first;
-                        first += nblk - P.cskip_n[m];
-                    }
-                    P.ncol = nsz;
-                    P.first[nsz] = first;
-                    launch_group(s0, true, (unsigned)first, P);
-                }
-                chain(p + 1);
+            hipLaunchKernelGGL(k_group_writeback, dim3(nblk - size(p), size(p)), dim3(256), 0, s0, A, ld, base(p), size(p), panels(p), ld);
+            update(s0, p, false);
+        }
+    } else {
+        (void)hipEventRecord(Ep[0], s0);
+        for (int p = 0; p < ng; ++p) {
+            (void)hipStreamWaitEvent(s1, Ep[p], 0);
+            update(s1, p, true);
+            if (p + 1 < ng) {
+                if (nA) (void)hipStreamWaitValue32(s0, ws.cnt + 2 * p, nA, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                super_pivot(p + 1);
+                if (nB) (void)hipStreamWaitValue32(s0, ws.cnt + 2 * p + 1, nB, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                group_panel(p + 1);
                 (void)hipEventRecord(Ep[p + 1], s0);
             }
-            (void)hipStreamWaitEvent(s0, Eb[ng - 1], 0);
-        } else if (pairs_on && nblk >= 6 && ws.G[2]) {
-            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
-            // panels of pair p: G[2 (p & 1) + {0, 1}]
-            auto PG = [&](int p, int w) { return ws.G[2 * (p & 1) + w]; };
-            auto PH = [&](int p, int w) { return ws.H[2 * (p & 1) + w]; };
-            const int np = nblk / 2;
-            // chain of pair 0
-            panel(0, PG(0, 0), PH(0, 0));
-            slice(s0, 1, 0, 1, PG(0, 0), PH(0, 0), nullptr, nullptr, 0, PH(0, 0));
-            pivot(1);
-            panel(1, PG(0, 1), PH(0, 1));
-            slice(s0, 0, 1, 1, PG(0, 1), PH(0, 1), nullptr, nullptr, 1, PH(0, 1));
-            (void)hipEventRecord(Ep[0], s0);
-            for (int p = 0; p < np; ++p) {
-                const int k1 = 2 * p, k3 = k1 + 2, k4 = k1 + 3;
-                const bool has3 = k3 < nblk, has4 = k4 < nblk;
-                // side stream: the pair's update of everything outside the pair and outside the next chain's columns
-                (void)hipStreamWaitEvent(s1, Ep[p], 0);
-                timed_update(s1, k1, 2 + (has3 ? 1 : 0) + (has4 ? 1 : 0), PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1));
-                (void)hipEventRecord(Eb[p], s1);
-                if (!has3) break;
-                if (p >= 1) (void)hipStreamWaitEvent(s0, Eb[p - 1], 0);  // columns k3, k4 carry update p-1
-                // one launch for the tiles of pair p's update that involve block k3 and (if any) block k4
-                slice(s0, k3, k1, 2, PG(p, 0), PH(p, 0), PG(p, 1), PH(p, 1), -1, nullptr, has4 ? k4 : -1);
-                pivot(k3);
-                panel(k3, PG(p + 1, 0), PH(p + 1, 0));
-                if (has4) {
-                    slice(s0, k4, k3, 1, PG(p + 1, 0), PH(p + 1, 0), nullptr, nullptr, k3, PH(p + 1, 0));
-                    pivot(k4);
-                    panel(k4, PG(p + 1, 1), PH(p + 1, 1));
-                    slice(s0, k3, k4, 1, PG(p + 1, 1), PH(p + 1, 1), nullptr, nullptr, k4, PH(p + 1, 1));
-                    (void)hipEventRecord(Ep[p + 1], s0);
-                } else {
-                    // odd block count: the last pivot stands alone
-                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k3, PH(p + 1, 0), ld);
-                    (void)hipStreamWaitEvent(s0, Eb[p], 0);
-                    timed_update(s0, k3, 1, PG(p + 1, 0), PH(p + 1, 0), nullptr, nullptr);
-                }
-            }
-            (void)hipStreamWaitEvent(s0, Eb[np - 1], 0);
-        } else {
-            hipEvent_t *Ep = sync_ev, *Eb = sync_ev + nblk;
-            panel(0, ws.G[0], ws.H[0]);
-            (void)hipEventRecord(Ep[0], s0);
-            for (int k = 0; k < nblk; ++k) {
-                const bool has_next = k + 1 < nblk;
-                const double *G = ws.G[k & 1], *H = ws.H[k & 1];
-                // side stream: everything of update k that does not touch block k+1
-                (void)hipStreamWaitEvent(s1, Ep[k], 0);
-                timed_update(s1, k, has_next ? 2 : 1, G, H, nullptr, nullptr);
-                (void)hipEventRecord(Eb[k], s1);
-                if (has_next) {
-                    if (k >= 1) (void)hipStreamWaitEvent(s0, Eb[k - 1], 0);
-                    // look-ahead slice: the nblk-1 tiles in row/column k+1 (+ write-back of column k), then the next
-                    // pivot and panel
-                    slice(s0, k + 1, k, 1, G, H, nullptr, nullptr, k, H);
-                    pivot(k + 1);
-                    panel(k + 1, ws.G[(k + 1) & 1], ws.H[(k + 1) & 1]);
-                    (void)hipEventRecord(Ep[k + 1], s0);
-                } else {
-                    // last pivot: no look-ahead launch to carry its column write-back
-                    hipLaunchKernelGGL(k_panel_writeback, dim3(nblk - 1), dim3(256), 0, s0, A, ld, k, H, ld);
-                }
-            }
-            (void)hipStreamWaitEvent(s0, Eb[nblk - 1], 0);
         }
+        (void)hipEventRecord(Eb[0], s1);
+        (void)hipStreamWaitEvent(s0, Eb[0], 0);
     }
     if (n_upd_launch) *n_upd_launch = nl;
     if (upd_flops) *upd_flops = fl;

@@ -57,7 +57,8 @@ int main()
             hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
             hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice);
             hipMemset(sc, 0, sizeof(*sc));
-            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA + (size_t)k * n + (size_t)k * n * ld, (size_t)ld, dP,
+            double *Akk = dA + (size_t)k * n + (size_t)k * n * ld;
+            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, (const double *)Akk, (size_t)ld, Akk, (size_t)ld, dP,
                                (size_t)n, sc, k * n, ld);
             hipError_t e = hipDeviceSynchronize();
             gdca_dev_scalars h;
@@ -85,9 +86,12 @@ int main()
         double *dA, *dP;
         hipMalloc(&dA, A.size() * 8);
         hipMalloc(&dP, A.size() * 8);
+        double *dP2;
+        hipMalloc(&dP2, A.size() * 8);
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
         hipMemset(sc, 0, sizeof(*sc));
-        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA, (size_t)n, dP, (size_t)n, sc, 256, 100000);
+        hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, (const double *)dA, (size_t)n, dA, (size_t)n, dP, (size_t)n, sc,
+                           256, 100000);
         gdca_dev_scalars h;
         hipMemcpy(&h, sc, sizeof(h), hipMemcpyDeviceToHost);
         printf("non-PD at local index 38, index0 256: info %d (want 294)\n", h.info);
@@ -98,7 +102,8 @@ int main()
             hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
             hipEventRecord(e0, 0);
             for (int it = 0; it < 50; ++it)  // the block is overwritten by -inverse: values stay finite under repetition? use fresh copies
-                hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, dA, (size_t)n, dP, (size_t)n, sc, 0, 0);
+                hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2,
+                                   (size_t)n, sc, 0, 0);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms;
