@@ -34,6 +34,7 @@ struct gdca_ctx {
     // named device buffers (grow-only)
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
     hipStream_t side;          // side stream of the SPD inverse: the big trailing updates
+    int ncu, side_cus;         // compute units of the device / of the side stream's CU mask
     bool lookahead;
     hipEvent_t sev[MAX_EV];    // cross-stream ordering events
     int n_sev;
@@ -136,6 +137,11 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     // (measured, same tool).  GDCA_RESERVE_CU=k reserves k CUs per XCD (default 1; 0 = no mask).
     ctx->side = nullptr;
     const int reserve = getenv("GDCA_RESERVE_CU") ? atoi(getenv("GDCA_RESERVE_CU")) : 1;
+    {
+        hipDeviceProp_t prop0;
+        ctx->ncu = hipGetDeviceProperties(&prop0, device_id) == hipSuccess ? prop0.multiProcessorCount : 256;
+        ctx->side_cus = ctx->ncu;
+    }
     if (reserve > 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount == 256) {
@@ -149,6 +155,8 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
             if (hipExtStreamCreateWithCUMask(&ctx->side, 8, mask) != hipSuccess) {
                 (void)hipGetLastError();
                 ctx->side = nullptr;
+            } else {
+                ctx->side_cus = 256 - 8 * (reserve < 16 ? reserve : 16);
             }
         }
     }
@@ -374,7 +382,7 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     CHK(ensure(ctx, ctx->G, (size_t)npan * pbytes));
     CHK(ensure(ctx, ctx->H, (size_t)npan * pbytes));
     CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
-    CHK(ensure(ctx, ctx->Sg, 3 * sg + (size_t)2 * nblk * sizeof(unsigned)));
+    CHK(ensure(ctx, ctx->Sg, 3 * sg + (size_t)(nblk + 2) * (nblk + 2) * sizeof(unsigned)));
     gdca_inverse_ws ws;
     for (int w = 0; w < 8; ++w) {
         ws.G[w] = (double *)((char *)ctx->G.p + (size_t)(w % npan) * pbytes);
@@ -385,6 +393,7 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     ws.Sg[1] = (double *)((char *)ctx->Sg.p + sg);
     ws.Pg = (double *)((char *)ctx->Sg.p + 2 * sg);
     ws.cnt = (unsigned *)((char *)ctx->Sg.p + 3 * sg);
+    ws.update_cus = la ? ctx->side_cus : ctx->ncu;
     if (la) CHK(need_sync_events(ctx, 2 * nblk));
     hipEvent_t *uev = nullptr;
     int max_ev = 0;

@@ -88,7 +88,8 @@ struct gdca_inverse_ws {
     double *P;      // 128 x 128 inverse of one pivot block
     double *Sg[2];  // 512 x 512 dense scratch copies of a group's diagonal super-block (ping-pong)
     double *Pg;     // 512 x 512: inverse of the group's diagonal super-block
-    unsigned *cnt;  // 2 counters per pivot group: ticks of the head workgroups of the group's update launch
+    unsigned *cnt;  // (n_pad / 128 + 2) counters per pivot group: head ticks, panel ticks per row block, work counter
+    int update_cus; // compute units the update launches may use (the CU mask of the stream they run on)
 };
 // In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles
 // authoritative): A <- -inverse(A) by the block symmetric sweep.  info (device) gets the

@@ -26,6 +26,15 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// threadIdx.x behind a volatile asm: inside the persistent loop of the update kernel the compiler would otherwise treat
+// every per-thread address offset of every path (hundreds of values) as loop-invariant, hoist them all and spill them
+__device__ __forceinline__ int opaque_tid()
+{
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 #define T 128          // tile edge
 #define KC 16          // k-chunk staged per pass
 #define LDS_LD (T + 16)  // f64 elements per k-row in LDS (128-byte pad)
@@ -400,7 +409,7 @@ __device__ __forceinline__ void tile_product(double4_t (&acc)[TM][4], const doub
                                              const double *__restrict__ hsrc, size_t hld, double (*Gs)[LDS_LD],
                                              double (*Hs)[LDS_LD], double *__restrict__ gcopy, size_t gcopy_ld)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1;
     StageRegs<TM> R;
     stage_load<GT, TM>(R, gsrc, gld, hsrc, hld, 0, tid);
@@ -477,7 +486,7 @@ struct UpdateChunks {
                                                double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD],
                                                const double *__restrict__ At, size_t ld)
     {
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
         const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
         // on entry: LDS buffer CI & 1 holds chunk CI (barrier passed); R holds (or is receiving) chunk CI + 1
         if constexpr (CI > 0) cpiece_add<(CI > 0 ? CI - 1 : 0)>(acc, cp);  // requested one chunk ago
@@ -504,7 +513,7 @@ struct UpdateChunks {
 __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, size_t ld, int kblk, int i,
                                                      const double *__restrict__ Hbuf, size_t pld, double (*Ts)[LDS_LD])
 {
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid();
     const double *H = Hbuf + (size_t)i * T;
     if (i > kblk) {
         double *dst = A + (size_t)i * T + (size_t)kblk * T * ld;
@@ -551,10 +560,18 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
 //   2. the write-back of this group's new columns (A[., g] <- -H)           -> counter cnt[1]
 //   3. the other tiles in the next group's columns (all remaining rows)     -> counter cnt[1]
 // followed by the big remainder (every tile over the blocks outside [skip_lo, skip_lo + skip_n) = this group and the
-// next).  A head workgroup makes its stores visible device-wide (agent-scope release) and ticks its counter; the main
-// stream waits on the counter VALUES (hipStreamWaitValue32) -- the next group's pivot chain starts ~one tile time after
-// the launch does, its panel when the head is through, both while the remainder keeps the chip busy: no separate
-// look-ahead launches competing with the update for compute units, no kernel boundary between look-ahead and bulk.
+// next).  A kind-1 workgroup makes its stores visible device-wide (agent-scope release) and ticks cnt[0]; the main
+// stream waits on the counter VALUE (hipStreamWaitValue32): the next group's pivot chain starts ~one tile time after
+// the launch does, while the remainder keeps the chip busy -- no separate look-ahead launches competing with the
+// update for compute units, no kernel boundary between look-ahead and bulk.
+//
+// In FRONT of all tiles the same launch carries the group's PANEL: workgroup (row block i, 64 of the 128 nop columns)
+// forms G_i = the group's columns of row block i (from the lower triangle: A[i, k] below the group, A[k, i]^T above it)
+// and H_i = -G_i Pg (K = 128 nop), stores them in the panel buffers and ticks row block i's counter (2 nop ticks = the
+// row block is ready).  A tile (I, J) waits for row blocks I and J before it touches its operands, the write-back of
+// row block i waits for row block i (its panel workgroups are the ones that read the OLD columns).  Workgroups are
+// dispatched in index order and panel workgroups never wait, so the waits cannot deadlock.  Kind 2 and kind 3 need no
+// counter any more: the next group's update is a later launch on the same stream.
 // Head part: up to 8 pseudo-columns; entry m covers the tiles (b, col[m]) for n1[m] blocks b from lo1[m] and then
 // blocks from lo2[m] on; first[m] .. first[m+1]-1 are its workgroups; entries below ndiag_cols are the diagonal
 // super-block.
@@ -566,19 +583,84 @@ struct GroupUpd {
     int ncol, ndiag;                               // head: entries; workgroups of kind 1
     int col[8], first[9], lo1[8], n1[8], lo2[8];
     int wb_first, wb_rows, wb_b0, wb_sz, nhead;    // kind 2: workgroups [wb_first, nhead): (row block, column w of the group)
-    const double *wbH;                             // H panels of the group (panel w at wbH + w * wb_stride)
-    size_t wb_stride;
-    unsigned *cnt;                                 // cnt[0], cnt[1]; nullptr: no signalling (serial schedule)
+    int npanel;                                    // panel workgroups in front of everything: (row block, 64 columns of H)
+    double *G0, *H0;                               // the group's panels (panel w at G0 / H0 + w * pstride)
+    size_t pstride;
+    const double *Pg;                              // inverse of the group's diagonal super-block (ld = 128 wb_sz)
+    unsigned *cnt;                                 // cnt[0]: ticks of the kind-1 workgroups; cnt[1 + i]: panel ticks of row block i
+    unsigned *next;                                // work counter of the launch: the next work item to hand out
+    int total;                                     // work items: npanel + nhead + remainder
 };
 
+// One work item (panel workgroup, head tile, write-back tile or remainder tile) of a group's update.
 template <bool MULTI>
-__global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A, size_t ld, size_t pld, const GroupUpd P)
+__device__ __forceinline__ void group_update_item(double *__restrict__ A, size_t ld, size_t pld, const GroupUpd &P, int item,
+                                                  double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD])
 {
-    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
-    const int t = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    if (item < P.npanel) {
+        // ---- panel workgroup ----
+        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+        const int sz = P.wb_sz, b0 = P.wb_b0;
+        const int y = item % (2 * sz), w = y >> 1, ch = y & 1;
+        int i = item / (2 * sz);
+        const int irow = i;
+        if (i >= b0) i += sz;
+        const size_t pgld = (size_t)sz * T;
+        double4_t acc[2][4];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
+        const double *hsrc0 = P.Pg + (size_t)w * T + (size_t)ch * 64;
+        double *gcopy0 = (y == 0) ? P.G0 + (size_t)i * T : nullptr;
+        if (i > b0) {  // below the group: G_i = A[i, k]
+#pragma unroll 1
+            for (int v = 0; v < sz; ++v)
+                tile_product<false, 2>(acc, A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+                                       Hs[0], gcopy0 ? gcopy0 + (size_t)v * P.pstride : nullptr, pld);
+        } else {       // above the group: G_i = A[k, i]^T
+#pragma unroll 1
+            for (int v = 0; v < sz; ++v)
+                tile_product<true, 2>(acc, A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+                                      Hs[0], gcopy0 ? gcopy0 + (size_t)v * P.pstride : nullptr, pld);
+        }
+        double *Hw = P.H0 + (size_t)w * P.pstride + (size_t)i * T;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = wr * 64 + tn * 16 + l15;
+                    const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                    Hw[(size_t)r + (size_t)c * pld] = -acc[tm][tn][reg];
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(P.cnt + 1 + irow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int t = item - P.npanel;
     const bool head = t < P.nhead;
+    // wait until the panels of row blocks ra and rb (indices among the blocks outside the group) are complete
+    auto wait_rows = [&](int blk_a, int blk_b) {
+        if (tid == 0) {
+            const unsigned need = 2u * (unsigned)P.wb_sz;
+            const int ra = blk_a >= P.wb_b0 ? blk_a - P.wb_sz : blk_a, rb = blk_b >= P.wb_b0 ? blk_b - P.wb_sz : blk_b;
+            while (__hip_atomic_load(P.cnt + 1 + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need ||
+                   __hip_atomic_load(P.cnt + 1 + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+                __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    };
     int I, J;
     if (head && t >= P.wb_first) {
         // write-back of one tile of the group's new columns
@@ -586,7 +668,8 @@ __global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A,
         int i = e % P.wb_rows;
         const int w = e / P.wb_rows;
         if (i >= P.wb_b0) i += P.wb_sz;
-        panel_writeback_tile(A, ld, P.wb_b0 + w, i, P.wbH + (size_t)w * P.wb_stride, pld, Gs[0]);
+        wait_rows(i, i);
+        panel_writeback_tile(A, ld, P.wb_b0 + w, i, P.H0 + (size_t)w * P.pstride, pld, Gs[0]);
         I = J = -1;
     } else if (head) {
         int m = 0;
@@ -607,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A,
         I = ii;
         J = jj;
     }
+    if (I >= 0) wait_rows(I, J);
     if (I >= 0) {
         const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
         double *At = A + (size_t)I * T + (size_t)J * T * ld;
@@ -655,15 +739,50 @@ __global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A,
                     At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
                 }
     }
-    if (head && P.cnt) {
+    if (t < P.ndiag) {
         // publish: every wave's stores have left the CU, then one agent-scope release and the tick
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(P.cnt + (t < P.ndiag ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(P.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// The launch is PERSISTENT: two workgroups per compute unit of the stream's CU mask, each taking work items off one
+// device-wide counter until none are left.  Items are handed out in index order (so "panel first, head next" holds as
+// it would for dispatch order, and a waiting item can only wait for items that are already running); a compute unit that
+// is slower for any reason (a shader engine that lost a CU to the mask and still gets an equal share of a static grid,
+// the tail round of a static grid) simply takes fewer items; and the next item's operand loads are issued while the
+// previous item's stores drain, with no workgroup launch in between.
+template <bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_group_update(const GroupUpd Parg, double *__restrict__ A, size_t ld, size_t pld)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
+    __shared__ int s_item;
+    // the descriptor is read where it lies, in the kernel-argument segment (first argument = offset 0): indexing its
+    // arrays with run-time indices through a by-value copy would put the copy into scratch memory
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const GroupUpd __attribute__((address_space(4))) *kernarg_desc_t;
+    const GroupUpd &P = *(const GroupUpd *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Parg;
+#else
+    const GroupUpd &P = Parg;
+#endif
+    for (;;) {
+        if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(P.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= P.total) break;
+        // the leading dimensions are made opaque per iteration: otherwise every per-thread address offset of every path
+        // (hundreds of 64-bit values) is hoisted out of this loop as loop-invariant and spilled to scratch
+        size_t ld_i = ld, pld_i = pld;
+        asm volatile("" : "+s"(ld_i), "+s"(pld_i));
+        group_update_item<MULTI>(A, ld_i, pld_i, P, item, Gs, Hs);
+        __syncthreads();  // LDS and s_item are free again
     }
 }
 
@@ -673,9 +792,9 @@ __global__ __launch_bounds__(256, 2) void k_group_update(double *__restrict__ A,
 // Only Pg is serial work, and it is small: the m x m diagonal super-block is copied to a dense scratch matrix
 // (k_gather_diag) and swept there block by block -- k_pivot for the 128 x 128 pivot, then two tiny launches of tile
 // products (k_tile_jobs) for the other blocks of the scratch matrix -- while the bulk of the group's look-ahead work
-// (the previous group's update applied to this group's columns, all rows) runs beside it on another stream.  One
-// launch then forms H for every row block (k_group_panel, K = m) and one writes the new columns back
-// (k_group_writeback).  Per group: no per-pivot panel / slice launches over the whole matrix any more.
+// (the previous group's update applied to this group's columns, all rows) runs beside it inside the previous group's
+// update launch.  The group's own update launch then forms G and H for every row block in its front part (K = m) and
+// writes the new columns back.  Per group: no per-pivot panel / slice launches over the whole matrix any more.
 
 // Sg (m x m, ld = m, full storage) <- the diagonal super-block of A at block b0 (lower triangle authoritative)
 __global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ A, size_t ld, int b0, int m,
@@ -775,81 +894,14 @@ __global__ __launch_bounds__(256, 1) void k_tile_jobs(const TileJobs J)
             }
 }
 
-struct GroupPanels {
-    double *G0, *H0;  // panel w of the group = G0 + w * stride (the panels of a group are carved from one buffer)
-    size_t stride;
-};
-
-// Panel of a group: for every row block i outside the group, G_i = the group's m columns of row block i (read from the
-// lower triangle: A[i, k] for i below the group, A[k, i]^T for i above it) and H_i = -G_i Pg.  Workgroup = (row block i,
-// 64 of the m columns of H_i), K = m; the workgroups of the first 64 columns also keep the untransposed G_i for the
-// update launches.
-__global__ __launch_bounds__(256, 2) void k_group_panel(const double *__restrict__ A, size_t ld, int b0, int sz,
-                                                         const double *__restrict__ Pg, size_t pgld, const GroupPanels gp,
-                                                         size_t pld)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[KC][LDS_LD];
-    int i = blockIdx.x;
-    if (i >= b0) i += sz;
-    const int w = blockIdx.y >> 1, ch = blockIdx.y & 1;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double4_t acc[2][4];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
-    const double *hsrc0 = Pg + (size_t)w * T + (size_t)ch * 64;
-    double *gcopy0 = (blockIdx.y == 0) ? gp.G0 + (size_t)i * T : nullptr;
-    if (i > b0) {  // below the group: G_i = A[i, k]
-#pragma unroll 1
-        for (int v = 0; v < sz; ++v)
-            tile_product<false, 2>(acc, A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs, Hs,
-                                   gcopy0 ? gcopy0 + (size_t)v * gp.stride : nullptr, pld);
-    } else {       // above the group: G_i = A[k, i]^T
-#pragma unroll 1
-        for (int v = 0; v < sz; ++v)
-            tile_product<true, 2>(acc, A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs, Hs,
-                                  gcopy0 ? gcopy0 + (size_t)v * gp.stride : nullptr, pld);
-    }
-    double *Hw = gp.H0 + (size_t)w * gp.stride + (size_t)i * T;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                Hw[(size_t)r + (size_t)c * pld] = -acc[tm][tn][reg];
-            }
-}
-
-// The group's new column blocks: A[i, b0 + w] <- -H_w[i] for every row block i outside the group (transposed into
-// A[b0 + w, i] for the row blocks above it).  A launch of its own, after the panel: every panel workgroup reads the OLD
-// columns as its G operand.
-__global__ __launch_bounds__(256) void k_group_writeback(double *__restrict__ A, size_t ld, int b0, int sz,
-                                                          const GroupPanels gp, size_t pld)
-{
-    __shared__ __attribute__((aligned(16))) double Ts[KC][LDS_LD];
-    int i = blockIdx.x;
-    if (i >= b0) i += sz;
-    const int w = blockIdx.y;
-    panel_writeback_tile(A, ld, b0 + w, i, gp.H0 + (size_t)w * gp.stride, pld, Ts);
-}
-
-// Host driver of the block sweep: pivot groups of g blocks (g = 1 .. 4 by matrix size; GDCA_GROUP=g forces).
-// With a side stream (s1) it runs with look-ahead over two streams:
-//     side stream   U(p): ONE launch per group -- every tile outside group p, head first (k_group_update)
-//     main stream   the chain of group p+1 (high priority; a few CUs are kept free of U's workgroups for it):
-//                     wait for U(p)'s first counter (the next diagonal super-block carries update p)
-//                     M   Pg = inverse of the super-block: gather, sz x (k_pivot, two tile-job launches), scatter
-//                     wait for U(p)'s second counter (group p's columns written back, group p+1's columns updated)
-//                     Pn  G, H = -G Pg for every row block (k_group_panel)
-//                   then U(p+1) may start as soon as U(p) has drained.
-// Panels are double-buffered by group parity.  Without a side stream everything runs on s0 in order.
+// Host driver of the block sweep: pivot groups of g blocks (g = 1 .. 4 by matrix size; GDCA_GROUP=g forces).  Per
+// group p two things happen:
+//     M(p)  Pg = inverse of the group's diagonal super-block: gather, sz x (k_pivot, two tile-job launches), scatter
+//     U(p)  ONE launch (k_group_update): panel, look-ahead head, write-back, remainder -- everything else of the group
+// With a side stream (s1) they overlap: U(p) runs on the side stream; the main (high-priority) stream waits for U(p)'s
+// head counter (the next diagonal super-block carries update p) and runs M(p+1) on the few CUs that are kept free of
+// U's workgroups; U(p+1) follows U(p) on the side stream as soon as M(p+1) is done.  Panels are double-buffered by
+// group parity.  Without a side stream everything runs on s0 in order.
 void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
                              gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev, int max_upd_ev,
                              int *n_upd_launch, double *upd_flops)
@@ -868,15 +920,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
     const int ng = (nblk + g - 1) / g;
     hipEvent_t *Ep = sync_ev, *Eb = sync_ev + ng;
     const size_t pstride = (size_t)(ws.G[1] - ws.G[0]);
+    const int cstride = nblk + 2;  // counters per group: [0] head ticks, [1 + i] panel ticks of row block i, [nblk + 1] work counter
     auto base = [&](int p) { return p * g; };
     auto size = [&](int p) { return std::min(g, nblk - p * g); };
-    auto panels = [&](int p) {
-        GroupPanels gp{};
-        gp.G0 = ws.G[4 * (p & 1)];
-        gp.H0 = ws.H[4 * (p & 1)];
-        gp.stride = pstride;
-        return gp;
-    };
     // M: Pg of group p (and A_gg <- -Pg)
     auto super_pivot = [&](int p) {
         const int b0 = base(p), sz = size(p), m = sz * T;
@@ -926,106 +972,92 @@ void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pa
         }
         hipLaunchKernelGGL(k_scatter_diag, dim3(eg), dim3(256), 0, s0, A, ld, b0, m, (const double *)ws.Sg[cur], ws.Pg);
     };
-    auto group_panel = [&](int p) {
+    // U(p): panel, head (diagonal super-block of group p+1, the other rows of group p+1's columns, write-back of group
+    // p's columns), remainder.  Returns the head-counter target.
+    auto update = [&](hipStream_t st, int p) -> unsigned {
         const int b0 = base(p), sz = size(p);
-        if (nblk - sz <= 0) return;
-        hipLaunchKernelGGL(k_group_panel, dim3(nblk - sz, 2 * sz), dim3(256), 0, s0, (const double *)A, ld, b0, sz,
-                           (const double *)ws.Pg, (size_t)(sz * T), panels(p), ld);
-    };
-    // U(p).  ordered = with the look-ahead head (diagonal super-block of group p+1, write-back of group p, the other rows
-    // of group p+1's columns) and its two counters; otherwise the plain update of everything outside group p.
-    unsigned nA = 0, nB = 0;
-    auto update = [&](hipStream_t st, int p, bool ordered) {
-        const int b0 = base(p), sz = size(p);
-        const int nsz = (ordered && p + 1 < ng) ? size(p + 1) : 0, c0 = b0 + sz;
+        const int nsz = p + 1 < ng ? size(p + 1) : 0, c0 = b0 + sz;
         GroupUpd P{};
         for (int w = 0; w < 4; ++w) {
             P.G[w] = ws.G[4 * (p & 1) + std::min(w, sz - 1)];
             P.H[w] = ws.H[4 * (p & 1) + std::min(w, sz - 1)];
         }
         P.nop = sz;
-        int first = 0, mcol = 0;
-        for (int mm = 0; mm < nsz; ++mm, ++mcol) {  // diagonal super-block of the next group: rows mm .. nsz-1 of column mm
-            P.col[mcol] = c0 + mm;
-            P.first[mcol] = first;
-            P.lo1[mcol] = c0 + mm;
-            P.n1[mcol] = nsz - mm;
-            P.lo2[mcol] = 0;
+        int first = 0;
+        for (int mm = 0; mm < nsz; ++mm) {  // diagonal super-block of the next group: rows mm .. nsz-1 of column mm
+            P.col[mm] = c0 + mm;
+            P.first[mm] = first;
+            P.lo1[mm] = c0 + mm;
+            P.n1[mm] = nsz - mm;
+            P.lo2[mm] = 0;
             first += nsz - mm;
         }
         P.ndiag = first;
         const int nrest = nblk - sz - nsz;
-        int ncol_rest = 0;
-        for (int mm = 0; mm < nsz && nrest > 0; ++mm, ++ncol_rest) {  // the other rows: above group p, then below group p+1
+        const int ncol_rest = nrest > 0 ? nsz : 0;
+        for (int mm = 0; mm < ncol_rest; ++mm) {  // the other rows: above group p, then below group p+1
             const int e = nsz + mm;
             P.col[e] = c0 + mm;
+            P.first[e] = first;
             P.lo1[e] = 0;
             P.n1[e] = b0;
             P.lo2[e] = c0 + nsz;
+            first += nrest;
         }
-        // workgroup order of the head: diagonal entries, rest entries, write-back
         P.ncol = nsz + ncol_rest;
+        P.first[P.ncol] = first;
+        P.wb_first = first;
         P.wb_rows = nblk - sz;
         P.wb_b0 = b0;
         P.wb_sz = sz;
-        const int nwb = ordered ? (nblk - sz) * sz : 0;
-        for (int mm = 0; mm < ncol_rest; ++mm) {
-            P.first[nsz + mm] = first;
-            first += nrest;
-        }
-        P.first[P.ncol] = first;
-        P.wb_first = first;
-        P.nhead = first + nwb;
-        P.wbH = ws.H[4 * (p & 1)];
-        P.wb_stride = pstride;
-        P.cnt = ordered ? ws.cnt + 2 * p : nullptr;
-        nA = (unsigned)P.ndiag;
-        nB = (unsigned)(P.nhead - P.ndiag);
+        P.nhead = first + (nblk - sz) * sz;
+        P.npanel = (nblk - sz) * 2 * sz;
+        P.G0 = ws.G[4 * (p & 1)];
+        P.H0 = ws.H[4 * (p & 1)];
+        P.pstride = pstride;
+        P.Pg = ws.Pg;
+        P.cnt = ws.cnt + (size_t)p * cstride;
+        P.next = P.cnt + nblk + 1;
         P.skip_lo = b0;
         P.skip_n = sz + nsz;
         const int mrem = nblk - P.skip_n;
         const long long nbig = mrem > 0 ? (long long)mrem * (mrem + 1) / 2 : 0;
-        const unsigned grid = (unsigned)(P.nhead + nbig);
-        if (grid == 0) return;
+        P.total = (int)(P.npanel + P.nhead + nbig);
+        if (P.total == 0) return 0u;
+        const unsigned grid = (unsigned)std::min<long long>(P.total, 2 * ws.update_cus);
         const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
         if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
         if (sz > 1)
-            hipLaunchKernelGGL((k_group_update<true>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+            hipLaunchKernelGGL((k_group_update<true>), dim3(grid), dim3(256), 0, st, P, A, ld, ld);
         else
-            hipLaunchKernelGGL((k_group_update<false>), dim3(grid), dim3(256), 0, st, A, ld, ld, P);
+            hipLaunchKernelGGL((k_group_update<false>), dim3(grid), dim3(256), 0, st, P, A, ld, ld);
         if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
         ++nl;
-        fl += tile_flops * (double)(first + nbig) * (double)sz;
+        fl += tile_flops * ((double)(first + nbig) * (double)sz + (double)(nblk - sz) * (double)(sz * sz));
+        return (unsigned)P.ndiag;
     };
 
-    if (la) (void)hipMemsetAsync(ws.cnt, 0, (size_t)2 * ng * sizeof(unsigned), s0);
+    (void)hipMemsetAsync(ws.cnt, 0, (size_t)ng * cstride * sizeof(unsigned), s0);
     super_pivot(0);
     if (nblk == size(0)) {  // a single group: nothing to update
         if (n_upd_launch) *n_upd_launch = 0;
         if (upd_flops) *upd_flops = 0.0;
         return;
     }
-    group_panel(0);
     if (!la) {
         // serial schedule on s0
         for (int p = 0; p < ng; ++p) {
-            if (p > 0) {
-                super_pivot(p);
-                group_panel(p);
-            }
-            hipLaunchKernelGGL(k_group_writeback, dim3(nblk - size(p), size(p)), dim3(256), 0, s0, A, ld, base(p), size(p), panels(p), ld);
-            update(s0, p, false);
+            if (p > 0) super_pivot(p);
+            (void)update(s0, p);
         }
     } else {
         (void)hipEventRecord(Ep[0], s0);
         for (int p = 0; p < ng; ++p) {
             (void)hipStreamWaitEvent(s1, Ep[p], 0);
-            update(s1, p, true);
+            const unsigned nA = update(s1, p);
             if (p + 1 < ng) {
-                if (nA) (void)hipStreamWaitValue32(s0, ws.cnt + 2 * p, nA, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                if (nA) (void)hipStreamWaitValue32(s0, ws.cnt + (size_t)p * cstride, nA, hipStreamWaitValueGte, 0xFFFFFFFFu);
                 super_pivot(p + 1);
-                if (nB) (void)hipStreamWaitValue32(s0, ws.cnt + 2 * p + 1, nB, hipStreamWaitValueGte, 0xFFFFFFFFu);
-                group_panel(p + 1);
                 (void)hipEventRecord(Ep[p + 1], s0);
             }
         }
