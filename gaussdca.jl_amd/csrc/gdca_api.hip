@@ -33,11 +33,10 @@ struct gdca_ctx {
     char err[512];
     // named device buffers (grow-only)
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
-    hipStream_t side;          // side stream of the SPD inverse: the big trailing updates
-    int ncu, side_cus;         // compute units of the device / of the side stream's CU mask
-    bool lookahead;
-    hipEvent_t sev[MAX_EV];    // cross-stream ordering events
-    int n_sev;
+    hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
+    int ncu;                   // compute units of the device
+    int *item0_host;           // pinned staging of the sweep's item table
+    int item0_cap;
     gdca_buf scratch[N_SCRATCH];
     gdca_dev_scalars *sc_host;  // pinned
     hipEvent_t ev[MAX_EV];
@@ -127,39 +126,11 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     }
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
-    ctx->lookahead = getenv("GDCA_NO_LOOKAHEAD") == nullptr;
-    // The side stream carries the big trailing updates of the SPD inverse.  Its CU mask leaves a few compute units out, so the small, latency-bound kernels of the pivot chain on
-    // the main stream (the single-workgroup pivot, the tile jobs on a group's diagonal super-block) always find idle CUs
-    // instead of waiting for a register-hungry update workgroup to retire.  A workgroup is bound to an XCD round-robin at
-    // dispatch and then looks for a CU with room INSIDE that XCD, so every XCD needs its own idle CU: the reserved set is
-    // one CU per XCD (measured: a small high-priority kernel beside a chip-filling one starts in 7.5 us with it, 15-45 us
-    // without, tools/ubench_cumap.hip).  Mask bit i is XCD i % 8, shader engine (i / 8) % 4, CU i / 32 of that engine
-    // (measured, same tool).  GDCA_RESERVE_CU=k reserves k CUs per XCD (default 1; 0 = no mask).
-    ctx->side = nullptr;
-    const int reserve = getenv("GDCA_RESERVE_CU") ? atoi(getenv("GDCA_RESERVE_CU")) : 1;
     {
         hipDeviceProp_t prop0;
         ctx->ncu = hipGetDeviceProperties(&prop0, device_id) == hipSuccess ? prop0.multiProcessorCount : 256;
-        ctx->side_cus = ctx->ncu;
     }
-    if (reserve > 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount == 256) {
-            uint32_t mask[8];
-            for (int w = 0; w < 8; ++w) mask[w] = 0xFFFFFFFFu;
-            for (int r = 0; r < reserve && r < 16; ++r)
-                for (int x = 0; x < 8; ++x) {
-                    const int bit = 8 * r + x;  // k-th CU of XCD x: shader engines first (bits 8 r + x, r = 0 .. 3), then CU 1 ...
-                    mask[bit / 32] &= ~(1u << (bit % 32));
-                }
-            if (hipExtStreamCreateWithCUMask(&ctx->side, 8, mask) != hipSuccess) {
-                (void)hipGetLastError();
-                ctx->side = nullptr;
-            } else {
-                ctx->side_cus = 256 - 8 * (reserve < 16 ? reserve : 16);
-            }
-        }
-    }
+    ctx->side = nullptr;
     // from here on every failure goes through gdca_ctx_destroy, which frees whatever has been created so far
     if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
         ctx->side = nullptr;
@@ -234,7 +205,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
         free(ctx->gate);
     }
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i < ctx->n_sev; ++i) (void)hipEventDestroy(ctx->sev[i]);
+    if (ctx->item0_host) (void)hipHostFree(ctx->item0_host);
     if (ctx->ev_weights) (void)hipEventDestroy(ctx->ev_weights);
     if (ctx->ev_meff) (void)hipEventDestroy(ctx->ev_meff);
     if (ctx->side) {
@@ -275,16 +246,6 @@ static gdca_status need_events(gdca_ctx *ctx, int n)
     while (ctx->n_ev < n) {
         HIPCHK(hipEventCreate(&ctx->ev[ctx->n_ev]));
         ++ctx->n_ev;
-    }
-    return GDCA_OK;
-}
-
-static gdca_status need_sync_events(gdca_ctx *ctx, int n)
-{
-    if (n > MAX_EV) return fail(ctx, GDCA_EINVAL, "matrix too large for the event pool%s%s", "", "");
-    while (ctx->n_sev < n) {
-        HIPCHK(hipEventCreateWithFlags(&ctx->sev[ctx->n_sev], hipEventDisableTiming));
-        ++ctx->n_sev;
     }
     return GDCA_OK;
 }
@@ -374,36 +335,44 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     hipStream_t s = ctx->stream;
     const size_t pbytes = (size_t)n_pad * GDCA_TILE * sizeof(double);
     const int nblk = n_pad / GDCA_TILE;
-    const bool la = ctx->lookahead && nblk >= 3;
-    // 2 x 4 panels G and H (pivot groups of up to four blocks, double-buffered by group parity; without look-ahead one
-    // set), one 128 x 128 pivot inverse, three 512 x 512 scratch matrices for a group's diagonal super-block
-    const int npan = la ? 8 : 4;
+    // 2 x 4 panels G and H (pivot groups of up to four blocks, double-buffered by group parity), one 128 x 128 pivot
+    // inverse, four 512 x 512 scratch matrices for a group's diagonal super-block, the sweep's flags and item table
     const size_t sg = (size_t)4 * GDCA_TILE * 4 * GDCA_TILE * sizeof(double);
-    CHK(ensure(ctx, ctx->G, (size_t)npan * pbytes));
-    CHK(ensure(ctx, ctx->H, (size_t)npan * pbytes));
+    const size_t fbytes = gdca_inverse_flag_bytes(n_pad);
+    CHK(ensure(ctx, ctx->G, (size_t)8 * pbytes));
+    CHK(ensure(ctx, ctx->H, (size_t)8 * pbytes));
     CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
-    CHK(ensure(ctx, ctx->Sg, 3 * sg + (size_t)(nblk + 2) * (nblk + 2) * sizeof(unsigned)));
+    CHK(ensure(ctx, ctx->Sg, 4 * sg + fbytes + (size_t)2 * (nblk + 2) * sizeof(int)));
+    if (ctx->item0_cap < 2 * (nblk + 2)) {
+        if (ctx->item0_host) HIPCHK(hipHostFree(ctx->item0_host));
+        ctx->item0_host = nullptr;
+        ctx->item0_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&ctx->item0_host, (size_t)2 * (nblk + 2) * sizeof(int), hipHostMallocDefault));
+        ctx->item0_cap = 2 * (nblk + 2);
+    }
     gdca_inverse_ws ws;
     for (int w = 0; w < 8; ++w) {
-        ws.G[w] = (double *)((char *)ctx->G.p + (size_t)(w % npan) * pbytes);
-        ws.H[w] = (double *)((char *)ctx->H.p + (size_t)(w % npan) * pbytes);
+        ws.G[w] = (double *)((char *)ctx->G.p + (size_t)w * pbytes);
+        ws.H[w] = (double *)((char *)ctx->H.p + (size_t)w * pbytes);
     }
     ws.P = (double *)ctx->P.p;
     ws.Sg[0] = (double *)ctx->Sg.p;
     ws.Sg[1] = (double *)((char *)ctx->Sg.p + sg);
-    ws.Pg = (double *)((char *)ctx->Sg.p + 2 * sg);
-    ws.cnt = (unsigned *)((char *)ctx->Sg.p + 3 * sg);
-    ws.update_cus = la ? ctx->side_cus : ctx->ncu;
-    if (la) CHK(need_sync_events(ctx, 2 * nblk));
+    ws.Pg[0] = (double *)((char *)ctx->Sg.p + 2 * sg);
+    ws.Pg[1] = (double *)((char *)ctx->Sg.p + 3 * sg);
+    ws.flags = (unsigned *)((char *)ctx->Sg.p + 4 * sg);
+    ws.flags_bytes = fbytes;
+    ws.item0_dev = (int *)((char *)ctx->Sg.p + 4 * sg + fbytes);
+    ws.item0_host = ctx->item0_host;
+    ws.update_cus = ctx->ncu;
     hipEvent_t *uev = nullptr;
     int max_ev = 0;
     if (timed) {
-        CHK(need_events(ctx, 16 + 2 * nblk));
+        CHK(need_events(ctx, 18));
         uev = ctx->ev + 16;
-        max_ev = ctx->n_ev - 16;
+        max_ev = 2;
     }
-    gdca_launch_spd_inverse(s, la ? ctx->side : nullptr, (double *)ctx->A.p, n_pad, ws,
-                            (gdca_dev_scalars *)ctx->sc.p, n, ctx->sev, uev, max_ev, n_upd, upd_flops);
+    gdca_launch_spd_inverse(s, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n, uev, max_ev, n_upd, upd_flops);
     return check_launch(ctx, "spd_inverse");
 }
 

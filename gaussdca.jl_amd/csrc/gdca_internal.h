@@ -83,22 +83,23 @@ void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int
 
 // ---- k_inverse.hip -------------------------------------------------------------------------
 struct gdca_inverse_ws {
-    double *G[8];   // n_pad x 128 panels: [4 (p & 1) + w] = column block w of pivot group p (double-buffered by group parity)
-    double *H[8];   // n_pad x 128 panels, -G * Pg
-    double *P;      // 128 x 128 inverse of one pivot block
-    double *Sg[2];  // 512 x 512 dense scratch copies of a group's diagonal super-block (ping-pong)
-    double *Pg;     // 512 x 512: inverse of the group's diagonal super-block
-    unsigned *cnt;  // (n_pad / 128 + 2) counters per pivot group: head ticks, panel ticks per row block, work counter
-    int update_cus; // compute units the update launches may use (the CU mask of the stream they run on)
+    double *G[8];      // n_pad x 128 panels: [4 (p & 1) + w] = column block w of pivot group p (double-buffered by group parity)
+    double *H[8];      // n_pad x 128 panels, -G * Pg
+    double *P;         // 128 x 128 inverse of one pivot block
+    double *Sg[2];     // 512 x 512 dense scratch copies of a group's diagonal super-block (ping-pong)
+    double *Pg[2];     // 512 x 512: inverse of a group's diagonal super-block, by group parity
+    unsigned *flags;   // dependency flags of the sweep (zeroed per inverse by the launcher)
+    size_t flags_bytes;
+    int *item0_host;   // pinned: first work item of every group's sequence in the main list and in the M list (2 x (n_pad / 128 + 2) entries)
+    int *item0_dev;
+    int update_cus;    // compute units of the device
 };
-// In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles
-// authoritative): A <- -inverse(A) by the block symmetric sweep.  info (device) gets the
-// 1-based index of the first non-positive pivot, if any.
-// s1 == nullptr: serial schedule on s0.  Otherwise look-ahead over two streams; sync_ev must hold
-// 2 * (n_pad / 128) events.  upd_ev (optional, 2 per update launch) are recorded on the stream the launch runs on.
-void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
-                             gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev,
-                             int max_upd_ev, int *n_upd_launch, double *upd_flops);
+// In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles authoritative): A <- -inverse(A) by
+// the block symmetric sweep, ONE persistent launch on stream s.  sc->info gets the 1-based index of the first
+// non-positive pivot, if any.  upd_ev (optional, 2 events) are recorded around the launch.
+size_t gdca_inverse_flag_bytes(int n_pad);
+void gdca_launch_spd_inverse(hipStream_t s, double *A, int n_pad, const gdca_inverse_ws &ws, gdca_dev_scalars *sc, int n_real,
+                             hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch, double *upd_flops);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
 
 // ---- k_score.hip ---------------------------------------------------------------------------

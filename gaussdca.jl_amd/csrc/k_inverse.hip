@@ -21,6 +21,8 @@
 // [k][row] with a 128-byte pad per k-row, which puts the four k-rows a ds_read_b64 touches on
 // disjoint bank halves (conflict-free).
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "gdca_internal.h"
 
@@ -156,41 +158,48 @@ __device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_
     MicroStep<0>::run(v, l15, lq, colsrc, index_base, badj);
 }
 
-// Ain (ld = ldin) is read, Aout (ld = ldout) receives -P; the two may be the same tile.
-__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout,
-                                                          double *__restrict__ P, size_t pld, gdca_dev_scalars *sc, int index0,
-                                                          int n_real)
+// The blocked sweep as a device routine for NW waves holding NT tiles each (NW * NT = 36): NW = 12, NT = 3 (a whole CU
+// for the pivot: the stand-alone kernel) or NW = 4, NT = 9 (one 256-thread workgroup of the persistent sweep kernel).
+// Ain (ld = ldin) is read, Aout (ld = ldout) receives -P; the two may be the same tile.  Gs, Ns: MB * PV_ROW doubles of
+// LDS each; Pms: 2 * MB * MB doubles; badj: one int, zeroed by the caller before a barrier.
+template <int NW, int NT>
+__device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
+                                            size_t pld, double *Gs, double *Ns, double (*Pms)[MB][MB], int *badj)
 {
-    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];  // -Pm of micro-block K in Pms[K & 1]
-    __shared__ int badj;
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    static_assert(NW * NT == 36 && (NW == 12 || NW == 4), "36 lower-triangular micro-tiles");
+    const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) badj = 0;
-
-    // tile ownership: waves 0..7: (w, w) + off-diagonal tiles 2w, 2w+1; waves 8..11: off-diagonal tiles 16 + 3 (w-8) + {0,1,2}
-    // (off-diagonal tile e <-> (rb, cb), rb > cb, e = rb (rb-1) / 2 + cb)
-    int trb[3], tcb[3];
+    // off-diagonal tile e <-> (rb, cb), rb > cb, e = rb (rb-1) / 2 + cb
     auto offdiag = [](int e, int &rb, int &cb) {
         int r = 1;
         while ((r + 1) * r / 2 <= e) ++r;
         rb = r;
         cb = e - r * (r - 1) / 2;
     };
-    if (wv < NMB) {
-        trb[0] = tcb[0] = wv;
-        offdiag(2 * wv, trb[1], tcb[1]);
-        offdiag(2 * wv + 1, trb[2], tcb[2]);
-    } else {
+    // tile ownership.  NW = 12: waves 0..7 own (w, w) + off-diagonal tiles 2w, 2w+1; waves 8..11 three off-diagonal tiles.
+    // NW = 4: wave w owns (w, w), (w+4, w+4) and off-diagonal tiles 7w .. 7w+6.  Slot 0 is always the diagonal tile whose
+    // micro-pivot this wave computes next (NW = 4: slots 0 and 1 are swapped once the first one has been used).
+    int trb[NT], tcb[NT];
+    if (NW == 12) {
+        if (wv < NMB) {
+            trb[0] = tcb[0] = wv;
+            offdiag(2 * wv, trb[1], tcb[1]);
+            offdiag(2 * wv + 1, trb[2], tcb[2]);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) offdiag(16 + 3 * (wv - NMB) + t, trb[t], tcb[t]);
+            for (int t = 0; t < 3; ++t) offdiag(16 + 3 * (wv - NMB) + t, trb[t], tcb[t]);
+        }
+    } else {
+        trb[0] = tcb[0] = wv;
+        trb[1] = tcb[1] = wv + 4;
+#pragma unroll
+        for (int t = 2; t < NT; ++t) offdiag(7 * wv + t - 2, trb[t], tcb[t]);
     }
 
     // load: acc[t][reg] = D[16 rb + l15][16 cb + lq + 4 reg]; diagonal tiles mirror their lower triangle
-    double acc[3][4];
+    double acc[NT][4];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
@@ -201,54 +210,67 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size
             }
             acc[t][reg] = Ain[(size_t)r + (size_t)c * ldin];
         }
-    __syncthreads();  // badj initialised
 
     // K = -1 is the prologue: only the micro-pivot of micro-block 0 (no update precedes it); the same code as the
-    // look-ahead micro-pivots of the loop, so that the kernel carries ONE copy of the unrolled 16-step sweep (the pivot
-    // is launched once per block with other kernels in between: its instructions are fetched cold every time)
+    // look-ahead micro-pivots of the loop, so that there is ONE copy of the unrolled 16-step sweep
 #pragma unroll 1
     for (int K = -1; K < NMB; ++K) {
-      if (K >= 0) {
-        // ---- phase A: the old column block K into Gs ([kk][row]); rows of micro-block K of both images ----
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (tcb[t] == K && trb[t] > K) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Gs[pv_off(lq + 4 * reg) + MB * trb[t] + l15] = acc[t][reg];
-            } else if (trb[t] == K && tcb[t] < K) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Gs[pv_off(l15) + MB * tcb[t] + lq + 4 * reg] = acc[t][reg];
-            }
-        }
-        __syncthreads();  // Gs complete; Pms[K & 1] (written in the previous update phase) visible
-        // ---- phase B: Ns = -(G Pm) for the row blocks != K (waves 0..7, one row block each); specials by waves 8, 9 ----
-        if (wv < NMB && wv != K) {
-            double4_t g = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const int kk = 4 * t4 + lq;
-                const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
-                const double a = Pms[K & 1][lo][hi];                       // -Pm(l15, kk), lower triangle authoritative
-                const double b = Gs[pv_off(kk) + MB * wv + l15];           // G(16 wv + l15, kk)
-                g = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, g, 0, 0, 0);
-            }
-            // lane holds -(G Pm)(16 wv + l15, lq + 4 reg)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Ns[pv_off(lq + 4 * reg) + MB * wv + l15] = g[reg];
-        } else if (wv == NMB) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                Gs[pv_off(lq + 4 * reg) + MB * K + l15] = (l15 == lq + 4 * reg) ? -1.0 : 0.0;
-        } else if (wv == NMB + 1) {
+        if (NW == 4 && K == 3) {
+            // from now on the look-ahead micro-pivots are those of the second diagonal tile of each wave
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int kk = lq + 4 * reg;
-                const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
-                Ns[pv_off(kk) + MB * K + l15] = -Pms[K & 1][lo][hi];       // +Pm(l15, kk)
+                const double x = acc[0][reg];
+                acc[0][reg] = acc[1][reg];
+                acc[1][reg] = x;
             }
+            const int x = trb[0];
+            trb[0] = tcb[0] = trb[1];
+            trb[1] = tcb[1] = x;
         }
-        __syncthreads();
-      }
+        if (K >= 0) {
+            // ---- phase A: the old column block K into Gs ([kk][row]) ----
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (tcb[t] == K && trb[t] > K) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) Gs[pv_off(lq + 4 * reg) + MB * trb[t] + l15] = acc[t][reg];
+                } else if (trb[t] == K && tcb[t] < K) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) Gs[pv_off(l15) + MB * tcb[t] + lq + 4 * reg] = acc[t][reg];
+                }
+            }
+            __syncthreads();  // Gs complete; Pms[K & 1] (written in the previous update phase) visible
+            // ---- phase B: Ns = -(G Pm) for the row blocks != K; the rows of micro-block K of both images ----
+            for (int rb = wv; rb < NMB; rb += NW) {
+                if (rb == K) continue;
+                double4_t g = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int kk = 4 * t4 + lq;
+                    const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
+                    const double a = Pms[K & 1][lo][hi];                       // -Pm(l15, kk), lower triangle authoritative
+                    const double b = Gs[pv_off(kk) + MB * rb + l15];           // G(16 rb + l15, kk)
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, g, 0, 0, 0);
+                }
+                // lane holds -(G Pm)(16 rb + l15, lq + 4 reg)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Ns[pv_off(lq + 4 * reg) + MB * rb + l15] = g[reg];
+            }
+            if (wv == (NW == 12 ? NMB : (K & 3))) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    Gs[pv_off(lq + 4 * reg) + MB * K + l15] = (l15 == lq + 4 * reg) ? -1.0 : 0.0;
+            }
+            if (wv == (NW == 12 ? NMB + 1 : (K & 3))) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int kk = lq + 4 * reg;
+                    const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
+                    Ns[pv_off(kk) + MB * K + l15] = -Pms[K & 1][lo][hi];       // +Pm(l15, kk)
+                }
+            }
+            __syncthreads();
+        }
         // ---- phase C: every tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T ----
         auto update_tile = [&](int t) {
             double4_t c4;
@@ -266,23 +288,23 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size
             for (int reg = 0; reg < 4; ++reg) acc[t][reg] = c4[reg];
         };
         if (K >= 0) update_tile(0);
-        if (K + 1 < NMB && wv == K + 1) {
+        if (K + 1 < NMB && wv == (NW == 12 ? K + 1 : ((K + 1) & 3))) {
             // look-ahead: the next micro-pivot, beside the other waves' updates
             double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
-            micro_pivot(v, lane, MB * (K + 1), &badj);
+            micro_pivot(v, lane, MB * (K + 1), badj);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
         }
         if (K >= 0) {
-            update_tile(1);
-            update_tile(2);
+#pragma unroll
+            for (int t = 1; t < NT; ++t) update_tile(t);
             __syncthreads();
         }
     }
 
-    // D = -inverse (lower-triangular tiles).  P = -D and A_KK = D, both as full symmetric matrices
+    // D = -inverse (lower-triangular tiles).  P = -D and the output tile = D, both as full symmetric matrices
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
@@ -296,7 +318,22 @@ __global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size
                 }
             }
         }
-    if (tid == 0 && badj != 0 && (index0 + badj) <= n_real) {
+}
+
+// Stand-alone form (one launch = one 128 x 128 block on a whole CU): used by tools/test_pivot.hip.
+__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout,
+                                                          double *__restrict__ P, size_t pld, gdca_dev_scalars *sc, int index0,
+                                                          int n_real)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];  // -Pm of micro-block K in Pms[K & 1]
+    __shared__ int badj;
+    if (threadIdx.x == 0) badj = 0;
+    __syncthreads();
+    pivot_block<12, 3>(Ain, ldin, Aout, ldout, P, pld, Gs, Ns, Pms, &badj);
+    __syncthreads();
+    if (threadIdx.x == 0 && badj != 0 && (index0 + badj) <= n_real) {
         if (sc->info == 0) sc->info = index0 + badj;
     }
 }
@@ -548,337 +585,305 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
     }
 }
 
-// ---- trailing update: up to four pivots per launch -------------------------------------------------------------
-// One launch applies the rank-128 updates of the nop <= 4 pivots of a group (K = 128 nop): lower-triangle tiles
-//       A_IJ += sum_w G_w[I] H_w[J]^T,     H_w = -(G Pg)_w,
-// so the C tile is read and written once per nop updates and a workgroup's launch / first-chunk / store-drain
-// overhead is paid once per nop times the work (with one pivot per launch the update is HBM-bound).
+// =====================================================================================================================
+// The sweep as ONE persistent launch
+// =====================================================================================================================
+// Pivots are taken in GROUPS of sz <= 4 consecutive 128-blocks (m = 128 sz columns), each swept as one pivot of width m:
+//       Pg = (A_gg)^-1 (m x m),   G = A_{.,g},   H = -G Pg,   A_ij += H_i G_j^T (K = m),   A_{.,g} <- -H,   A_gg <- -Pg,
+// so the C tile of a trailing-update product is read and written once per sz rank-128 updates (with one pivot per pass
+// the update is HBM-bound) and a tile's per-item overheads are paid once per sz times the work.
 //
-// The launch covers every tile outside the group's own blocks, in an ORDER that serves the look-ahead: workgroups are
-// dispatched by ascending block index, and the HEAD of the grid holds what the pivot chain of the NEXT group waits for,
-//   1. the tiles inside the next group's diagonal super-block              -> counter cnt[0] (one tick per workgroup)
-//   2. the write-back of this group's new columns (A[., g] <- -H)           -> counter cnt[1]
-//   3. the other tiles in the next group's columns (all remaining rows)     -> counter cnt[1]
-// followed by the big remainder (every tile over the blocks outside [skip_lo, skip_lo + skip_n) = this group and the
-// next).  A kind-1 workgroup makes its stores visible device-wide (agent-scope release) and ticks cnt[0]; the main
-// stream waits on the counter VALUE (hipStreamWaitValue32): the next group's pivot chain starts ~one tile time after
-// the launch does, while the remainder keeps the chip busy -- no separate look-ahead launches competing with the
-// update for compute units, no kernel boundary between look-ahead and bulk.
+// The whole inverse is a list of WORK ITEMS, cut so that every item is one workgroup's job of tens of microseconds, and
+// ordered so that every item depends only on items EARLIER in the list:
+//   MAIN list, for group p = 0, 1, ...
+//     panel(p)     (row block i, 64 of the m columns):  G_i, H_i = -G_i Pg            needs Pg(p), the group's columns of row i
+//     diag2(p+2)   tiles of update p inside the diagonal super-block of group p+2      (early: the chain of that group needs them)
+//     rest(p+1)    the tiles of update p in the next group's columns (rows outside both groups)
+//     wb(p)        write the group's new columns back (A[., g] <- -H)
+//     rem(p)       every other tile of update p
+//   M list (the serial chain), for group q = 0, 1, ...
+//     M(q)         Pg(q): gather the diagonal super-block into a dense scratch matrix, sweep it block by block (128 x 128
+//                  pivot, then tile products for the other blocks of the scratch matrix), scatter -Pg back
+//     mpanel(q)    the panel items of the NEXT group's row blocks
+//     diag(q+1)    the tiles of update q inside the next group's diagonal super-block  -> M(q+1) can start
+//   The chain never waits for the bulk of an update, only for the early diag2 / rest items of the previous group.
+// ONE launch of 2 workgroups per compute unit runs the list: a workgroup takes the next item off a device-wide counter,
+// waits (one lane polling, s_sleep) until the few flags the item depends on are set, does it, publishes its result
+// (agent-scope release) and sets the item's own flag.  Items are handed out in list order, so an item can only wait for
+// items that somebody already holds: no deadlock.  The serial part of a group -- M(p+1), some dozen small items on a
+// handful of workgroups -- runs while the ~3000 remainder tiles of update p keep every other workgroup busy; the tail of
+// update p overlaps the head of update p+1; nothing is a kernel boundary, a stream, an event or a priority.
 //
-// In FRONT of all tiles the same launch carries the group's PANEL: workgroup (row block i, 64 of the 128 nop columns)
-// forms G_i = the group's columns of row block i (from the lower triangle: A[i, k] below the group, A[k, i]^T above it)
-// and H_i = -G_i Pg (K = 128 nop), stores them in the panel buffers and ticks row block i's counter (2 nop ticks = the
-// row block is ready).  A tile (I, J) waits for row blocks I and J before it touches its operands, the write-back of
-// row block i waits for row block i (its panel workgroups are the ones that read the OLD columns).  Workgroups are
-// dispatched in index order and panel workgroups never wait, so the waits cannot deadlock.  Kind 2 and kind 3 need no
-// counter any more: the next group's update is a later launch on the same stream.
-// Head part: up to 8 pseudo-columns; entry m covers the tiles (b, col[m]) for n1[m] blocks b from lo1[m] and then
-// blocks from lo2[m] on; first[m] .. first[m+1]-1 are its workgroups; entries below ndiag_cols are the diagonal
-// super-block.
-struct GroupUpd {
-    const double *G[4];
-    const double *H[4];
-    int nop;
-    int skip_lo, skip_n;                           // remainder
-    int ncol, ndiag;                               // head: entries; workgroups of kind 1
-    int col[8], first[9], lo1[8], n1[8], lo2[8];
-    int wb_first, wb_rows, wb_b0, wb_sz, nhead;    // kind 2: workgroups [wb_first, nhead): (row block, column w of the group)
-    int npanel;                                    // panel workgroups in front of everything: (row block, 64 columns of H)
-    double *G0, *H0;                               // the group's panels (panel w at G0 / H0 + w * pstride)
+// Flags (device memory, zeroed by the host before the launch):
+//   gen[I][J]   how many groups have been applied to tile (I, J), I >= J: every group touches every tile exactly once
+//               (update, write-back or scatter), so "group p may touch it" is gen == p, and it leaves gen = p + 1
+//   rb[p][i]    panel items of row block i done in group p (2 sz = complete)
+//   mc[q]       M items of group q done (levels are thresholds of this one counter)
+//   done[p]     tile and write-back items of group p done (guards the reuse of the double-buffered panels / Pg)
+struct SweepDesc {
+    double *A;
+    size_t ld;
+    int nblk, g, ng;
+    double *G0, *H0;       // panels: parity q, column w of the group at G0 + (4 q + w) * pstride
     size_t pstride;
-    const double *Pg;                              // inverse of the group's diagonal super-block (ld = 128 wb_sz)
-    unsigned *cnt;                                 // cnt[0]: ticks of the kind-1 workgroups; cnt[1 + i]: panel ticks of row block i
-    unsigned *next;                                // work counter of the launch: the next work item to hand out
-    int total;                                     // work items: npanel + nhead + remainder
+    double *Sg0, *Sg1;     // dense scratch copies of a group's diagonal super-block (ping-pong), ld = 128 sz
+    double *Pg0, *Pg1;     // Pg by group parity, ld = 128 sz
+    double *Pw;            // 128 x 128: inverse of the current pivot block
+    unsigned *gen, *rb, *mc, *done, *next, *next_m, *mcu;
+    const int *item0;      // [ng + 1]: first item of group p's sequence in the main list
+    const int *mitem0;     // [ng + 1]: first item of M(q) in the M list
+    int total, total_m;
+    int n_mcu;             // compute units to elect for the M list (<= 16)
+    int n_real;
+    gdca_dev_scalars *sc;
+    unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
 };
 
-// One work item (panel workgroup, head tile, write-back tile or remainder tile) of a group's update.
-template <bool MULTI>
-__device__ __forceinline__ void group_update_item(double *__restrict__ A, size_t ld, size_t pld, const GroupUpd &P, int item,
-                                                  double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD])
+__device__ __forceinline__ unsigned flag_load(const unsigned *p)
 {
-    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
-    if (item < P.npanel) {
-        // ---- panel workgroup ----
-        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-        const int sz = P.wb_sz, b0 = P.wb_b0;
-        const int y = item % (2 * sz), w = y >> 1, ch = y & 1;
-        int i = item / (2 * sz);
-        const int irow = i;
-        if (i >= b0) i += sz;
-        const size_t pgld = (size_t)sz * T;
-        double4_t acc[2][4];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
-        const double *hsrc0 = P.Pg + (size_t)w * T + (size_t)ch * 64;
-        double *gcopy0 = (y == 0) ? P.G0 + (size_t)i * T : nullptr;
-        if (i > b0) {  // below the group: G_i = A[i, k]
-#pragma unroll 1
-            for (int v = 0; v < sz; ++v)
-                tile_product<false, 2>(acc, A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
-                                       Hs[0], gcopy0 ? gcopy0 + (size_t)v * P.pstride : nullptr, pld);
-        } else {       // above the group: G_i = A[k, i]^T
-#pragma unroll 1
-            for (int v = 0; v < sz; ++v)
-                tile_product<true, 2>(acc, A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
-                                      Hs[0], gcopy0 ? gcopy0 + (size_t)v * P.pstride : nullptr, pld);
-        }
-        double *Hw = P.H0 + (size_t)w * P.pstride + (size_t)i * T;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r = wr * 64 + tn * 16 + l15;
-                    const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                    Hw[(size_t)r + (size_t)c * pld] = -acc[tm][tn][reg];
-                }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every wave's stores have left the CU, then ONE agent-scope release; the caller then sets its flag(s) from thread 0
+__device__ __forceinline__ void publish_begin()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    }
+}
+
+// after thread 0 has seen all the flags it polled: agent-scope acquire, then the workgroup may load the data
+__device__ __forceinline__ void acquire_end()
+{
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// M(q): sz (sz+1) / 2 gather items (one lower tile each), per block w a pivot + 2 (sz-1) + 2 (sz-1)^2 tile jobs, then
+// sz (sz+1) / 2 scatter items
+__device__ __forceinline__ int m_items(int sz)
+{
+    return sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1));
+}
+
+// ---- M(q): one item of the super-block inverse of group q -------------------------------------------------------------
+__device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD])
+{
+    const int tid = opaque_tid();
+    const int b0 = q * D.g, sz = min(D.g, D.nblk - b0), m = sz * T;
+    const int n1 = 2 * (sz - 1), n2 = 2 * (sz - 1) * (sz - 1), per_w = 1 + n1 + n2, nt = sz * (sz + 1) / 2;
+    const int nm = 2 * nt + sz * per_w;
+    double *Agg = D.A + (size_t)b0 * T + (size_t)b0 * T * D.ld;
+    unsigned *mc = D.mc + q;
+    if (e < nt || e >= nm - nt) {
+        // gather / scatter, one lower-triangle tile (ib >= jb) of the super-block per item
+        const bool gather = e < nt;
+        int x = gather ? e : e - (nm - nt), jb = 0;
+        while (x >= sz - jb) {
+            x -= sz - jb;
+            ++jb;
+        }
+        const int ib = jb + x;
+        unsigned *genp = D.gen + (size_t)(b0 + ib) * D.nblk + (b0 + jb);
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(P.cnt + 1 + irow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gather) {
+                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);   // the tile carries all earlier groups
+            } else {
+                while (flag_load(mc) < (unsigned)(nm - nt)) __builtin_amdgcn_s_sleep(8);
+                if (q >= 2) {
+                    const int psz = D.g, pn = D.nblk - psz;  // group q-2 is complete (Pg parity reuse)
+                    const unsigned want = (unsigned)(pn * psz + (long long)pn * (pn + 1) / 2);
+                    while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
+        acquire_end();
+        double *At = Agg + (size_t)ib * T + (size_t)jb * T * D.ld;
+        double(*Ts)[LDS_LD] = Gs[0];
+        // the tile goes 16 columns at a time: straight copies stay contiguous along columns, and the mirror images
+        // (transposes) pass through LDS so that their stores are 128-byte row segments instead of single 8-byte words
+        if (gather) {
+            // Sg0 (m x m, full storage) <- the tile and its mirror (lower triangle authoritative inside a diagonal tile)
+            double *S = D.Sg0;
+            double *Sd = S + (size_t)ib * T + (size_t)jb * T * m;   // (r, c)
+            double *Sm = S + (size_t)jb * T + (size_t)ib * T * m;   // mirror: (c, r)
+            for (int cb = 0; cb < T; cb += KC) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = tid + 256 * u, r = idx & 127, c = cb + (idx >> 7);
+                    const double v = At[(size_t)r + (size_t)c * D.ld];
+                    if (ib != jb || r >= c) Sd[(size_t)r + (size_t)c * m] = v;
+                    Ts[idx >> 7][r] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = tid + 256 * u, cc = idx & 15, r = idx >> 4;   // element (r, cb + cc) -> mirror position
+                    if (ib != jb || r > cb + cc) Sm[(size_t)(cb + cc) + (size_t)r * m] = Ts[cc][r];
+                }
+            }
+        } else {
+            // A_gg <- -Pg (lower-triangle tiles, diagonal tiles in full), Pg <- exactly symmetric from the lower triangle
+            const double *Sf = ((sz & 1) ? D.Sg1 : D.Sg0) + (size_t)ib * T + (size_t)jb * T * m;
+            double *Pg = (q & 1) ? D.Pg1 : D.Pg0;
+            double *Pd = Pg + (size_t)ib * T + (size_t)jb * T * m, *Pm = Pg + (size_t)jb * T + (size_t)ib * T * m;
+            for (int cb = 0; cb < T; cb += KC) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = tid + 256 * u, r = idx & 127, c = cb + (idx >> 7);
+                    const double v = Sf[(size_t)r + (size_t)c * m];
+                    if (ib != jb || r >= c) {
+                        At[(size_t)r + (size_t)c * D.ld] = v;
+                        Pd[(size_t)r + (size_t)c * m] = -v;
+                    }
+                    Ts[idx >> 7][r] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = tid + 256 * u, cc = idx & 15, r = idx >> 4;
+                    if (ib != jb || r > cb + cc) {
+                        Pm[(size_t)(cb + cc) + (size_t)r * m] = -Ts[cc][r];
+                        if (ib == jb) At[(size_t)(cb + cc) + (size_t)r * D.ld] = Ts[cc][r];
+                    }
+                }
+            }
+        }
+        publish_begin();
+        if (tid == 0) {
+            if (!gather) __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
-    const int t = item - P.npanel;
-    const bool head = t < P.nhead;
-    // wait until the panels of row blocks ra and rb (indices among the blocks outside the group) are complete
-    auto wait_rows = [&](int blk_a, int blk_b) {
-        if (tid == 0) {
-            const unsigned need = 2u * (unsigned)P.wb_sz;
-            const int ra = blk_a >= P.wb_b0 ? blk_a - P.wb_sz : blk_a, rb = blk_b >= P.wb_b0 ? blk_b - P.wb_sz : blk_b;
-            while (__hip_atomic_load(P.cnt + 1 + ra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need ||
-                   __hip_atomic_load(P.cnt + 1 + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
-                __builtin_amdgcn_s_sleep(8);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    const int w = (e - nt) / per_w, r = (e - nt) % per_w;
+    const int base_w = nt + w * per_w;  // M items before the pivot of block w
+    const double *Sin = (w & 1) ? D.Sg1 : D.Sg0;
+    double *Sout = (w & 1) ? D.Sg0 : D.Sg1;
+    if (r == 0) {
+        // pivot of block w of the scratch matrix
+        if (tid == 0)
+            while (flag_load(mc) < (unsigned)base_w) __builtin_amdgcn_s_sleep(8);
+        acquire_end();
+        // LDS of the tile paths reused: operand images in the first halves of Gs / Hs, Pms and the flag behind them
+        double *pGs = &Gs[0][0][0], *pNs = &Hs[0][0][0];
+        static_assert(MB * PV_ROW + 2 * MB * MB <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
+        double(*Pms)[MB][MB] = reinterpret_cast<double(*)[MB][MB]>(pGs + MB * PV_ROW);
+        int *badj = reinterpret_cast<int *>(pNs + MB * PV_ROW);
+        if (tid == 0) *badj = 0;
         __syncthreads();
-    };
-    int I, J;
-    if (head && t >= P.wb_first) {
-        // write-back of one tile of the group's new columns
-        const int e = t - P.wb_first;
-        int i = e % P.wb_rows;
-        const int w = e / P.wb_rows;
-        if (i >= P.wb_b0) i += P.wb_sz;
-        wait_rows(i, i);
-        panel_writeback_tile(A, ld, P.wb_b0 + w, i, P.H0 + (size_t)w * P.pstride, pld, Gs[0]);
-        I = J = -1;
-    } else if (head) {
-        int m = 0;
-        while (m + 1 < P.ncol && t >= P.first[m + 1]) ++m;
-        const int local = t - P.first[m];
-        const int b = local < P.n1[m] ? P.lo1[m] + local : P.lo2[m] + (local - P.n1[m]);
-        const int cb = P.col[m];
-        I = b > cb ? b : cb;
-        J = b > cb ? cb : b;
+        const size_t dd = (size_t)w * T + (size_t)w * T * m;
+        pivot_block<4, 9>(Sin + dd, (size_t)m, Sout + dd, (size_t)m, D.Pw, (size_t)T, pGs, pNs, Pms, badj);
+        __syncthreads();
+        if (tid == 0 && *badj != 0) {
+            // pivots run one after the other (each waits for the previous one's tile jobs): the first report is the smallest index
+            const int idx = (b0 + w) * T + *badj;
+            if (idx <= D.n_real && D.sc->info == 0) D.sc->info = idx;
+        }
+        publish_begin();
+        if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // tile jobs on the scratch matrix (128 x 64 each):  J1: S_iw <- S_iw Pw (and its mirror S_wi);  J2: S_ij <- S_ij - (S_iw Pw) S_jw^T
+    const bool second = r > n1;
+    const int k = second ? r - 1 - n1 : r - 1;
+    const int ch = k & 1;
+    int ii, jj = 0;
+    if (!second) {
+        ii = k >> 1;
     } else {
-        const int tt = t - P.nhead;
-        int ii = (int)((sqrt(8.0 * (double)tt + 1.0) - 1.0) * 0.5);
-        while ((long long)ii * (ii + 1) / 2 > tt) --ii;
-        while ((long long)(ii + 1) * (ii + 2) / 2 <= tt) ++ii;
-        int jj = tt - (int)((long long)ii * (ii + 1) / 2);
-        if (ii >= P.skip_lo) ii += P.skip_n;
-        if (jj >= P.skip_lo) jj += P.skip_n;
-        I = ii;
-        J = jj;
+        ii = (k >> 1) / (sz - 1);
+        jj = (k >> 1) % (sz - 1);
     }
-    if (I >= 0) wait_rows(I, J);
-    if (I >= 0) {
-        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-        double *At = A + (size_t)I * T + (size_t)J * T * ld;
-        double4_t acc[4][4];
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        {
-            StageRegs<4> R;
-            double cp[8];
-            const size_t go = (size_t)I * T, ho = (size_t)J * T;
-            const double *g1 = P.G[0] + go, *h1 = P.H[0] + ho;
-            stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
-            stage_store<false, 4>(R, Gs[0], Hs[0], tid);
-            stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
-            __syncthreads();
-            if constexpr (MULTI) {
-                UpdateChunks<0, true>::run(acc, R, cp, g1, h1, P.G[1] + go, P.H[1] + ho, pld, Gs, Hs, At, ld);
-                // pivots 2 .. nop of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
-                // chunk 0 is in LDS buffer 0 and chunk 1 in R
-                const int total = (T / KC) * (P.nop - 1);
-#pragma unroll 1
-                for (int c = 0; c < total; ++c) {
-                    chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                    if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
-                    if (c + 2 < total) {
-                        const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
-                        stage_load<false, 4>(R, P.G[op] + go, pld, P.H[op] + ho, pld, kc, tid);
-                    }
-                    chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                    __syncthreads();
-                }
-            } else {
-                UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
-            }
-        }
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r = wr * 64 + tn * 16 + l15;
-                    const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                    At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
-                }
-    }
-    if (t < P.ndiag) {
-        // publish: every wave's stores have left the CU, then one agent-scope release and the tick
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(P.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// The launch is PERSISTENT: two workgroups per compute unit of the stream's CU mask, each taking work items off one
-// device-wide counter until none are left.  Items are handed out in index order (so "panel first, head next" holds as
-// it would for dispatch order, and a waiting item can only wait for items that are already running); a compute unit that
-// is slower for any reason (a shader engine that lost a CU to the mask and still gets an equal share of a static grid,
-// the tail round of a static grid) simply takes fewer items; and the next item's operand loads are issued while the
-// previous item's stores drain, with no workgroup launch in between.
-template <bool MULTI>
-__global__ __launch_bounds__(256, 2) void k_group_update(const GroupUpd Parg, double *__restrict__ A, size_t ld, size_t pld)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
-    __shared__ int s_item;
-    // the descriptor is read where it lies, in the kernel-argument segment (first argument = offset 0): indexing its
-    // arrays with run-time indices through a by-value copy would put the copy into scratch memory
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const GroupUpd __attribute__((address_space(4))) *kernarg_desc_t;
-    const GroupUpd &P = *(const GroupUpd *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)Parg;
-#else
-    const GroupUpd &P = Parg;
-#endif
-    for (;;) {
-        if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(P.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int item = s_item;
-        if (item >= P.total) break;
-        // the leading dimensions are made opaque per iteration: otherwise every per-thread address offset of every path
-        // (hundreds of 64-bit values) is hoisted out of this loop as loop-invariant and spilled to scratch
-        size_t ld_i = ld, pld_i = pld;
-        asm volatile("" : "+s"(ld_i), "+s"(pld_i));
-        group_update_item<MULTI>(A, ld_i, pld_i, P, item, Gs, Hs);
-        __syncthreads();  // LDS and s_item are free again
-    }
-}
-
-// ---- the look-ahead chain of a pivot GROUP ------------------------------------------------------------------------
-// A group of sz <= 4 consecutive pivot blocks (m = 128 sz columns) is swept as ONE pivot of width m:
-//       Pg = (A_gg)^-1 (m x m),   G = A_{.,g},   H = -G Pg,   A_ij += H_i G_j^T  (the launches above),   A_{.,g} <- -H,   A_gg <- -Pg.
-// Only Pg is serial work, and it is small: the m x m diagonal super-block is copied to a dense scratch matrix
-// (k_gather_diag) and swept there block by block -- k_pivot for the 128 x 128 pivot, then two tiny launches of tile
-// products (k_tile_jobs) for the other blocks of the scratch matrix -- while the bulk of the group's look-ahead work
-// (the previous group's update applied to this group's columns, all rows) runs beside it inside the previous group's
-// update launch.  The group's own update launch then forms G and H for every row block in its front part (K = m) and
-// writes the new columns back.  Per group: no per-pivot panel / slice launches over the whole matrix any more.
-
-// Sg (m x m, ld = m, full storage) <- the diagonal super-block of A at block b0 (lower triangle authoritative)
-__global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ A, size_t ld, int b0, int m,
-                                                      double *__restrict__ Sg)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m * m) return;
-    const int r = e % m, c = e / m;
-    const double *Agg = A + (size_t)b0 * T + (size_t)b0 * T * ld;
-    Sg[e] = r >= c ? Agg[(size_t)r + (size_t)c * ld] : Agg[(size_t)c + (size_t)r * ld];
-}
-
-// Sg holds -Pg: A_gg <- Sg (lower-triangle tiles, diagonal tiles in full), Pg <- -Sg, exactly symmetric (from the lower
-// triangle)
-__global__ __launch_bounds__(256) void k_scatter_diag(double *__restrict__ A, size_t ld, int b0, int m,
-                                                       const double *__restrict__ Sg, double *__restrict__ Pg)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m * m) return;
-    const int r = e % m, c = e / m;
-    if (r < c) return;
-    double *Agg = A + (size_t)b0 * T + (size_t)b0 * T * ld;
-    const double v = Sg[e];
-    Agg[(size_t)r + (size_t)c * ld] = v;
-    Pg[(size_t)r + (size_t)c * m] = -v;
-    if (r > c) {
-        Pg[(size_t)c + (size_t)r * m] = -v;
-        if (r / T == c / T) Agg[(size_t)c + (size_t)r * ld] = v;
-    }
-}
-
-// A handful of independent 128 x 128 x 128 tile products on the scratch matrix, two workgroups (64 columns each) per
-// job:   X = g h^T;   out = cin ? cin - X : X;   outT (optional) = out^T.
-struct TileJob {
-    const double *g, *h, *cin;
-    double *out, *outT;
-};
-struct TileJobs {
-    TileJob j[9];
-    size_t gld, hld, cld;
-};
-
-// The jobs run beside the big update, when a dependent global load takes several microseconds: all of a job's operands
-// (K = 128: 8 chunks) are requested up front and the chunks then pass through a double-buffered LDS stage, one barrier
-// each -- one memory round trip per job instead of one per chunk.
-__global__ __launch_bounds__(256, 1) void k_tile_jobs(const TileJobs J)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
-    const TileJob job = J.j[blockIdx.x >> 1];
-    const int ch = blockIdx.x & 1;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (ii >= w) ++ii;
+    if (jj >= w) ++jj;
+    if (tid == 0)
+        while (flag_load(mc) < (unsigned)(base_w + 1 + (second ? n1 : 0))) __builtin_amdgcn_s_sleep(8);
+    acquire_end();
+    const double *gsrc = (second ? (const double *)Sout : Sin) + (size_t)ii * T + (size_t)w * T * m;
+    const double *hsrc = second ? Sin + (size_t)jj * T + (size_t)w * T * m : D.Pw;
+    const size_t hld = second ? (size_t)m : (size_t)T;
+    const int lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    constexpr int NCH = T / KC;
-    StageRegs<2> R[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) stage_load<false, 2>(R[c], job.g, J.gld, job.h + (size_t)ch * 64, J.hld, c * KC, tid);
-    // the tile of cin this thread will combine with, requested now as well
-    double cin[2][4][4];
-    if (job.cin) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int r = wr * 64 + tn * 16 + l15;
-                    const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                    cin[tm][tn][reg] = job.cin[(size_t)r + (size_t)c * J.cld];
-                }
-    }
     double4_t acc[2][4];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    stage_store<false, 2>(R[0], Gs[0], Hs[0], tid);
-    __syncthreads();
+    tile_product<false, 2>(acc, gsrc, (size_t)m, hsrc + (size_t)ch * 64, hld, Gs[0], Hs[0], nullptr, 0);
+    const double *cin = second ? Sin + (size_t)ii * T + (size_t)jj * T * m : nullptr;
+    double *out = Sout + (size_t)ii * T + (size_t)(second ? jj : w) * T * m;
+    double *outT = second ? nullptr : Sout + (size_t)w * T + (size_t)ii * T * m;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) stage_store<false, 2>(R[c + 1], Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
-        chunk_mma<2>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-        __syncthreads();
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = wr * 64 + tn * 16 + l15;
+                const int cc = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                double v = acc[tm][tn][reg];
+                if (cin) v = cin[(size_t)rr + (size_t)cc * m] - v;
+                out[(size_t)rr + (size_t)cc * m] = v;
+                if (outT) outT[(size_t)cc + (size_t)rr * m] = v;
+            }
+    publish_begin();
+    if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- panel(p): G_i and 64 columns of H_i = -G_i Pg for one row block ------------------------------------------------------
+// (i = the row block, y = which 64 of the m columns of H)
+__device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int i, int y, double (*Gs)[KC][LDS_LD],
+                                                 double (*Hs)[KC][LDS_LD])
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
+    const int w = y >> 1, ch = y & 1;
+    if (tid == 0) {
+        while (flag_load(D.mc + p) < (unsigned)m_items(sz)) __builtin_amdgcn_s_sleep(8);           // Pg(p)
+        for (int v = 0; v < sz; ++v) {                                                              // the group's columns of row i
+            const int k = b0 + v, I = i > k ? i : k, J = i > k ? k : i;
+            while (flag_load(D.gen + (size_t)I * D.nblk + J) < (unsigned)p) __builtin_amdgcn_s_sleep(8);
+        }
+        if (p >= 2) {                                                                               // panel buffers of parity p free
+            const int pn = D.nblk - D.g;
+            const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
+            while (flag_load(D.done + (p - 2)) < want) __builtin_amdgcn_s_sleep(8);
+        }
     }
+    acquire_end();
+    const size_t ld = D.ld, pgld = (size_t)sz * T;
+    const double *Pg = (p & 1) ? D.Pg1 : D.Pg0;
+    double *G0 = D.G0 + (size_t)4 * (p & 1) * D.pstride, *H0 = D.H0 + (size_t)4 * (p & 1) * D.pstride;
+    double4_t acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
+    const double *hsrc0 = Pg + (size_t)w * T + (size_t)ch * 64;
+    double *gcopy0 = (y == 0) ? G0 + (size_t)i * T : nullptr;
+    if (i > b0) {  // below the group: G_i = A[i, k]
+#pragma unroll 1
+        for (int v = 0; v < sz; ++v)
+            tile_product<false, 2>(acc, D.A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+                                   Hs[0], gcopy0 ? gcopy0 + (size_t)v * D.pstride : nullptr, ld);
+    } else {       // above the group: G_i = A[k, i]^T
+#pragma unroll 1
+        for (int v = 0; v < sz; ++v)
+            tile_product<true, 2>(acc, D.A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+                                  Hs[0], gcopy0 ? gcopy0 + (size_t)v * D.pstride : nullptr, ld);
+    }
+    double *Hw = H0 + (size_t)w * D.pstride + (size_t)i * T;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -887,185 +892,360 @@ __global__ __launch_bounds__(256, 1) void k_tile_jobs(const TileJobs J)
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wr * 64 + tn * 16 + l15;
                 const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                double v = acc[tm][tn][reg];
-                if (job.cin) v = cin[tm][tn][reg] - v;
-                job.out[(size_t)r + (size_t)c * J.cld] = v;
-                if (job.outT) job.outT[(size_t)c + (size_t)r * J.cld] = v;
+                Hw[(size_t)r + (size_t)c * ld] = -acc[tm][tn][reg];
             }
+    publish_begin();
+    if (tid == 0) __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Host driver of the block sweep: pivot groups of g blocks (g = 1 .. 4 by matrix size; GDCA_GROUP=g forces).  Per
-// group p two things happen:
-//     M(p)  Pg = inverse of the group's diagonal super-block: gather, sz x (k_pivot, two tile-job launches), scatter
-//     U(p)  ONE launch (k_group_update): panel, look-ahead head, write-back, remainder -- everything else of the group
-// With a side stream (s1) they overlap: U(p) runs on the side stream; the main (high-priority) stream waits for U(p)'s
-// head counter (the next diagonal super-block carries update p) and runs M(p+1) on the few CUs that are kept free of
-// U's workgroups; U(p+1) follows U(p) on the side stream as soon as M(p+1) is done.  Panels are double-buffered by
-// group parity.  Without a side stream everything runs on s0 in order.
-void gdca_launch_spd_inverse(hipStream_t s0, hipStream_t s1, double *A, int n_pad, const gdca_inverse_ws &ws,
-                             gdca_dev_scalars *sc, int n_real, hipEvent_t *sync_ev, hipEvent_t *upd_ev, int max_upd_ev,
-                             int *n_upd_launch, double *upd_flops)
+// ---- one tile of update p:  A_IJ += sum_w G_w[I] H_w[J]^T ------------------------------------------------------------------
+template <bool MULTI>
+__device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
+                                                double (*Hs)[KC][LDS_LD])
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
+    unsigned *genp = D.gen + (size_t)I * D.nblk + J;
+    if (tid == 0) {
+        const unsigned need = 2u * (unsigned)sz;
+        while (flag_load(D.rb + (size_t)p * D.nblk + I) < need || flag_load(D.rb + (size_t)p * D.nblk + J) < need ||
+               flag_load(genp) < (unsigned)p)
+            __builtin_amdgcn_s_sleep(8);
+    }
+    acquire_end();
+    const size_t ld = D.ld, pld = D.ld;
+    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride;
+    double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        StageRegs<4> R;
+        double cp[8];
+        const size_t go = (size_t)I * T, ho = (size_t)J * T;
+        const double *g1 = Gp + go, *h1 = Hp + ho;
+        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
+        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
+        __syncthreads();
+        if constexpr (MULTI) {
+            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, Gp + D.pstride + go, Hp + D.pstride + ho, pld, Gs, Hs, At, ld);
+            // pivots 2 .. sz of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
+            // chunk 0 is in LDS buffer 0 and chunk 1 in R
+            const int total = (T / KC) * (sz - 1);
+#pragma unroll 1
+            for (int c = 0; c < total; ++c) {
+                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+                if (c + 2 < total) {
+                    const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
+                    stage_load<false, 4>(R, Gp + (size_t)op * D.pstride + go, pld, Hp + (size_t)op * D.pstride + ho, pld, kc, tid);
+                }
+                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+                __syncthreads();
+            }
+        } else {
+            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = wr * 64 + tn * 16 + l15;
+                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
+            }
+    publish_begin();
+    if (tid == 0) {
+        __hip_atomic_store(genp, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- wb(p): one tile of the group's new columns ----------------------------------------------------------------------------
+__device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, double (*Gs)[KC][LDS_LD])
+{
+    const int tid = opaque_tid();
+    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), rows = D.nblk - sz;
+    int i = e % rows;
+    const int w = e / rows;
+    if (i >= b0) i += sz;
+    const int k = b0 + w;
+    if (tid == 0)
+        while (flag_load(D.rb + (size_t)p * D.nblk + i) < 2u * (unsigned)sz) __builtin_amdgcn_s_sleep(8);
+    acquire_end();
+    panel_writeback_tile(D.A, D.ld, k, i, D.H0 + (size_t)(4 * (p & 1) + w) * D.pstride, D.ld, Gs[0]);
+    publish_begin();
+    if (tid == 0) {
+        const int I = i > k ? i : k, J = i > k ? k : i;
+        __hip_atomic_store(D.gen + (size_t)I * D.nblk + J, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
+    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
+    __shared__ int s_item;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the descriptor is read where it lies, in the kernel-argument segment
+    typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
+    const SweepDesc &D = *(const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Darg;
+#else
+    const SweepDesc &D = Darg;
+#endif
+    // ---- the M list runs on compute units of its own ----
+    // The serial chain of a group (128 dependent steps per pivot block, each a handful of VALU / DPP / MFMA instructions) is
+    // several times slower when its waves share their SIMDs with the MFMA stream of a tile item, and then IT sets the pace
+    // of the whole inverse.  So a few compute units of one XCD (n_mcu, up to 16) are elected at run time -- the first ones that show up;
+    // both workgroups of an elected CU become M workers -- and take only M items (their own counter); one XCD, so that the
+    // items of a chain hand their data on through one L2.  Everybody else takes the main list.  The elected CUs are lost to
+    // the tiles (2 n_mcu of 512 workgroups) and join them once the M list is exhausted.
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        int worker = 0;
+        if ((xcc & 15u) == 0u) {
+            const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
+            for (int k = 0; k < D.n_mcu && !worker; ++k) {
+                const unsigned old = atomicCAS(D.mcu + k, 0u, key);
+                if (old == 0u || old == key) worker = 1;
+            }
+        }
+        s_item = worker;
+    }
+    __syncthreads();
+    const bool m_worker = s_item != 0;
+    __syncthreads();
+    if (m_worker) {
+        int q = 0;
+        for (;;) {
+            if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(D.next_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int item = s_item;
+            __syncthreads();
+            if (item >= D.total_m) break;
+            while (item >= D.mitem0[q + 1]) ++q;
+            int e = item - D.mitem0[q];
+            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
+            const int b0 = q * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
+            const int nsz = q + 1 < D.ng ? min(D.g, D.nblk - c0) : 0;
+            const int nm = m_items(sz);
+            if (e < nm) {
+                sweep_m_item(D, q, e, Gs, Hs);
+                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+                continue;
+            }
+            e -= nm;
+            if (e < nsz * 2 * sz) {
+                sweep_panel_item(D, q, c0 + e / (2 * sz), e % (2 * sz), Gs, Hs);
+                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+                continue;
+            }
+            e -= nsz * 2 * sz;
+            int mm = 0, first = 0;
+            while (e >= first + (nsz - mm)) {
+                first += nsz - mm;
+                ++mm;
+            }
+            if (MULTI && sz > 1)
+                sweep_tile_item<true>(D, q, c0 + mm + (e - first), c0 + mm, Gs, Hs);
+            else
+                sweep_tile_item<false>(D, q, c0 + mm + (e - first), c0 + mm, Gs, Hs);
+            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+        }
+    }
+    int p = 0;  // group whose sequence the last item belonged to (items come in ascending order)
+    // the NEXT item is requested while the current one is being worked on (the returning atomic takes a microsecond or two
+    // under load): s_next holds the item for the next trip
+    __shared__ int s_next;
+    if (threadIdx.x == 0) s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        __syncthreads();
+        const int item = s_next;
+        __syncthreads();  // everybody has read s_next
+        if (item >= D.total) break;
+        if (threadIdx.x == 0) s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (item >= D.item0[p + 1]) ++p;
+        int e = item - D.item0[p];
+        const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
+        const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
+        const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
+        const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
+        if (e < nrest * 2 * sz) {
+            int i = e / (2 * sz);
+            if (i >= b0) i += sz + nsz;
+            sweep_panel_item(D, p, i, e % (2 * sz), Gs, Hs);
+            continue;
+        }
+        e -= nrest * 2 * sz;
+        const int n_diag2 = n2 * (n2 + 1) / 2;
+        int I = -1, J = -1;
+        if (e < n_diag2) {
+            int mm = 0, first = 0;
+            while (e >= first + (n2 - mm)) {
+                first += n2 - mm;
+                ++mm;
+            }
+            I = d0 + mm + (e - first);
+            J = d0 + mm;
+        } else {
+            e -= n_diag2;
+            if (e < nsz * nrest) {
+                const int mm = e / nrest, local = e % nrest;
+                const int b = local < b0 ? local : local - b0 + d0;
+                const int cb = c0 + mm;
+                I = b > cb ? b : cb;
+                J = b > cb ? cb : b;
+            } else {
+                e -= nsz * nrest;
+                const int n_wb = (D.nblk - sz) * sz;
+                if (e < n_wb) {
+                    sweep_wb_item(D, p, e, Gs);
+                    continue;
+                }
+                e -= n_wb;
+                int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while ((long long)ii * (ii + 1) / 2 > e) --ii;
+                while ((long long)(ii + 1) * (ii + 2) / 2 <= e) ++ii;
+                int jj = e - (int)((long long)ii * (ii + 1) / 2);
+                if (ii >= b0) ii += sz + nsz;
+                if (jj >= b0) jj += sz + nsz;
+                I = ii;
+                J = jj;
+                if (J >= d0 && I < d0 + n2) continue;  // inside the diagonal super-block of group p+2: done above (diag2)
+            }
+        }
+        if (MULTI && sz > 1)
+            sweep_tile_item<true>(D, p, I, J, Gs, Hs);
+        else
+            sweep_tile_item<false>(D, p, I, J, Gs, Hs);
+    }
+}
+
+size_t gdca_inverse_flag_bytes(int n_pad)
+{
+    const size_t nblk = (size_t)(n_pad / T);
+    return (nblk * nblk + nblk * nblk + 2 * nblk + 20) * sizeof(unsigned);  // gen, rb (ng <= nblk), mc, done, next, next_m, mcu[16]
+}
+
+// Host side: the item table, the flags, one launch.
+void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_inverse_ws &ws, gdca_dev_scalars *sc, int n_real,
+                             hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch, double *upd_flops)
 {
     const int nblk = n_pad / T;
-    const size_t ld = (size_t)n_pad;
-    const double tile_flops = 2.0 * T * T * T;
-    int nl = 0;
-    double fl = 0.0;
-    const bool la = s1 != nullptr && nblk >= 3;
-    // pivots per group: more pivots per launch raise the update's arithmetic intensity (K = 128 g) and amortise its
-    // per-tile overheads; the group's chain grows with g and must stay shorter than the update it hides behind
+    // pivots per group: more pivots per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
+    // costs; the serial part of a group grows with g and must stay shorter than the update it runs beside
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
     int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 48 ? 3 : (nblk >= 24 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     const int ng = (nblk + g - 1) / g;
-    hipEvent_t *Ep = sync_ev, *Eb = sync_ev + ng;
-    const size_t pstride = (size_t)(ws.G[1] - ws.G[0]);
-    const int cstride = nblk + 2;  // counters per group: [0] head ticks, [1 + i] panel ticks of row block i, [nblk + 1] work counter
-    auto base = [&](int p) { return p * g; };
+    // item table on the host, then to the device (pinned staging buffer of the workspace)
+    int *it = ws.item0_host;
     auto size = [&](int p) { return std::min(g, nblk - p * g); };
-    // M: Pg of group p (and A_gg <- -Pg)
-    auto super_pivot = [&](int p) {
-        const int b0 = base(p), sz = size(p), m = sz * T;
-        if (sz == 1) {
-            double *Akk = A + (size_t)b0 * T + (size_t)b0 * T * ld;
-            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, (const double *)Akk, ld, Akk, ld, ws.Pg, (size_t)T, sc,
-                               b0 * T, n_real);
-            return;
-        }
-        const unsigned eg = (unsigned)((m * m + 255) / 256);
-        hipLaunchKernelGGL(k_gather_diag, dim3(eg), dim3(256), 0, s0, (const double *)A, ld, b0, m, ws.Sg[0]);
-        int cur = 0;
-        for (int w = 0; w < sz; ++w) {
-            const double *Sin = ws.Sg[cur];
-            double *Sout = ws.Sg[cur ^ 1];
-            const size_t dd = (size_t)w * T + (size_t)w * T * m;
-            hipLaunchKernelGGL(k_pivot, dim3(1), dim3(PIVOT_THREADS), 0, s0, Sin + dd, (size_t)m, Sout + dd, (size_t)m, ws.P,
-                               (size_t)T, sc, (b0 + w) * T, n_real);
-            // the other blocks of the scratch matrix:  S_iw <- S_iw Pw (and its mirror S_wi),  S_ij <- S_ij - (S_iw Pw) S_jw^T
-            TileJobs J1{}, J2{};
-            int n1 = 0, n2 = 0;
-            for (int i = 0; i < sz; ++i) {
-                if (i == w) continue;
-                TileJob &a = J1.j[n1++];
-                a.g = Sin + (size_t)i * T + (size_t)w * T * m;
-                a.h = ws.P;
-                a.cin = nullptr;
-                a.out = Sout + (size_t)i * T + (size_t)w * T * m;
-                a.outT = Sout + (size_t)w * T + (size_t)i * T * m;
-                for (int j = 0; j < sz; ++j) {
-                    if (j == w) continue;
-                    TileJob &b = J2.j[n2++];
-                    b.g = Sout + (size_t)i * T + (size_t)w * T * m;
-                    b.h = Sin + (size_t)j * T + (size_t)w * T * m;
-                    b.cin = Sin + (size_t)i * T + (size_t)j * T * m;
-                    b.out = Sout + (size_t)i * T + (size_t)j * T * m;
-                    b.outT = nullptr;
-                }
-            }
-            J1.gld = (size_t)m;
-            J1.hld = (size_t)T;
-            J1.cld = (size_t)m;
-            J2.gld = J2.hld = J2.cld = (size_t)m;
-            hipLaunchKernelGGL(k_tile_jobs, dim3(2 * n1), dim3(256), 0, s0, J1);
-            hipLaunchKernelGGL(k_tile_jobs, dim3(2 * n2), dim3(256), 0, s0, J2);
-            cur ^= 1;
-        }
-        hipLaunchKernelGGL(k_scatter_diag, dim3(eg), dim3(256), 0, s0, A, ld, b0, m, (const double *)ws.Sg[cur], ws.Pg);
-    };
-    // U(p): panel, head (diagonal super-block of group p+1, the other rows of group p+1's columns, write-back of group
-    // p's columns), remainder.  Returns the head-counter target.
-    auto update = [&](hipStream_t st, int p) -> unsigned {
-        const int b0 = base(p), sz = size(p);
-        const int nsz = p + 1 < ng ? size(p + 1) : 0, c0 = b0 + sz;
-        GroupUpd P{};
-        for (int w = 0; w < 4; ++w) {
-            P.G[w] = ws.G[4 * (p & 1) + std::min(w, sz - 1)];
-            P.H[w] = ws.H[4 * (p & 1) + std::min(w, sz - 1)];
-        }
-        P.nop = sz;
-        int first = 0;
-        for (int mm = 0; mm < nsz; ++mm) {  // diagonal super-block of the next group: rows mm .. nsz-1 of column mm
-            P.col[mm] = c0 + mm;
-            P.first[mm] = first;
-            P.lo1[mm] = c0 + mm;
-            P.n1[mm] = nsz - mm;
-            P.lo2[mm] = 0;
-            first += nsz - mm;
-        }
-        P.ndiag = first;
+    auto m_cnt = [&](int sz) { return sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)); };
+    int *mit = it + (ng + 1);
+    long long pos = 0, mpos = 0;
+    double tiles = 0.0;
+    for (int p = 0; p < ng; ++p) {
+        it[p] = (int)pos;
+        mit[p] = (int)mpos;
+        const int sz = size(p), nsz = p + 1 < ng ? size(p + 1) : 0, n2 = p + 2 < ng ? size(p + 2) : 0;
         const int nrest = nblk - sz - nsz;
-        const int ncol_rest = nrest > 0 ? nsz : 0;
-        for (int mm = 0; mm < ncol_rest; ++mm) {  // the other rows: above group p, then below group p+1
-            const int e = nsz + mm;
-            P.col[e] = c0 + mm;
-            P.first[e] = first;
-            P.lo1[e] = 0;
-            P.n1[e] = b0;
-            P.lo2[e] = c0 + nsz;
-            first += nrest;
-        }
-        P.ncol = nsz + ncol_rest;
-        P.first[P.ncol] = first;
-        P.wb_first = first;
-        P.wb_rows = nblk - sz;
-        P.wb_b0 = b0;
-        P.wb_sz = sz;
-        P.nhead = first + (nblk - sz) * sz;
-        P.npanel = (nblk - sz) * 2 * sz;
-        P.G0 = ws.G[4 * (p & 1)];
-        P.H0 = ws.H[4 * (p & 1)];
-        P.pstride = pstride;
-        P.Pg = ws.Pg;
-        P.cnt = ws.cnt + (size_t)p * cstride;
-        P.next = P.cnt + nblk + 1;
-        P.skip_lo = b0;
-        P.skip_n = sz + nsz;
-        const int mrem = nblk - P.skip_n;
-        const long long nbig = mrem > 0 ? (long long)mrem * (mrem + 1) / 2 : 0;
-        P.total = (int)(P.npanel + P.nhead + nbig);
-        if (P.total == 0) return 0u;
-        const unsigned grid = (unsigned)std::min<long long>(P.total, 2 * ws.update_cus);
-        const bool tm = upd_ev && 2 * nl + 1 < max_upd_ev;
-        if (tm) (void)hipEventRecord(upd_ev[2 * nl], st);
-        if (sz > 1)
-            hipLaunchKernelGGL((k_group_update<true>), dim3(grid), dim3(256), 0, st, P, A, ld, ld);
-        else
-            hipLaunchKernelGGL((k_group_update<false>), dim3(grid), dim3(256), 0, st, P, A, ld, ld);
-        if (tm) (void)hipEventRecord(upd_ev[2 * nl + 1], st);
-        ++nl;
-        fl += tile_flops * ((double)(first + nbig) * (double)sz + (double)(nblk - sz) * (double)(sz * sz));
-        return (unsigned)P.ndiag;
-    };
+        mpos += m_cnt(sz) + nsz * 2 * sz + nsz * (nsz + 1) / 2;   // M(p), the next group's panel rows, its diagonal tiles
+        pos += (long long)nrest * 2 * sz;                          // panel (the other rows)
+        pos += n2 * (n2 + 1) / 2;                                  // diag2
+        pos += (long long)nsz * nrest;                             // rest
+        pos += (long long)(nblk - sz) * sz;                        // wb
+        pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
+        const long long pn = nblk - sz;
+        tiles += (double)(pn * (pn + 1) / 2) * sz + (double)pn * sz * sz;  // tile products + the panel's (K = 128 sz, 128 sz columns)
+    }
+    it[ng] = (int)pos;
+    mit[ng] = (int)mpos;
+    (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)2 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
+    (void)hipMemsetAsync(ws.flags, 0, ws.flags_bytes, s0);
 
-    (void)hipMemsetAsync(ws.cnt, 0, (size_t)ng * cstride * sizeof(unsigned), s0);
-    super_pivot(0);
-    if (nblk == size(0)) {  // a single group: nothing to update
-        if (n_upd_launch) *n_upd_launch = 0;
-        if (upd_flops) *upd_flops = 0.0;
-        return;
+    SweepDesc D{};
+    D.A = A;
+    D.ld = (size_t)n_pad;
+    D.nblk = nblk;
+    D.g = g;
+    D.ng = ng;
+    D.G0 = ws.G[0];
+    D.H0 = ws.H[0];
+    D.pstride = (size_t)(ws.G[1] - ws.G[0]);
+    D.Sg0 = ws.Sg[0];
+    D.Sg1 = ws.Sg[1];
+    D.Pg0 = ws.Pg[0];
+    D.Pg1 = ws.Pg[1];
+    D.Pw = ws.P;
+    unsigned *f = ws.flags;
+    D.gen = f;
+    f += (size_t)nblk * nblk;
+    D.rb = f;
+    f += (size_t)ng * nblk;
+    D.mc = f;
+    f += ng;
+    D.done = f;
+    f += ng;
+    D.next = f;
+    D.next_m = f + 1;
+    D.mcu = f + 2;
+    D.item0 = ws.item0_dev;
+    D.mitem0 = ws.item0_dev + (ng + 1);
+    D.total = (int)pos;
+    D.total_m = (int)mpos;
+    static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
+    D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : 8;
+    D.n_real = n_real;
+    D.sc = sc;
+    // GDCA_SWEEP_TRACE=file: stamps of the M-list items of this inverse are written to `file` (debug aid; synchronises)
+    static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
+    unsigned long long *dbg = nullptr;
+    if (trace_path) {
+        (void)hipMalloc(&dbg, (size_t)2 * (mpos + 1) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, (size_t)2 * (mpos + 1) * sizeof(unsigned long long), s0);
     }
-    if (!la) {
-        // serial schedule on s0
-        for (int p = 0; p < ng; ++p) {
-            if (p > 0) super_pivot(p);
-            (void)update(s0, p);
-        }
-    } else {
-        (void)hipEventRecord(Ep[0], s0);
-        for (int p = 0; p < ng; ++p) {
-            (void)hipStreamWaitEvent(s1, Ep[p], 0);
-            const unsigned nA = update(s1, p);
-            if (p + 1 < ng) {
-                if (nA) (void)hipStreamWaitValue32(s0, ws.cnt + (size_t)p * cstride, nA, hipStreamWaitValueGte, 0xFFFFFFFFu);
-                super_pivot(p + 1);
-                (void)hipEventRecord(Ep[p + 1], s0);
+    D.dbg = dbg;
+    const unsigned grid = (unsigned)(2 * ws.update_cus);
+    const bool tm = upd_ev && max_upd_ev >= 2;
+    if (tm) (void)hipEventRecord(upd_ev[0], s0);
+    if (g > 1)
+        hipLaunchKernelGGL((k_sweep<true>), dim3(grid), dim3(256), 0, s0, D);
+    else
+        hipLaunchKernelGGL((k_sweep<false>), dim3(grid), dim3(256), 0, s0, D);
+    if (tm) (void)hipEventRecord(upd_ev[1], s0);
+    if (dbg) {
+        (void)hipStreamSynchronize(s0);
+        std::vector<unsigned long long> h((size_t)2 * mpos);
+        (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        if (FILE *fp = fopen(trace_path, "w")) {
+            fprintf(fp, "# nblk %d g %d ng %d; per M-list item: group local_index start_us end_us (since the first stamp)\n", nblk, g, ng);
+            unsigned long long t0 = ~0ull;
+            for (size_t x = 0; x < h.size(); x += 2)
+                if (h[x] && h[x] < t0) t0 = h[x];
+            int q = 0;
+            for (long long x = 0; x < mpos; ++x) {
+                while (x >= mit[q + 1]) ++q;
+                fprintf(fp, "%d %lld %.2f %.2f\n", q, x - mit[q], (double)(h[2 * x] - t0) / 100.0, (double)(h[2 * x + 1] - t0) / 100.0);
             }
+            fclose(fp);
         }
-        (void)hipEventRecord(Eb[0], s1);
-        (void)hipStreamWaitEvent(s0, Eb[0], 0);
     }
-    if (n_upd_launch) *n_upd_launch = nl;
-    if (upd_flops) *upd_flops = fl;
+    if (n_upd_launch) *n_upd_launch = 1;
+    if (upd_flops) *upd_flops = 2.0 * T * T * T * tiles;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -1,0 +1,23 @@
+"""Debug aid: run one SPD inverse of size n with GDCA_SWEEP_TRACE set and print the M-list timeline of a few groups."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+os.environ["GDCA_SWEEP_TRACE"] = "/tmp/sweep_trace.txt"
+import gaussdca.jl_amd as g
+ctx = g.Context(0)
+rng = np.random.default_rng(0)
+B = rng.standard_normal((n, 64))
+A = B @ B.T / 64 + np.diag(0.5 + rng.random(n))
+X = g.inv_cholesky(A, ctx=ctx)
+X = g.inv_cholesky(A, ctx=ctx)   # second call: warm
+rows = [l.split() for l in open("/tmp/sweep_trace.txt") if not l.startswith("#")]
+print(open("/tmp/sweep_trace.txt").readline().strip())
+gsel = {int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "11"])}
+prev_end = None
+for q, e, a, b in rows:
+    q, e, a, b = int(q), int(e), float(a), float(b)
+    if q in gsel:
+        print("group %2d item %3d  start %9.1f  end %9.1f  dur %7.1f" % (q, e, a, b, b - a))
+last = max(float(r[3]) for r in rows)
+print("M list span %.1f us" % last)
