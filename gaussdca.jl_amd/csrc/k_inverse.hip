@@ -667,9 +667,31 @@ __device__ __forceinline__ void acquire_end()
 
 // M(q): sz (sz+1) / 2 gather items (one lower tile each), per block w a pivot + 2 (sz-1) + 2 (sz-1)^2 tile jobs, then
 // sz (sz+1) / 2 scatter items
+// (a group of ONE block needs no scratch copy: a single item, the pivot in place)
 __device__ __forceinline__ int m_items(int sz)
 {
-    return sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1));
+    return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1));
+}
+
+// One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: operand images in the first halves
+// of Gs / Hs, Pms and the flag behind them).  ONE call site in the kernel: the unrolled 16-step micro-sweep is long.
+__device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *P,
+                                                      double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD], int index0, int n_real,
+                                                      gdca_dev_scalars *sc)
+{
+    double *pGs = &Gs[0][0][0], *pNs = &Hs[0][0][0];
+    static_assert(MB * PV_ROW + 2 * MB * MB <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
+    double(*Pms)[MB][MB] = reinterpret_cast<double(*)[MB][MB]>(pGs + MB * PV_ROW);
+    int *badj = reinterpret_cast<int *>(pNs + MB * PV_ROW);
+    if (threadIdx.x == 0) *badj = 0;
+    __syncthreads();
+    pivot_block<4, 9>(Ain, ldin, Aout, ldout, P, (size_t)T, pGs, pNs, Pms, badj);
+    __syncthreads();
+    if (threadIdx.x == 0 && *badj != 0) {
+        // pivots run one after the other (each waits for the previous one's items): the first report is the smallest index
+        const int idx = index0 + *badj;
+        if (idx <= n_real && sc->info == 0) sc->info = idx;
+    }
 }
 
 // ---- M(q): one item of the super-block inverse of group q -------------------------------------------------------------
@@ -681,7 +703,7 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     const int nm = 2 * nt + sz * per_w;
     double *Agg = D.A + (size_t)b0 * T + (size_t)b0 * T * D.ld;
     unsigned *mc = D.mc + q;
-    if (e < nt || e >= nm - nt) {
+    if (sz > 1 && (e < nt || e >= nm - nt)) {
         // gather / scatter, one lower-triangle tile (ib >= jb) of the super-block per item
         const bool gather = e < nt;
         int x = gather ? e : e - (nm - nt), jb = 0;
@@ -764,32 +786,36 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         }
         return;
     }
-    const int w = (e - nt) / per_w, r = (e - nt) % per_w;
+    const int w = sz == 1 ? 0 : (e - nt) / per_w, r = sz == 1 ? 0 : (e - nt) % per_w;
     const int base_w = nt + w * per_w;  // M items before the pivot of block w
     const double *Sin = (w & 1) ? D.Sg1 : D.Sg0;
     double *Sout = (w & 1) ? D.Sg0 : D.Sg1;
     if (r == 0) {
-        // pivot of block w of the scratch matrix
-        if (tid == 0)
-            while (flag_load(mc) < (unsigned)base_w) __builtin_amdgcn_s_sleep(8);
-        acquire_end();
-        // LDS of the tile paths reused: operand images in the first halves of Gs / Hs, Pms and the flag behind them
-        double *pGs = &Gs[0][0][0], *pNs = &Hs[0][0][0];
-        static_assert(MB * PV_ROW + 2 * MB * MB <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
-        double(*Pms)[MB][MB] = reinterpret_cast<double(*)[MB][MB]>(pGs + MB * PV_ROW);
-        int *badj = reinterpret_cast<int *>(pNs + MB * PV_ROW);
-        if (tid == 0) *badj = 0;
-        __syncthreads();
-        const size_t dd = (size_t)w * T + (size_t)w * T * m;
-        pivot_block<4, 9>(Sin + dd, (size_t)m, Sout + dd, (size_t)m, D.Pw, (size_t)T, pGs, pNs, Pms, badj);
-        __syncthreads();
-        if (tid == 0 && *badj != 0) {
-            // pivots run one after the other (each waits for the previous one's tile jobs): the first report is the smallest index
-            const int idx = (b0 + w) * T + *badj;
-            if (idx <= D.n_real && D.sc->info == 0) D.sc->info = idx;
+        // pivot of block w: on the scratch matrix, or -- a group of ONE block -- in place on A with Pg = its inverse
+        unsigned *genp = D.gen + (size_t)b0 * D.nblk + b0;
+        if (tid == 0) {
+            if (sz == 1) {
+                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);
+                if (q >= 2) {
+                    const int pn = D.nblk - D.g;  // group q-2 is complete (Pg parity reuse)
+                    const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
+                    while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
+                }
+            } else {
+                while (flag_load(mc) < (unsigned)base_w) __builtin_amdgcn_s_sleep(8);
+            }
         }
+        acquire_end();
+        const size_t dd = (size_t)w * T + (size_t)w * T * m;
+        const double *pin = sz == 1 ? (const double *)Agg : Sin + dd;
+        double *pout = sz == 1 ? Agg : Sout + dd;
+        const size_t pld_io = sz == 1 ? D.ld : (size_t)m;
+        sweep_pivot(pin, pld_io, pout, pld_io, sz == 1 ? ((q & 1) ? D.Pg1 : D.Pg0) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
         publish_begin();
-        if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            if (sz == 1) __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     // tile jobs on the scratch matrix (128 x 64 each):  J1: S_iw <- S_iw Pw (and its mirror S_wi);  J2: S_ij <- S_ij - (S_iw Pw) S_jw^T
@@ -1145,15 +1171,17 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
 {
     const int nblk = n_pad / T;
     // pivots per group: more pivots per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
-    // costs; the serial part of a group grows with g and must stay shorter than the update it runs beside
+    // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
+    // are bound by the chain itself, which is shortest with single pivots (no scratch copy, no tile jobs).  Measured on
+    // MI355X (tools/sweep_groups.py): g = 1 is fastest up to 55 blocks, 3 from 63 to 79, 4 from 86 on.
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 48 ? 3 : (nblk >= 24 ? 2 : 1)));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 84 ? 4 : (nblk >= 60 ? 3 : 1));
     if (nblk < 2 * g) g = 1;
     const int ng = (nblk + g - 1) / g;
     // item table on the host, then to the device (pinned staging buffer of the workspace)
     int *it = ws.item0_host;
     auto size = [&](int p) { return std::min(g, nblk - p * g); };
-    auto m_cnt = [&](int sz) { return sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)); };
+    auto m_cnt = [&](int sz) { return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)); };
     int *mit = it + (ng + 1);
     long long pos = 0, mpos = 0;
     double tiles = 0.0;

@@ -300,8 +300,8 @@ def test_headline_config_properties(g, ctx):
 
 @pytest.mark.parametrize("n", [6000, 9100])
 def test_large_spd_inverse_residual(g, ctx, n):
-    """n = 6000 (47 pivot blocks: groups of two pivots) and n = 9100 (72 blocks: groups of three, K = 384 trailing
-    updates): A X v == v on random probes."""
+    """n = 6000 (47 pivot blocks: single pivots) and n = 9100 (72 blocks: groups of three, K = 384 trailing updates):
+    A X v == v on random probes."""
     rng = np.random.default_rng(4)
     B = rng.standard_normal((n, 64))
     d = 0.5 + rng.random(n)
@@ -338,14 +338,13 @@ print(json.dumps(out))
 
 
 @pytest.mark.parametrize("env", [{"GDCA_GROUP": "1"}, {"GDCA_GROUP": "2"}, {"GDCA_GROUP": "3"}, {"GDCA_GROUP": "4"},
-                                 {"GDCA_NO_LOOKAHEAD": "1", "GDCA_GROUP": "1"}, {"GDCA_NO_LOOKAHEAD": "1", "GDCA_GROUP": "3"},
-                                 {"GDCA_GROUP": "3", "GDCA_RESERVE_CU": "0"}, {"GDCA_GROUP": "2", "GDCA_RESERVE_CU": "8"}])
+                                 {"GDCA_GROUP": "3", "GDCA_MCUS": "1"}, {"GDCA_GROUP": "2", "GDCA_MCUS": "16"},
+                                 {"GDCA_GROUP": "4", "GDCA_MCUS": "3"}])
 def test_every_inverse_schedule_matches_lapack(env):
-    """The SPD inverse sweeps pivot groups of 1-4 blocks, with look-ahead over three streams or serially on one, with or
-    without compute units held back for the pivot chain; the group size is chosen by matrix size.  Each combination,
-    forced through its environment switches in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks (even
-    and odd block counts, short last groups and matrices smaller than one group included) and the same `info` on a
-    non-PD matrix."""
+    """The SPD inverse is one persistent launch that sweeps pivot groups of 1-4 blocks (the group size is chosen by matrix
+    size) with its serial chain on 1-16 elected compute units.  Each combination, forced through its environment switches
+    in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks (even and odd block counts, short last groups
+    and matrices smaller than one group included) and the same `info` on a non-PD matrix."""
     import json
     import subprocess
     import sys
@@ -363,7 +362,7 @@ def test_every_inverse_schedule_matches_lapack(env):
 @pytest.mark.parametrize("N,M,score,pc", [(430, 4000, "frob", 0.8), (260, 5000, "DI", 0.2)])
 def test_mid_size_families_match_oracle(g, ctx, o, N, M, score, pc):
     """Whole hot path against the oracle at sizes where the production schedules are active: N = 430 (n = 8600,
-    68 pivot blocks: groups of three pivots, K = 384 trailing updates) and N = 260 (41 blocks: groups of two).
+    68 pivot blocks: groups of three pivots, K = 384 trailing updates) and N = 260 (41 blocks: single pivots).
     Integers bit-exact, scores within 1e-6 relative (north_star)."""
     from gaussdca.jl_amd import synth
 
