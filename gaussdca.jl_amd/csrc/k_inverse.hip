@@ -637,6 +637,7 @@ struct SweepDesc {
     int n_real;
     gdca_dev_scalars *sc;
     unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
+    unsigned long long *dbg_main;  // optional: [0] ticks tile items waited, [1] panel items waited, [2..] ticks / counts by kind
 };
 
 __device__ __forceinline__ unsigned flag_load(const unsigned *p)
@@ -653,6 +654,21 @@ __device__ __forceinline__ void publish_begin()
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+}
+
+// The write-through form: every store of the published bytes was an agent-scope (sc1) store -- it goes to memory, not
+// into this XCD's write-back L2 -- so draining the stores (each wave's vmcnt(0)) is all there is to do before the flag: no
+// L2 write-back of the whole XCD per item (measured cost of that release beside streaming tiles: several microseconds of
+// a ~100 us tile item)
+__device__ __forceinline__ void store_wt(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void publish_wt_begin()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // after thread 0 has seen all the flags it polled: agent-scope acquire, then the workgroup may load the data
@@ -875,6 +891,7 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
     const int w = y >> 1, ch = y & 1;
     if (tid == 0) {
+        const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         while (flag_load(D.mc + p) < (unsigned)m_items(sz)) __builtin_amdgcn_s_sleep(8);           // Pg(p)
         for (int v = 0; v < sz; ++v) {                                                              // the group's columns of row i
             const int k = b0 + v, I = i > k ? i : k, J = i > k ? k : i;
@@ -885,6 +902,7 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
             const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
             while (flag_load(D.done + (p - 2)) < want) __builtin_amdgcn_s_sleep(8);
         }
+        if (D.dbg) atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
     }
     acquire_end();
     const size_t ld = D.ld, pgld = (size_t)sz * T;
@@ -934,10 +952,12 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
     const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
     unsigned *genp = D.gen + (size_t)I * D.nblk + J;
     if (tid == 0) {
+        const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         const unsigned need = 2u * (unsigned)sz;
         while (flag_load(D.rb + (size_t)p * D.nblk + I) < need || flag_load(D.rb + (size_t)p * D.nblk + J) < need ||
                flag_load(genp) < (unsigned)p)
             __builtin_amdgcn_s_sleep(8);
+        if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
     }
     acquire_end();
     const size_t ld = D.ld, pld = D.ld;
@@ -985,9 +1005,9 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wr * 64 + tn * 16 + l15;
                 const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                At[(size_t)r + (size_t)c * ld] = acc[tm][tn][reg];
+                store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
             }
-    publish_begin();
+    publish_wt_begin();
     if (tid == 0) {
         __hip_atomic_store(genp, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1108,10 +1128,16 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
         const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
         const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
+        const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
+        const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
         if (e < nrest * 2 * sz) {
             int i = e / (2 * sz);
             if (i >= b0) i += sz + nsz;
             sweep_panel_item(D, p, i, e % (2 * sz), Gs, Hs);
+            if (D.dbg && threadIdx.x == 0) {
+                atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
+                atomicAdd(D.dbg_main + 3, 1ull);
+            }
             continue;
         }
         e -= nrest * 2 * sz;
@@ -1138,6 +1164,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
                 const int n_wb = (D.nblk - sz) * sz;
                 if (e < n_wb) {
                     sweep_wb_item(D, p, e, Gs);
+                    if (D.dbg && threadIdx.x == 0) {
+                        atomicAdd(D.dbg_main + 4, wall_clock64() - t_item);
+                        atomicAdd(D.dbg_main + 5, 1ull);
+                    }
                     continue;
                 }
                 e -= n_wb;
@@ -1156,7 +1186,13 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             sweep_tile_item<true>(D, p, I, J, Gs, Hs);
         else
             sweep_tile_item<false>(D, p, I, J, Gs, Hs);
+        if (D.dbg && threadIdx.x == 0) {
+            atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
+            atomicAdd(D.dbg_main + 7, 1ull);
+            atomicAdd(D.dbg_main + 8 + 1023, (unsigned long long)clock64() - c_item);  // shader-clock cycles of the tile items
+        }
     }
+    if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work
 }
 
 size_t gdca_inverse_flag_bytes(int n_pad)
@@ -1242,10 +1278,11 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
     unsigned long long *dbg = nullptr;
     if (trace_path) {
-        (void)hipMalloc(&dbg, (size_t)2 * (mpos + 1) * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, (size_t)2 * (mpos + 1) * sizeof(unsigned long long), s0);
+        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024) * sizeof(unsigned long long), s0);
     }
     D.dbg = dbg;
+    D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
     const unsigned grid = (unsigned)(2 * ws.update_cus);
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
@@ -1256,11 +1293,27 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
     if (dbg) {
         (void)hipStreamSynchronize(s0);
-        std::vector<unsigned long long> h((size_t)2 * mpos);
+        std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024);
         (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hm.data(), dbg + 2 * (mpos + 1), hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
         if (FILE *fp = fopen(trace_path, "w")) {
             fprintf(fp, "# nblk %d g %d ng %d; per M-list item: group local_index start_us end_us (since the first stamp)\n", nblk, g, ng);
+            unsigned long long tend = 0, tmin = ~0ull;
+            for (unsigned w = 0; w < grid; ++w) {
+                if (hm[8 + w] > tend) tend = hm[8 + w];
+                if (hm[8 + w] && hm[8 + w] < tmin) tmin = hm[8 + w];
+            }
+            double idle_end = 0;
+            for (unsigned w = 0; w < grid; ++w)
+                if (hm[8 + w]) idle_end += (double)(tend - hm[8 + w]) / 100.0;
+            fprintf(fp, "# main list: tile items %llu, %.1f us each incl. %.1f us waiting; panel items %llu, %.1f us each incl. %.1f us waiting; "
+                        "wb items %llu, %.1f us each; workers idle at the end: %.1f us on average (first out %.1f us before the last)\n",
+                    hm[7], hm[7] ? hm[6] / 100.0 / hm[7] : 0.0, hm[7] ? hm[0] / 100.0 / hm[7] : 0.0, hm[3],
+                    hm[3] ? hm[2] / 100.0 / hm[3] : 0.0, hm[3] ? hm[1] / 100.0 / hm[3] : 0.0, hm[5], hm[5] ? hm[4] / 100.0 / hm[5] : 0.0,
+                    idle_end / grid, (double)(tend - tmin) / 100.0);
+            fprintf(fp, "# shader clock during tile items: %.3f GHz (s_memtime cycles / 100 MHz wall clock)\n",
+                    hm[6] ? (double)hm[8 + 1023] / (double)hm[6] * 0.1 : 0.0);
             unsigned long long t0 = ~0ull;
             for (size_t x = 0; x < h.size(); x += 2)
                 if (h[x] && h[x] < t0) t0 = h[x];

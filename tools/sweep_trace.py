@@ -12,7 +12,8 @@ A = B @ B.T / 64 + np.diag(0.5 + rng.random(n))
 X = g.inv_cholesky(A, ctx=ctx)
 X = g.inv_cholesky(A, ctx=ctx)   # second call: warm
 rows = [l.split() for l in open("/tmp/sweep_trace.txt") if not l.startswith("#")]
-print(open("/tmp/sweep_trace.txt").readline().strip())
+for l in open("/tmp/sweep_trace.txt"):
+    if l.startswith("#"): print(l.strip())
 gsel = {int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "11"])}
 prev_end = None
 for q, e, a, b in rows:
