@@ -34,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
+MEASURED_SHADER_GHZ = 2.10  # s_memtime / wall clock inside k_sweep's tile items (profiles/r02_sweep_trace_C.txt); spec 2.4
 PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_update_traffic.json")
 
 CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
@@ -194,6 +195,9 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         o.correct_APC(S)
         stage["score"] = time.time() - t
         how = "the whole family, every stage measured in full"
+        # the all-thread rates of the sanity ratios come from the full-size stages (the probes are start-up-bound on 256 threads)
+        ham_rate = (M * (M - 1.0) / 2) / max(1e-6, stage["ham"])
+        freq_all = stage["freq"] / M
     else:
         f_h = min(1.0, (0.4 * budget_s / est_ham) ** 0.5)
         Mh = max(Mp, int(M * f_h))
@@ -392,7 +396,8 @@ def main():
         upd_launch = int(np.sum([s["update_launches"] for s in stats]))
         upd_flops = float(np.sum([s["update_flops"] for s in stats]))
         inv_ms = float(np.sum([s["ms_inverse"] for s in stats]))
-        achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        alg_flops = float(np.sum([s["inverse_flops"] for s in stats]))  # F = n^3 + n^2 + n per family
+        achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         N0, M0 = fams[0][1], fams[0][2]
         if args.config == "E":
             wl = ("batch of %d synthetic Pfam-like families, N in [100,600], M in [5k,80k], q=%d, score=:%s, "
@@ -425,8 +430,8 @@ def main():
                          ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
                           "ms_score")},
             "roofline": {
-                "kernel": "k_group_update<false,true> (big trailing update of the SPD inverse: f64 MFMA 128x128 tiles, "
-                          "several pivots per launch)",
+                "kernel": "k_sweep (the whole SPD inverse as ONE persistent launch: block symmetric sweep, f64 MFMA 128x128 "
+                          "tiles, pivot chain on elected CUs; duration from HIP events on its stream)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F64_MFMA_TFLOPS,
@@ -434,8 +439,10 @@ def main():
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
                 "traffic": pmc_traffic(N0, M0, args.score) if args.config != "E" else None,
                 "launches_per_step": upd_launch / K,
-                "flops_per_launch": upd_flops / max(1, upd_launch),
+                "flops_per_launch": alg_flops / max(1, upd_launch),
+                "mfma_flops_issued_per_launch": upd_flops / max(1, upd_launch),  # incl. the padding to 128-blocks
                 "avg_launch_ms": upd_ms / max(1, upd_launch),
+                "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * MEASURED_SHADER_GHZ / 2.4,
             },
         }
         if args.config != "E":

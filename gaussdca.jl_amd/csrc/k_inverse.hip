@@ -1283,7 +1283,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     }
     D.dbg = dbg;
     D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
-    const unsigned grid = (unsigned)(2 * ws.update_cus);
+    // workgroup slots: two per CU; fewer when the caller wants room left beside the sweep (a pipeline peer's reweighting
+    // and tally kernels then co-reside with ONE sweep workgroup on some CUs: VALU / LDS-atomic work beside MFMA work)
+    const unsigned grid = (unsigned)std::max(16, 2 * ws.update_cus - ws.free_slots);
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
     if (g > 1)

@@ -20,6 +20,7 @@
 // diagonal only, off-diagonal blocks pc/q^2 everywhere) and subtracts Pi'Pi'^T, so the n x n
 // covariance is written to HBM exactly once (8 n^2 bytes) and Pij never exists in memory.
 #include "gdca_internal.h"
+#include <cstdlib>
 
 typedef unsigned long long u64;
 
@@ -289,6 +290,8 @@ static size_t tally_lds_bytes(int s, int TJ)
 
 int gdca_tally_tj(int q)
 {
+    static const int tj_env = getenv("GDCA_TALLY_TJ") ? atoi(getenv("GDCA_TALLY_TJ")) : 0;
+    if (tj_env == 16) return 16;
     return tally_lds_bytes(q - 1, 32) <= 160 * 1024 ? 32 : 16;
 }
 

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime: it must be loaded before libgdca.so (which links the system one), otherwise torch.cuda
+# finds no device later in the same process (INTEGRATION.md "load order")
+import torch  # noqa: E402,F401
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Second half of the round's measurements (counter passes, calibration, in-kernel traces, micro-benchmarks):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round2.sh r02'
+tag=${1:-rXX}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+python -c "import torch" 2>/dev/null
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/pmc_$c.log 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/calib_$c -- $R/tools/_bin/ubench_fetch_calib > $R/$out/calib_$c.log 2>&1
+done
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $R/$out/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/pmc_mfma.log 2>&1
+cd $R
+GDCA_SWEEP_TRACE=$out/sweep_trace_C.txt timeout 300 python tools/sweep_trace.py 10000 > $out/sweep_trace_C.log 2>&1
+GDCA_SWEEP_TRACE=$out/sweep_trace_D.txt timeout 300 python tools/sweep_trace.py 20000 > $out/sweep_trace_D.log 2>&1
+GDCA_SWEEP_TRACE=$out/sweep_trace_B.txt timeout 300 python tools/sweep_trace.py 2560 5,6 > $out/sweep_trace_B.log 2>&1
+head -4 $out/sweep_trace_C.log
+find $out -name "*agent_info*" -delete
+bash tools/gpu_ubench.sh $tag > $out/ubench.log 2>&1
+bash tools/_bin/gpucmd.sh > $out/pipeline_experiment.log 2>&1
+cat $out/pipeline_experiment.log
+du -sh $out

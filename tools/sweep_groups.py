@@ -19,15 +19,17 @@ for N in [int(x) for x in sys.argv[2].split(",")]:
     out[N] = best
 print(json.dumps(out))
 '''
-Ns = "100,150,200,250,300,350,400,450,500,550,600,800,1000"
+Ns = "100,128,200,300,350,400,450,500,550,600,800,1000"
 res = {}
-for gsz in (1, 2, 3, 4):
-    env = dict(os.environ, GDCA_GROUP=str(gsz))
+combos = [(gsz, m) for gsz in (1, 2, 3, 4) for m in ((8,) if "--quick" in sys.argv else (4, 8, 12, 16))]
+for gsz, m in combos:
+    env = dict(os.environ, GDCA_GROUP=str(gsz), GDCA_MCUS=str(m))
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, Ns], capture_output=True, text=True, env=env, timeout=900)
-    res[gsz] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
-print("N   nblk " + " ".join("g=%d     " % k for k in res))
+    res[(gsz, m)] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+print("ms_inverse; columns = (GDCA_GROUP, GDCA_MCUS)")
+print("N   nblk " + " ".join("g%d/m%-2d   " % k for k in res))
 for N in Ns.split(","):
     nblk = -(-int(N) * 20 // 128)
     row = [res[k].get(N, float("nan")) for k in res]
     best = min(range(len(row)), key=lambda i: row[i])
-    print("%4s %4d " % (N, nblk) + " ".join("%8.3f" % x for x in row) + "   best g=%d" % (best + 1))
+    print("%4s %4d " % (N, nblk) + " ".join("%8.3f" % x for x in row) + "   best g=%d mcus=%d" % combos[best])

@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-os.environ["GDCA_SWEEP_TRACE"] = "/tmp/sweep_trace.txt"
+TRACE = os.environ.setdefault("GDCA_SWEEP_TRACE", "/tmp/sweep_trace.txt")
 import gaussdca.jl_amd as g
 ctx = g.Context(0)
 rng = np.random.default_rng(0)
@@ -11,8 +11,8 @@ B = rng.standard_normal((n, 64))
 A = B @ B.T / 64 + np.diag(0.5 + rng.random(n))
 X = g.inv_cholesky(A, ctx=ctx)
 X = g.inv_cholesky(A, ctx=ctx)   # second call: warm
-rows = [l.split() for l in open("/tmp/sweep_trace.txt") if not l.startswith("#")]
-for l in open("/tmp/sweep_trace.txt"):
+rows = [l.split() for l in open(TRACE) if not l.startswith("#")]
+for l in open(TRACE):
     if l.startswith("#"): print(l.strip())
 gsel = {int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "11"])}
 prev_end = None
