@@ -365,9 +365,6 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     ws.item0_dev = (int *)((char *)ctx->Sg.p + 4 * sg + fbytes);
     ws.item0_host = ctx->item0_host;
     ws.update_cus = ctx->ncu;
-    // in a pipeline (gdca_ctx_create_peer) the other family's reweighting and tallies run beside this sweep
-    static const int free_env = getenv("GDCA_SWEEP_FREE_SLOTS") ? atoi(getenv("GDCA_SWEEP_FREE_SLOTS")) : -1;
-    ws.free_slots = free_env >= 0 ? free_env : 0;
     hipEvent_t *uev = nullptr;
     int max_ev = 0;
     if (timed) {

@@ -93,7 +93,6 @@ struct gdca_inverse_ws {
     int *item0_host;   // pinned: first work item of every group's sequence in the main list and in the M list (2 x (n_pad / 128 + 2) entries)
     int *item0_dev;
     int update_cus;    // compute units of the device
-    int free_slots;    // workgroup slots (of 2 per CU) the sweep leaves to other kernels
 };
 // In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles authoritative): A <- -inverse(A) by
 // the block symmetric sweep, ONE persistent launch on stream s.  sc->info gets the 1-based index of the first

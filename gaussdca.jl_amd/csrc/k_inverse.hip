@@ -633,6 +633,8 @@ struct SweepDesc {
     const int *item0;      // [ng + 1]: first item of group p's sequence in the main list
     const int *mitem0;     // [ng + 1]: first item of M(q) in the M list
     int total, total_m;
+    int pro;               // main list: the first `pro` items are panel(0); group p's sequence follows at pro + item0[p]
+    int rem_tail;          // remainder tiles of update p that are listed AFTER panel(p+1)
     int n_mcu;             // compute units to elect for the M list (<= 16)
     int n_real;
     gdca_dev_scalars *sc;
@@ -719,7 +721,15 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     const int nm = 2 * nt + sz * per_w;
     double *Agg = D.A + (size_t)b0 * T + (size_t)b0 * T * D.ld;
     unsigned *mc = D.mc + q;
-    if (sz > 1 && (e < nt || e >= nm - nt)) {
+    // The FIRST pivot of a multi-block group is item 0 and reads its tile straight from A: it needs only the group's first
+    // diagonal tile (the first thing the previous group's chain produces), not the gathered copy of the whole super-block, so
+    // it runs beside the other diagonal tiles and the gathers instead of after them.  Its old slot (e == nt) only counts.
+    const bool first_pivot = sz > 1 && e == 0;
+    if (sz > 1 && e == nt) {
+        if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (sz > 1 && !first_pivot && (e < nt || e >= nm - nt)) {
         // gather / scatter, one lower-triangle tile (ib >= jb) of the super-block per item
         const bool gather = e < nt;
         int x = gather ? e : e - (nm - nt), jb = 0;
@@ -802,7 +812,7 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         }
         return;
     }
-    const int w = sz == 1 ? 0 : (e - nt) / per_w, r = sz == 1 ? 0 : (e - nt) % per_w;
+    const int w = (sz == 1 || first_pivot) ? 0 : (e - nt) / per_w, r = (sz == 1 || first_pivot) ? 0 : (e - nt) % per_w;
     const int base_w = nt + w * per_w;  // M items before the pivot of block w
     const double *Sin = (w & 1) ? D.Sg1 : D.Sg0;
     double *Sout = (w & 1) ? D.Sg0 : D.Sg1;
@@ -817,16 +827,19 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
                     const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
                     while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
                 }
+            } else if (first_pivot) {
+                // (the tile at generation q implies that M(q-1) is complete: the scratch matrices and Pw are free)
+                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);
             } else {
                 while (flag_load(mc) < (unsigned)base_w) __builtin_amdgcn_s_sleep(8);
             }
         }
         acquire_end();
         const size_t dd = (size_t)w * T + (size_t)w * T * m;
-        const double *pin = sz == 1 ? (const double *)Agg : Sin + dd;
+        const double *pin = (sz == 1 || first_pivot) ? (const double *)Agg : Sin + dd;
         double *pout = sz == 1 ? Agg : Sout + dd;
-        const size_t pld_io = sz == 1 ? D.ld : (size_t)m;
-        sweep_pivot(pin, pld_io, pout, pld_io, sz == 1 ? ((q & 1) ? D.Pg1 : D.Pg0) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
+        const size_t pld_in = (sz == 1 || first_pivot) ? D.ld : (size_t)m, pld_out = sz == 1 ? D.ld : (size_t)m;
+        sweep_pivot(pin, pld_in, pout, pld_out, sz == 1 ? ((q & 1) ? D.Pg1 : D.Pg0) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
         publish_begin();
         if (tid == 0) {
             if (sz == 1) __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -892,15 +905,23 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     const int w = y >> 1, ch = y & 1;
     if (tid == 0) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
-        while (flag_load(D.mc + p) < (unsigned)m_items(sz)) __builtin_amdgcn_s_sleep(8);           // Pg(p)
-        for (int v = 0; v < sz; ++v) {                                                              // the group's columns of row i
-            const int k = b0 + v, I = i > k ? i : k, J = i > k ? k : i;
-            while (flag_load(D.gen + (size_t)I * D.nblk + J) < (unsigned)p) __builtin_amdgcn_s_sleep(8);
+        // Pg(p); the group's columns of row i at generation p; the panel buffers of parity p free (group p-2 complete): all
+        // flags of a round are loaded together
+        const int pn = D.nblk - D.g;
+        const unsigned want = p >= 2 ? (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2) : 0u;
+        const unsigned *dn = D.done + (p >= 2 ? p - 2 : 0);
+        const unsigned *gp[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = b0 + (v < sz ? v : 0), I = i > k ? i : k, J = i > k ? k : i;
+            gp[v] = D.gen + (size_t)I * D.nblk + J;
         }
-        if (p >= 2) {                                                                               // panel buffers of parity p free
-            const int pn = D.nblk - D.g;
-            const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
-            while (flag_load(D.done + (p - 2)) < want) __builtin_amdgcn_s_sleep(8);
+        const unsigned nmi = (unsigned)m_items(sz);
+        for (;;) {
+            const unsigned f0 = flag_load(D.mc + p), f1 = flag_load(gp[0]), f2 = flag_load(gp[1]), f3 = flag_load(gp[2]),
+                           f4 = flag_load(gp[3]), f5 = flag_load(dn);
+            if ((f0 >= nmi) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= (unsigned)p) & (f4 >= (unsigned)p) & (f5 >= want)) break;
+            __builtin_amdgcn_s_sleep(8);
         }
         if (D.dbg) atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
     }
@@ -954,9 +975,13 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
     if (tid == 0) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         const unsigned need = 2u * (unsigned)sz;
-        while (flag_load(D.rb + (size_t)p * D.nblk + I) < need || flag_load(D.rb + (size_t)p * D.nblk + J) < need ||
-               flag_load(genp) < (unsigned)p)
+        // the three flags are loaded TOGETHER (one L2 round trip, ~1.5 us under load, instead of three dependent ones)
+        for (;;) {
+            const unsigned f1 = flag_load(D.rb + (size_t)p * D.nblk + I), f2 = flag_load(D.rb + (size_t)p * D.nblk + J),
+                           f3 = flag_load(genp);
+            if ((f1 >= need) & (f2 >= need) & (f3 >= (unsigned)p)) break;
             __builtin_amdgcn_s_sleep(8);
+        }
         if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
     }
     acquire_end();
@@ -1085,7 +1110,6 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             int e = item - D.mitem0[q];
             if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
             const int b0 = q * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
-            const int nsz = q + 1 < D.ng ? min(D.g, D.nblk - c0) : 0;
             const int nm = m_items(sz);
             if (e < nm) {
                 sweep_m_item(D, q, e, Gs, Hs);
@@ -1093,21 +1117,24 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
                 continue;
             }
             e -= nm;
-            if (e < nsz * 2 * sz) {
-                sweep_panel_item(D, q, c0 + e / (2 * sz), e % (2 * sz), Gs, Hs);
+            // the next group's rows, one after the other: the 2 sz panel items of row rr, then the tiles (rr, 0 .. rr) of its
+            // diagonal super-block -- its FIRST diagonal tile, which the next group's first pivot waits for, is complete after one
+            // round of panel items instead of after all of them
+            int rr = 0;
+            while (e >= 2 * sz + rr + 1) {
+                e -= 2 * sz + rr + 1;
+                ++rr;
+            }
+            if (e < 2 * sz) {
+                sweep_panel_item(D, q, c0 + rr, e, Gs, Hs);
                 if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
                 continue;
             }
-            e -= nsz * 2 * sz;
-            int mm = 0, first = 0;
-            while (e >= first + (nsz - mm)) {
-                first += nsz - mm;
-                ++mm;
-            }
+            e -= 2 * sz;
             if (MULTI && sz > 1)
-                sweep_tile_item<true>(D, q, c0 + mm + (e - first), c0 + mm, Gs, Hs);
+                sweep_tile_item<true>(D, q, c0 + rr, c0 + e, Gs, Hs);
             else
-                sweep_tile_item<false>(D, q, c0 + mm + (e - first), c0 + mm, Gs, Hs);
+                sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
             if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
         }
     }
@@ -1122,25 +1149,24 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         __syncthreads();  // everybody has read s_next
         if (item >= D.total) break;
         if (threadIdx.x == 0) s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (item >= D.item0[p + 1]) ++p;
-        int e = item - D.item0[p];
-        const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
-        const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
-        const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
-        const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
         const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
-        if (e < nrest * 2 * sz) {
-            int i = e / (2 * sz);
-            if (i >= b0) i += sz + nsz;
-            sweep_panel_item(D, p, i, e % (2 * sz), Gs, Hs);
+        if (item < D.pro) {  // panel(0): nobody is ahead of it
+            const int sz0 = min(D.g, D.nblk), nsz0 = D.ng > 1 ? min(D.g, D.nblk - sz0) : 0;
+            sweep_panel_item(D, 0, sz0 + nsz0 + item / (2 * sz0), item % (2 * sz0), Gs, Hs);
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 3, 1ull);
             }
             continue;
         }
-        e -= nrest * 2 * sz;
+        while (item - D.pro >= D.item0[p + 1]) ++p;
+        int e = item - D.pro - D.item0[p];
+        const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
+        const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
+        const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
+        const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
+        // group p's sequence: diag2(p+2) | rest(p+1) | wb(p) | rem(p) but for its tail | panel(p+1) | the tail of rem(p)
         const int n_diag2 = n2 * (n2 + 1) / 2;
         int I = -1, J = -1;
         if (e < n_diag2) {
@@ -1171,6 +1197,26 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
                     continue;
                 }
                 e -= n_wb;
+                const int n_rem = nrest > 0 ? nrest * (nrest + 1) / 2 : 0;
+                const int n_head = n_rem - min(n_rem, D.rem_tail);
+                if (e >= n_head) {
+                    // panel(p+1) for the rows outside groups p+1 and p+2: Pg(p+1) comes from the chain, which runs a group ahead,
+                    // and its other inputs were produced early in this sequence -- so the panels are ready when the tile items
+                    // of update p+1 are handed out, instead of holding all of them up at the start of every group
+                    const int n_pan = nsz > 0 ? (D.nblk - nsz - n2) * 2 * nsz : 0;
+                    if (e - n_head < n_pan) {
+                        const int ep = e - n_head;
+                        int i = ep / (2 * nsz);
+                        if (i >= c0) i += nsz + n2;
+                        sweep_panel_item(D, p + 1, i, ep % (2 * nsz), Gs, Hs);
+                        if (D.dbg && threadIdx.x == 0) {
+                            atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
+                            atomicAdd(D.dbg_main + 3, 1ull);
+                        }
+                        continue;
+                    }
+                    e -= n_pan;
+                }
                 int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
                 while ((long long)ii * (ii + 1) / 2 > e) --ii;
                 while ((long long)(ii + 1) * (ii + 2) / 2 <= e) ++ii;
@@ -1189,7 +1235,11 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         if (D.dbg && threadIdx.x == 0) {
             atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
             atomicAdd(D.dbg_main + 7, 1ull);
-            atomicAdd(D.dbg_main + 8 + 1023, (unsigned long long)clock64() - c_item);  // shader-clock cycles of the tile items
+            const unsigned long long cyc = (unsigned long long)clock64() - c_item;
+            atomicAdd(D.dbg_main + 8 + 1023, cyc);  // shader-clock cycles of the tile items
+            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p, cyc);  // ... and per group: cycles, ticks, items
+            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p + 1, wall_clock64() - t_item);
+            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p + 2, 1ull);
         }
     }
     if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work
@@ -1206,12 +1256,13 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
                              hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch, double *upd_flops)
 {
     const int nblk = n_pad / T;
-    // pivots per group: more pivots per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
+    // pivot blocks per group: more blocks per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
-    // are bound by the chain itself, which is shortest with single pivots (no scratch copy, no tile jobs).  Measured on
-    // MI355X (tools/sweep_groups.py): g = 1 is fastest up to 55 blocks, 3 from 63 to 79, 4 from 86 on.
+    // are bound by the chain itself, which is shortest with single blocks (no scratch copy, no tile jobs).  Measured on
+    // MI355X (tools/sweep_groups.py, profiles/r02_sweep_groups.log): g = 1 is fastest up to 57 blocks, 2 to 66, 3 to 89,
+    // 4 from 90 on.
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 84 ? 4 : (nblk >= 60 ? 3 : 1));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 67 ? 3 : (nblk >= 58 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     const int ng = (nblk + g - 1) / g;
     // item table on the host, then to the device (pinned staging buffer of the workspace)
@@ -1221,17 +1272,24 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     int *mit = it + (ng + 1);
     long long pos = 0, mpos = 0;
     double tiles = 0.0;
+    // remainder tiles of update p listed after panel(p+1): about one round of the workgroups, so that the panels are complete
+    // when the first tile items of update p+1 are handed out and the chain has had most of update p to produce Pg(p+1).
+    // Only where the update hides the chain (groups of three and four): on a chain-bound matrix Pg(p+1) is late anyway and
+    // workgroups parked on panel items are missing from update p (measured: config E 59.5 instead of 63.4 families/s).
+    static const int tail_env = getenv("GDCA_REM_TAIL") ? atoi(getenv("GDCA_REM_TAIL")) : -1;
+    const int rem_tail = tail_env >= 0 ? tail_env : (g >= 3 ? 2 * ws.update_cus : 0);
+    const int pro = ng > 0 ? (nblk - size(0) - (ng > 1 ? size(1) : 0)) * 2 * size(0) : 0;  // panel(0)
     for (int p = 0; p < ng; ++p) {
         it[p] = (int)pos;
         mit[p] = (int)mpos;
         const int sz = size(p), nsz = p + 1 < ng ? size(p + 1) : 0, n2 = p + 2 < ng ? size(p + 2) : 0;
         const int nrest = nblk - sz - nsz;
         mpos += m_cnt(sz) + nsz * 2 * sz + nsz * (nsz + 1) / 2;   // M(p), the next group's panel rows, its diagonal tiles
-        pos += (long long)nrest * 2 * sz;                          // panel (the other rows)
         pos += n2 * (n2 + 1) / 2;                                  // diag2
         pos += (long long)nsz * nrest;                             // rest
         pos += (long long)(nblk - sz) * sz;                        // wb
         pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
+        pos += nsz > 0 ? (long long)(nblk - nsz - n2) * 2 * nsz : 0;  // panel(p+1), the rows outside groups p+1 and p+2
         const long long pn = nblk - sz;
         tiles += (double)(pn * (pn + 1) / 2) * sz + (double)pn * sz * sz;  // tile products + the panel's (K = 128 sz, 128 sz columns)
     }
@@ -1268,24 +1326,28 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.mcu = f + 2;
     D.item0 = ws.item0_dev;
     D.mitem0 = ws.item0_dev + (ng + 1);
-    D.total = (int)pos;
+    D.total = pro + (int)pos;
     D.total_m = (int)mpos;
+    D.pro = pro;
+    D.rem_tail = rem_tail;
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
-    D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : 8;
+    // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
+    // once (16 CUs for single-block groups of small matrices, 8 otherwise); once the update hides the chain, 4 are enough and
+    // the rest go back to the tiles
+    const int mcu_rule = g == 1 ? (nblk < 28 ? 16 : 12) : ((g == 3 && nblk >= 76) || (g == 4 && nblk >= 110) ? 4 : 8);
+    D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
     D.sc = sc;
     // GDCA_SWEEP_TRACE=file: stamps of the M-list items of this inverse are written to `file` (debug aid; synchronises)
     static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
     unsigned long long *dbg = nullptr;
     if (trace_path) {
-        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024) * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024) * sizeof(unsigned long long), s0);
+        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024 + 3 * ng) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024 + 3 * ng) * sizeof(unsigned long long), s0);
     }
     D.dbg = dbg;
     D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
-    // workgroup slots: two per CU; fewer when the caller wants room left beside the sweep (a pipeline peer's reweighting
-    // and tally kernels then co-reside with ONE sweep workgroup on some CUs: VALU / LDS-atomic work beside MFMA work)
-    const unsigned grid = (unsigned)std::max(16, 2 * ws.update_cus - ws.free_slots);
+    const unsigned grid = (unsigned)(2 * ws.update_cus);  // two 256-VGPR workgroups per CU: every register file full
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
     if (g > 1)
@@ -1295,7 +1357,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
     if (dbg) {
         (void)hipStreamSynchronize(s0);
-        std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024);
+        std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024 + 3 * (size_t)ng);
         (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipMemcpy(hm.data(), dbg + 2 * (mpos + 1), hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
@@ -1316,6 +1378,12 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
                     idle_end / grid, (double)(tend - tmin) / 100.0);
             fprintf(fp, "# shader clock during tile items: %.3f GHz (s_memtime cycles / 100 MHz wall clock)\n",
                     hm[6] ? (double)hm[8 + 1023] / (double)hm[6] * 0.1 : 0.0);
+            fprintf(fp, "# per group: tile items, us each, shader clock GHz:");
+            for (int p = 0; p < ng; ++p) {
+                const unsigned long long *gp = &hm[8 + 1024 + 3 * (size_t)p];
+                if (gp[2]) fprintf(fp, " [%d] %llu %.1f %.3f", p, gp[2], gp[1] / 100.0 / gp[2], gp[1] ? (double)gp[0] / (double)gp[1] * 0.1 : 0.0);
+            }
+            fprintf(fp, "\n");
             unsigned long long t0 = ~0ull;
             for (size_t x = 0; x < h.size(); x += 2)
                 if (h[x] && h[x] < t0) t0 = h[x];

@@ -290,9 +290,12 @@ static size_t tally_lds_bytes(int s, int TJ)
 
 int gdca_tally_tj(int q)
 {
+    // 16 columns per workgroup: 80 KB of histograms at s = 20, so TWO 1024-thread workgroups share a CU and one's staging
+    // barriers and epilogue hide behind the other's atomics (measured at config C: 3.26 ms against 4.03 ms with 32 columns
+    // and one workgroup per CU; GDCA_TALLY_TJ=32 brings the wide form back for comparison)
     static const int tj_env = getenv("GDCA_TALLY_TJ") ? atoi(getenv("GDCA_TALLY_TJ")) : 0;
-    if (tj_env == 16) return 16;
-    return tally_lds_bytes(q - 1, 32) <= 160 * 1024 ? 32 : 16;
+    if (tj_env == 32 && tally_lds_bytes(q - 1, 32) <= 160 * 1024) return 32;
+    return 16;
 }
 
 void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,

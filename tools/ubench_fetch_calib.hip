@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void k_mix(const double *__restrict__ c_in, do
         double acc[64];
 #pragma unroll
         for (int u = 0; u < 64; ++u) acc[u] = ci[threadIdx.x + 256 * u];
-#pragma unroll 4
-        for (int u = 0; u < 6 * 32; ++u) {
+#pragma unroll
+        for (int u = 0; u < 6 * 32; ++u) {  // fully unrolled: acc[] must stay in registers (a rolled loop indexes it dynamically -> scratch)
             const double2 v = pp[threadIdx.x + 256 * u];
             acc[u & 63] += v.x * 1e-9 + v.y * 1e-9;
         }
