@@ -691,6 +691,71 @@ __device__ __forceinline__ int m_items(int sz)
     return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1));
 }
 
+// ---- the main list: item number -> what to do --------------------------------------------------------------------------
+// The first D.pro items are panel(0); then, group after group,
+//     diag2(p+2) | rest(p+1) | wb(p) | rem(p) but for its tail | panel(p+1) | the tail of rem(p)
+// (panel(p+1) covers the rows outside groups p+1 and p+2: Pg(p+1) comes from the chain, which runs a group ahead, and its
+// other inputs were produced early in this sequence -- so the panels are complete when the tile items of update p+1 are
+// handed out, instead of holding all of them up at the start of every group).
+// kind 0: panel item (group p, row block a, part b); 1: tile item (group p, tile (a, b)); 2: write-back item (group p,
+// index a); 3: nothing (a remainder slot that belongs to diag2).  `p` is the caller's running group (items ascend).
+struct MainItem {
+    int kind, p, a, b;
+};
+__device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int item)
+{
+    if (item < D.pro) {  // panel(0): nobody is ahead of it
+        const int sz0 = min(D.g, D.nblk), nsz0 = D.ng > 1 ? min(D.g, D.nblk - sz0) : 0;
+        return MainItem{0, 0, sz0 + nsz0 + item / (2 * sz0), item % (2 * sz0)};
+    }
+    while (item - D.pro >= D.item0[p + 1]) ++p;
+    int e = item - D.pro - D.item0[p];
+    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
+    const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
+    const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
+    const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
+    const int n_diag2 = n2 * (n2 + 1) / 2;
+    if (e < n_diag2) {
+        int mm = 0, first = 0;
+        while (e >= first + (n2 - mm)) {
+            first += n2 - mm;
+            ++mm;
+        }
+        return MainItem{1, p, d0 + mm + (e - first), d0 + mm};
+    }
+    e -= n_diag2;
+    if (e < nsz * nrest) {
+        const int mm = e / nrest, local = e % nrest;
+        const int b = local < b0 ? local : local - b0 + d0;
+        const int cb = c0 + mm;
+        return MainItem{1, p, b > cb ? b : cb, b > cb ? cb : b};
+    }
+    e -= nsz * nrest;
+    const int n_wb = (D.nblk - sz) * sz;
+    if (e < n_wb) return MainItem{2, p, e, 0};
+    e -= n_wb;
+    const int n_rem = nrest > 0 ? nrest * (nrest + 1) / 2 : 0;
+    const int n_head = n_rem - min(n_rem, D.rem_tail);
+    if (e >= n_head) {
+        const int n_pan = nsz > 0 ? (D.nblk - nsz - n2) * 2 * nsz : 0;
+        if (e - n_head < n_pan) {
+            const int ep = e - n_head;
+            int i = ep / (2 * nsz);
+            if (i >= c0) i += nsz + n2;
+            return MainItem{0, p + 1, i, ep % (2 * nsz)};
+        }
+        e -= n_pan;
+    }
+    int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((long long)ii * (ii + 1) / 2 > e) --ii;
+    while ((long long)(ii + 1) * (ii + 2) / 2 <= e) ++ii;
+    int jj = e - (int)((long long)ii * (ii + 1) / 2);
+    if (ii >= b0) ii += sz + nsz;
+    if (jj >= b0) jj += sz + nsz;
+    if (jj >= d0 && ii < d0 + n2) return MainItem{3, p, 0, 0};  // inside the diagonal super-block of group p+2: done as diag2
+    return MainItem{1, p, ii, jj};
+}
+
 // One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: operand images in the first halves
 // of Gs / Hs, Pms and the flag behind them).  ONE call site in the kernel: the unrolled 16-step micro-sweep is long.
 __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *P,
@@ -964,15 +1029,20 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 }
 
 // ---- one tile of update p:  A_IJ += sum_w G_w[I] H_w[J]^T ------------------------------------------------------------------
+// `ready`: the flags were seen set already (by the previous item's look-ahead, see the end of this function).
+// `nxt`, `s_next`, `s_ready` (main-list callers; thread 0's value / LDS words): the workgroup's NEXT item number, in flight as
+// an atomic since the start of this item.  While this item's stores drain, thread 0 looks that item up and, if it is a tile
+// item, reads its flags: the next trip then starts without the counter's and the flags' round trips (~3 us of a ~105 us item).
 template <bool MULTI>
 __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
-                                                double (*Hs)[KC][LDS_LD])
+                                                double (*Hs)[KC][LDS_LD], int ready = 0, int nxt = 0, int *s_next = nullptr,
+                                                int *s_ready = nullptr)
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
     unsigned *genp = D.gen + (size_t)I * D.nblk + J;
-    if (tid == 0) {
+    if (tid == 0 && !ready) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         const unsigned need = 2u * (unsigned)sz;
         // the three flags are loaded TOGETHER (one L2 round trip, ~1.5 us under load, instead of three dependent ones)
@@ -1032,6 +1102,21 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
                 const int c = wc * 64 + tm * 16 + lq + 4 * reg;
                 store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
             }
+    if (s_next && tid == 0) {
+        *s_next = nxt;
+        int r = 0;
+        if (nxt < D.total) {
+            int ph = p;
+            const MainItem ni = main_decode(D, ph, nxt);
+            if (ni.kind == 1) {
+                const int nsz2 = min(D.g, D.nblk - ni.p * D.g);
+                const unsigned f1 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.a), f2 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.b),
+                               f3 = flag_load(D.gen + (size_t)ni.a * D.nblk + ni.b);
+                r = (f1 >= 2u * (unsigned)nsz2) & (f2 >= 2u * (unsigned)nsz2) & (f3 >= (unsigned)ni.p);
+            }
+        }
+        *s_ready = r;
+    }
     publish_wt_begin();
     if (tid == 0) {
         __hip_atomic_store(genp, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1140,106 +1225,55 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     }
     int p = 0;  // group whose sequence the last item belonged to (items come in ascending order)
     // the NEXT item is requested while the current one is being worked on (the returning atomic takes a microsecond or two
-    // under load): s_next holds the item for the next trip
-    __shared__ int s_next;
-    if (threadIdx.x == 0) s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // under load); its number stays in a register of thread 0 until the end of the item (so that nobody waits for it) and
+    // reaches the others through s_next; s_ready = the next item is a tile item whose flags were already seen set
+    __shared__ int s_next, s_ready;
+    if (threadIdx.x == 0) {
+        s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ready = 0;
+    }
     for (;;) {
         __syncthreads();
-        const int item = s_next;
-        __syncthreads();  // everybody has read s_next
+        const int item = s_next, rdy = s_ready;
+        __syncthreads();  // everybody has read them
         if (item >= D.total) break;
-        if (threadIdx.x == 0) s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int nxt = 0;
+        if (threadIdx.x == 0) nxt = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
-        if (item < D.pro) {  // panel(0): nobody is ahead of it
-            const int sz0 = min(D.g, D.nblk), nsz0 = D.ng > 1 ? min(D.g, D.nblk - sz0) : 0;
-            sweep_panel_item(D, 0, sz0 + nsz0 + item / (2 * sz0), item % (2 * sz0), Gs, Hs);
+        const MainItem it = main_decode(D, p, item);
+        if (it.kind == 1) {
+            if (MULTI && min(D.g, D.nblk - it.p * D.g) > 1)
+                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+            else
+                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+            if (D.dbg && threadIdx.x == 0) {
+                atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
+                atomicAdd(D.dbg_main + 7, 1ull);
+                const unsigned long long cyc = (unsigned long long)clock64() - c_item;
+                atomicAdd(D.dbg_main + 8 + 1023, cyc);  // shader-clock cycles of the tile items
+                atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p, cyc);  // ... and per group: cycles, ticks, items
+                atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 1, wall_clock64() - t_item);
+                atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 2, 1ull);
+            }
+            continue;
+        }
+        if (it.kind == 0) {
+            sweep_panel_item(D, it.p, it.a, it.b, Gs, Hs);
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 3, 1ull);
             }
-            continue;
-        }
-        while (item - D.pro >= D.item0[p + 1]) ++p;
-        int e = item - D.pro - D.item0[p];
-        const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
-        const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
-        const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
-        const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
-        // group p's sequence: diag2(p+2) | rest(p+1) | wb(p) | rem(p) but for its tail | panel(p+1) | the tail of rem(p)
-        const int n_diag2 = n2 * (n2 + 1) / 2;
-        int I = -1, J = -1;
-        if (e < n_diag2) {
-            int mm = 0, first = 0;
-            while (e >= first + (n2 - mm)) {
-                first += n2 - mm;
-                ++mm;
-            }
-            I = d0 + mm + (e - first);
-            J = d0 + mm;
-        } else {
-            e -= n_diag2;
-            if (e < nsz * nrest) {
-                const int mm = e / nrest, local = e % nrest;
-                const int b = local < b0 ? local : local - b0 + d0;
-                const int cb = c0 + mm;
-                I = b > cb ? b : cb;
-                J = b > cb ? cb : b;
-            } else {
-                e -= nsz * nrest;
-                const int n_wb = (D.nblk - sz) * sz;
-                if (e < n_wb) {
-                    sweep_wb_item(D, p, e, Gs);
-                    if (D.dbg && threadIdx.x == 0) {
-                        atomicAdd(D.dbg_main + 4, wall_clock64() - t_item);
-                        atomicAdd(D.dbg_main + 5, 1ull);
-                    }
-                    continue;
-                }
-                e -= n_wb;
-                const int n_rem = nrest > 0 ? nrest * (nrest + 1) / 2 : 0;
-                const int n_head = n_rem - min(n_rem, D.rem_tail);
-                if (e >= n_head) {
-                    // panel(p+1) for the rows outside groups p+1 and p+2: Pg(p+1) comes from the chain, which runs a group ahead,
-                    // and its other inputs were produced early in this sequence -- so the panels are ready when the tile items
-                    // of update p+1 are handed out, instead of holding all of them up at the start of every group
-                    const int n_pan = nsz > 0 ? (D.nblk - nsz - n2) * 2 * nsz : 0;
-                    if (e - n_head < n_pan) {
-                        const int ep = e - n_head;
-                        int i = ep / (2 * nsz);
-                        if (i >= c0) i += nsz + n2;
-                        sweep_panel_item(D, p + 1, i, ep % (2 * nsz), Gs, Hs);
-                        if (D.dbg && threadIdx.x == 0) {
-                            atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
-                            atomicAdd(D.dbg_main + 3, 1ull);
-                        }
-                        continue;
-                    }
-                    e -= n_pan;
-                }
-                int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-                while ((long long)ii * (ii + 1) / 2 > e) --ii;
-                while ((long long)(ii + 1) * (ii + 2) / 2 <= e) ++ii;
-                int jj = e - (int)((long long)ii * (ii + 1) / 2);
-                if (ii >= b0) ii += sz + nsz;
-                if (jj >= b0) jj += sz + nsz;
-                I = ii;
-                J = jj;
-                if (J >= d0 && I < d0 + n2) continue;  // inside the diagonal super-block of group p+2: done above (diag2)
+        } else if (it.kind == 2) {
+            sweep_wb_item(D, it.p, it.a, Gs);
+            if (D.dbg && threadIdx.x == 0) {
+                atomicAdd(D.dbg_main + 4, wall_clock64() - t_item);
+                atomicAdd(D.dbg_main + 5, 1ull);
             }
         }
-        if (MULTI && sz > 1)
-            sweep_tile_item<true>(D, p, I, J, Gs, Hs);
-        else
-            sweep_tile_item<false>(D, p, I, J, Gs, Hs);
-        if (D.dbg && threadIdx.x == 0) {
-            atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
-            atomicAdd(D.dbg_main + 7, 1ull);
-            const unsigned long long cyc = (unsigned long long)clock64() - c_item;
-            atomicAdd(D.dbg_main + 8 + 1023, cyc);  // shader-clock cycles of the tile items
-            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p, cyc);  // ... and per group: cycles, ticks, items
-            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p + 1, wall_clock64() - t_item);
-            atomicAdd(D.dbg_main + 8 + 1024 + 3 * p + 2, 1ull);
+        if (threadIdx.x == 0) {
+            s_next = nxt;
+            s_ready = 0;
         }
     }
     if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work

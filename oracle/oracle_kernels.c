@@ -76,23 +76,34 @@ uint64_t orc_pair_identity_sum(const int8_t *Z, int N, int M)
     return tot;
 }
 
-/* n[k] (pre-set to 1 by the caller) += #{l != k : Hamming(k,l) < thresh} */
+/* n[k] (pre-set to 1 by the caller) += #{l != k : Hamming(k,l) < thresh}
+ * Cache-blocked: a block of KB sequences k meets blocks of LB sequences l (both resident in L1/L2 while they are
+ * compared), instead of streaming the whole alignment past every k (which is DRAM-bound on a many-core host).  Integer
+ * counts: the result does not depend on the blocking or on the thread count. */
 void orc_neighbour_counts(const int8_t *Z, int N, int M, int thresh, int32_t *n)
 {
+    const int KB = 32, LB = 256;
+    const int nkb = (M + KB - 1) / KB;
 #pragma omp parallel
     {
         int32_t *loc = (int32_t *)calloc((size_t)M, sizeof(int32_t));
-#pragma omp for schedule(dynamic, 16)
-        for (int k = 0; k < M - 1; ++k) {
-            const int8_t *a = Z + (size_t)k * N;
-            int32_t mine = 0;
-            for (int l = k + 1; l < M; ++l) {
-                if (hamming_bytes(a, Z + (size_t)l * N, N) < thresh) {
-                    ++mine;
-                    ++loc[l];
+#pragma omp for schedule(dynamic, 1)
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int k0 = kb * KB, k1 = k0 + KB < M ? k0 + KB : M;
+            for (int l0 = k0; l0 < M; l0 += LB) {
+                const int l1 = l0 + LB < M ? l0 + LB : M;
+                for (int k = k0; k < k1; ++k) {
+                    const int8_t *a = Z + (size_t)k * N;
+                    int32_t mine = 0;
+                    for (int l = (l0 > k + 1 ? l0 : k + 1); l < l1; ++l) {
+                        if (hamming_bytes(a, Z + (size_t)l * N, N) < thresh) {
+                            ++mine;
+                            ++loc[l];
+                        }
+                    }
+                    loc[k] += mine;
                 }
             }
-            loc[k] += mine;
         }
 #pragma omp critical
         for (int k = 0; k < M; ++k) n[k] += loc[k];

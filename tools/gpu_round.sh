@@ -1,5 +1,6 @@
 #!/bin/bash
-# Everything the round's measured numbers come from, in one reproducible pass on the GPU box:
+# First half of the round's measurements (tests, bench lines of every configuration, kernel statistics); the counter
+# passes, traces and micro-benchmarks are tools/gpu_round2.sh:
 #   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/gpu_round.sh r02'
 # Output under gpurun_out/<tag>/; the summaries are copied into profiles/ by hand afterwards (tools/prof_summary.py).
 tag=${1:-rXX}
@@ -16,7 +17,6 @@ timeout 900 python bench.py --score DI > $out/bench_C_DI.json 2> $out/bench_C_DI
 timeout 600 python bench.py --config B --steps 50 --warmup 5 > $out/bench_B.json 2> $out/bench_B.err
 timeout 900 python bench.py --config D --steps 5 --warmup 2 > $out/bench_D.json 2> $out/bench_D.err
 timeout 900 python bench.py --config E --steps 2 --warmup 1 > $out/bench_E.json 2> $out/bench_E.err
-timeout 900 python bench.py --config E --steps 2 --warmup 1 --pipeline 2 > $out/bench_E_p2.json 2> $out/bench_E_p2.err
 timeout 900 python bench.py --pipeline 2 --no-cpu-baseline > $out/bench_C_p2.json 2> $out/bench_C_p2.err
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import sys, json
@@ -33,16 +33,7 @@ done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_frob -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof_frob.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_di -- python3 $GRAFT_REPO_ROOT/bench.py --score DI --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof_di.log 2>&1
-# PMC passes: one counter set each, kernel-trace only
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/pmc_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/calib_$c -- $GRAFT_REPO_ROOT/tools/_bin/ubench_fetch_calib > $GRAFT_REPO_ROOT/$out/calib_$c.log 2>&1
-done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/pmc_mfma -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/pmc_mfma.log 2>&1
 cd $GRAFT_REPO_ROOT
-# the in-kernel trace of one inverse at config C and D (item times, waits, shader clock)
-GDCA_SWEEP_TRACE=$out/sweep_trace_C.txt timeout 300 python tools/sweep_trace.py 10000 > $out/sweep_trace_C.log 2>&1
-GDCA_SWEEP_TRACE=$out/sweep_trace_D.txt timeout 300 python tools/sweep_trace.py 20000 > $out/sweep_trace_D.log 2>&1
 # keep the merged-back directory small: the per-launch CSVs are what the summaries are made from
 find $out -name "*.csv" -size +8M -delete
 find $out -name "*agent_info*" -delete

@@ -7,6 +7,9 @@ mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -c "import torch" 2>/dev/null
+( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "schedule" > $out/pytest_schedules.log 2>&1; tail -2 $out/pytest_schedules.log )
+timeout 600 python tools/stress_inverse.py > $out/stress_inverse.log 2>&1; tail -3 $out/stress_inverse.log
+timeout 600 python bench.py > $out/bench_C_frob.json 2> $out/bench_C_frob.err
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/pmc_$c.log 2>&1
@@ -17,9 +20,8 @@ cd $R
 GDCA_SWEEP_TRACE=$out/sweep_trace_C.txt timeout 300 python tools/sweep_trace.py 10000 > $out/sweep_trace_C.log 2>&1
 GDCA_SWEEP_TRACE=$out/sweep_trace_D.txt timeout 300 python tools/sweep_trace.py 20000 > $out/sweep_trace_D.log 2>&1
 GDCA_SWEEP_TRACE=$out/sweep_trace_B.txt timeout 300 python tools/sweep_trace.py 2560 5,6 > $out/sweep_trace_B.log 2>&1
+GDCA_SWEEP_TRACE=$out/clock_ramp_C.txt timeout 300 python tools/clock_ramp.py 10000 8 > $out/clock_ramp_C.log 2>&1
 head -4 $out/sweep_trace_C.log
 find $out -name "*agent_info*" -delete
 bash tools/gpu_ubench.sh $tag > $out/ubench.log 2>&1
-bash tools/_bin/gpucmd.sh > $out/pipeline_experiment.log 2>&1
-cat $out/pipeline_experiment.log
 du -sh $out

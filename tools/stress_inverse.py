@@ -1,6 +1,7 @@
-"""Stress check of the SPD inverse schedules on the GPU: for a ladder of sizes (serial, single-pivot look-ahead,
-pivot pairs; even and odd block counts) the inverse must be bit-identical run to run (a race between the two
-streams would show up as run-to-run differences) and satisfy A X v = v on random probes.
+"""Stress check of the SPD inverse on the GPU: for a ladder of sizes (single-block groups, groups of two, three and four
+blocks; even and odd block counts; ragged last blocks) the inverse must be bit-identical run to run -- the persistent
+sweep kernel orders the updates of every tile by flags, so a missing dependency would show up as run-to-run differences
+-- symmetric, and satisfy A X v = v on random probes.
 
     python tools/stress_inverse.py [--repeat 3]
 """
@@ -19,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--sizes", type=int, nargs="*",
-                    default=[100, 128, 129, 384, 1000, 2560, 5000, 8320, 8448, 8576, 9000, 10000, 10112, 11000])
+                    default=[100, 128, 129, 384, 1000, 2560, 5000, 7424, 8320, 8448, 8576, 9000, 10000, 10112, 11000, 11600])
     args = ap.parse_args()
     ctx = g.Context(0)
     rng = np.random.default_rng(11)
