@@ -1080,11 +1080,15 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
 #pragma unroll 1
             for (int c = 0; c < total; ++c) {
                 chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
+#if !defined(GDCA_X_NOSTORE)
                 if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
+#endif
+#if !defined(GDCA_X_NOLOAD)
                 if (c + 2 < total) {
                     const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
                     stage_load<false, 4>(R, Gp + (size_t)op * D.pstride + go, pld, Hp + (size_t)op * D.pstride + ho, pld, kc, tid);
                 }
+#endif
                 chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
                 __syncthreads();
             }
