@@ -257,8 +257,9 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 40 for B / C, 10 for D, 2 for E: about a "
+                    "second or more of GPU time, long enough not to be a clock-ramp artefact)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5, 2, 1)")
     ap.add_argument("--config", default="C", choices=sorted(CONFIGS))
     ap.add_argument("--score", default="frob")
     ap.add_argument("--N", type=int, default=0, help="override the config's N (configs B, C, D)")
@@ -275,6 +276,10 @@ def main():
     ap.add_argument("--gate", action="store_true",
                     help="with --pipeline > 1: let the SPD-inverse stages of the families in flight take turns")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"B": 40, "C": 40, "D": 10, "E": 2}[args.config]
+    if args.warmup is None:
+        args.warmup = {"B": 5, "C": 5, "D": 2, "E": 1}[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
