@@ -49,9 +49,11 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
         assert np.array_equal(np.isfinite(S), np.isfinite(S_o))
         return
     if np.max(np.abs(S_o)) < 1e-10:
-        # no signal at all (e.g. two all-gap sequences): the exact scores are 0 and both sides hold rounding noise of the
-        # O(1) inverse-covariance entries they were computed from
-        assert np.max(np.abs(S)) < 1e-10
+        # no signal at all (e.g. two all-gap sequences): the exact scores are 0 and each side holds either rounding noise of
+        # the O(1) inverse-covariance entries they were computed from, or -- when that noise happens to cancel to an exact 0
+        # in every pair -- the 0/0 of correct_APC (src/GaussDCA.jl:78-86 divides by the sum of all scores), as the reference
+        # itself would
+        assert np.max(np.abs(np.nan_to_num(S, nan=0.0))) < 1e-10
         return
     # DI = s/2 log(1/2) + 1/2 sum_k log(1 + sqrt(1 + 4 gamma_k)) is a difference of O(s) quantities: with a pseudocount
     # near 1 the couplings vanish, the scores drop to ~1e-10 and BOTH implementations (and DCAUtils, which evaluates the
