@@ -156,8 +156,8 @@ gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
     gdca_status st = gdca_ctx_create_on_stream(device_id, nullptr, out);
     if (st != GDCA_OK) return st;
     gdca_ctx *ctx = *out;
-    // the main stream carries the pivot/panel chain of the SPD inverse (the critical path of the
-    // look-ahead schedule): give it the highest priority the device offers
+    // the context's own stream: non-blocking, at the highest priority the device offers (a family's kernels should not queue
+    // behind whatever else the process runs on the device)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {

@@ -5,13 +5,13 @@
 // D = A_KK (the Schur complement at that point -- the same matrix Cholesky would factor, so the
 // positive-definiteness test and the `info` index are the same as dpotrf's), P = D^-1, G = A_{.,K}:
 //       A_ij <- A_ij - G_i P G_j^T   (i, j != K),   A_{.,K} <- G P,   A_KK <- -P.
-// After all pivots A = -C^-1.  Same n^3 flop count as dpotrf+dpotri, but every step is ONE launch of
-// ~(n/128)^2/2 identical 128x128 tile products over the whole lower triangle: no shrinking trailing matrix, no
-// trtri/lauum dependency chains, no tail of tiny launches -- the shape a 256-CU chip wants.  The matrix stays
-// symmetric throughout, only the lower triangle (with full diagonal tiles) is touched.  Pivots are taken in groups
-// of up to four 128-blocks (one update launch of depth K = 128 g per group); the serial part of a group -- the
-// inverse of its 128 g x 128 g diagonal super-block -- runs on a small dense scratch copy while the bulk of the
-// look-ahead work proceeds beside it (see the driver at the end of this file).
+// After all pivots A = -C^-1.  Same n^3 flop count as dpotrf+dpotri, but every step is ~(n/128)^2/2 identical 128x128
+// tile products over the whole lower triangle: no shrinking trailing matrix, no trtri/lauum dependency chains, no tail
+// of tiny steps -- the shape a 256-CU chip wants.  The matrix stays symmetric throughout, only the lower triangle (with
+// full diagonal tiles) is touched.  Pivots are taken in groups of up to four 128-blocks (tile products of depth
+// K = 128 g per group); the serial part of a group -- the inverse of its 128 g x 128 g diagonal super-block -- runs on a
+// small dense scratch copy beside the tile products of the previous group.  The WHOLE inverse is one persistent launch
+// (k_sweep, second half of this file): work items off a device-wide counter, dependencies as flags in HBM.
 //
 // Tile product: 256 threads = 4 waves in 2 x 2, each wave a 64 x 64 sub-tile as 4 x 4
 // v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  The f64 C/D fragment is
@@ -545,8 +545,8 @@ struct UpdateChunks {
 
 // Write-back of the new column block: A[i,k] = G_i P = -H_i  (A[k,i] = (G_i P)^T for i < k).  Not done by
 // the panel kernel because the two panel workgroups of a row block both read the OLD A[i,k] as their G
-// operand.  Runs as extra workgroups of the look-ahead update launch (or as a launch of its own at the
-// last step): every thread first loads all of its 64 values, then stores them.
+// operand.  A work item of its own in the sweep kernel (wb): every thread first loads all of its 64 values, then
+// stores them.
 __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, size_t ld, int kblk, int i,
                                                      const double *__restrict__ Hbuf, size_t pld, double (*Ts)[LDS_LD])
 {
