@@ -635,6 +635,7 @@ struct SweepDesc {
     int total, total_m;
     int pro;               // main list: the first `pro` items are panel(0); group p's sequence follows at pro + item0[p]
     int rem_tail;          // remainder tiles of update p that are listed AFTER panel(p+1)
+    int ppb;               // main-list panel items per pivot block and row: 2 (128 x 64 each) or 1 (128 x 128)
     int n_mcu;             // compute units to elect for the M list (<= 16)
     int n_real;
     gdca_dev_scalars *sc;
@@ -706,7 +707,7 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
 {
     if (item < D.pro) {  // panel(0): nobody is ahead of it
         const int sz0 = min(D.g, D.nblk), nsz0 = D.ng > 1 ? min(D.g, D.nblk - sz0) : 0;
-        return MainItem{0, 0, sz0 + nsz0 + item / (2 * sz0), item % (2 * sz0)};
+        return MainItem{0, 0, sz0 + nsz0 + item / (D.ppb * sz0), item % (D.ppb * sz0)};
     }
     while (item - D.pro >= D.item0[p + 1]) ++p;
     int e = item - D.pro - D.item0[p];
@@ -737,12 +738,12 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     const int n_rem = nrest > 0 ? nrest * (nrest + 1) / 2 : 0;
     const int n_head = n_rem - min(n_rem, D.rem_tail);
     if (e >= n_head) {
-        const int n_pan = nsz > 0 ? (D.nblk - nsz - n2) * 2 * nsz : 0;
+        const int n_pan = nsz > 0 ? (D.nblk - nsz - n2) * D.ppb * nsz : 0;
         if (e - n_head < n_pan) {
             const int ep = e - n_head;
-            int i = ep / (2 * nsz);
+            int i = ep / (D.ppb * nsz);
             if (i >= c0) i += nsz + n2;
-            return MainItem{0, p + 1, i, ep % (2 * nsz)};
+            return MainItem{0, p + 1, i, ep % (D.ppb * nsz)};
         }
         e -= n_pan;
     }
@@ -959,15 +960,19 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- panel(p): G_i and 64 columns of H_i = -G_i Pg for one row block ------------------------------------------------------
-// (i = the row block, y = which 64 of the m columns of H)
+// ---- panel(p): G_i and 32 TM columns of H_i = -G_i Pg for one row block ---------------------------------------------------
+// (i = the row block, y = which 32 TM of the m columns of H).  TM = 2: 64 columns, two items per pivot block -- the chain's
+// form (M list), where the next group's rows are latency-critical; TM = 4: 128 columns, one item per pivot block -- the main
+// list's form for multi-block groups, where the panels are throughput (a 128 x 64 product does half the MFMA work per staged
+// operand byte: 73 us per item against 108 us for twice the flops).  The row's counter rb advances by TM / 2 per item.
+template <int TM>
 __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int i, int y, double (*Gs)[KC][LDS_LD],
                                                  double (*Hs)[KC][LDS_LD])
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
-    const int w = y >> 1, ch = y & 1;
+    const int w = TM == 2 ? y >> 1 : y, ch = TM == 2 ? (y & 1) : 0;
     if (tid == 0) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         // Pg(p); the group's columns of row i at generation p; the panel buffers of parity p free (group p-2 complete): all
@@ -994,9 +999,9 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     const size_t ld = D.ld, pgld = (size_t)sz * T;
     const double *Pg = (p & 1) ? D.Pg1 : D.Pg0;
     double *G0 = D.G0 + (size_t)4 * (p & 1) * D.pstride, *H0 = D.H0 + (size_t)4 * (p & 1) * D.pstride;
-    double4_t acc[2][4];
+    double4_t acc[TM][4];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
     // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
@@ -1005,27 +1010,27 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     if (i > b0) {  // below the group: G_i = A[i, k]
 #pragma unroll 1
         for (int v = 0; v < sz; ++v)
-            tile_product<false, 2>(acc, D.A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+            tile_product<false, TM>(acc, D.A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
                                    Hs[0], gcopy0 ? gcopy0 + (size_t)v * D.pstride : nullptr, ld);
     } else {       // above the group: G_i = A[k, i]^T
 #pragma unroll 1
         for (int v = 0; v < sz; ++v)
-            tile_product<true, 2>(acc, D.A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
+            tile_product<true, TM>(acc, D.A + (size_t)(b0 + v) * T + (size_t)i * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
                                   Hs[0], gcopy0 ? gcopy0 + (size_t)v * D.pstride : nullptr, ld);
     }
     double *Hw = H0 + (size_t)w * D.pstride + (size_t)i * T;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wr * 64 + tn * 16 + l15;
-                const int c = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
+                const int c = ch * 64 + wc * (16 * TM) + tm * 16 + lq + 4 * reg;
                 Hw[(size_t)r + (size_t)c * ld] = -acc[tm][tn][reg];
             }
     publish_begin();
-    if (tid == 0) __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + i, (unsigned)(TM / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- one tile of update p:  A_IJ += sum_w G_w[I] H_w[J]^T ------------------------------------------------------------------
@@ -1215,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
                 ++rr;
             }
             if (e < 2 * sz) {
-                sweep_panel_item(D, q, c0 + rr, e, Gs, Hs);
+                sweep_panel_item<2>(D, q, c0 + rr, e, Gs, Hs);
                 if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
                 continue;
             }
@@ -1263,7 +1268,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             continue;
         }
         if (it.kind == 0) {
-            sweep_panel_item(D, it.p, it.a, it.b, Gs, Hs);
+            if (D.ppb == 1)
+                sweep_panel_item<4>(D, it.p, it.a, it.b, Gs, Hs);
+            else
+                sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 3, 1ull);
@@ -1316,7 +1324,11 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // workgroups parked on panel items are missing from update p (measured: config E 59.5 instead of 63.4 families/s).
     static const int tail_env = getenv("GDCA_REM_TAIL") ? atoi(getenv("GDCA_REM_TAIL")) : -1;
     const int rem_tail = tail_env >= 0 ? tail_env : (g >= 3 ? 2 * ws.update_cus : 0);
-    const int pro = ng > 0 ? (nblk - size(0) - (ng > 1 ? size(1) : 0)) * 2 * size(0) : 0;  // panel(0)
+    // main-list panel items: one 128 x 128 item per pivot block and row where the panels are throughput (multi-block groups of
+    // three and four), two 128 x 64 halves where their latency counts
+    static const int ppb_env = getenv("GDCA_PANEL_HALVES") ? atoi(getenv("GDCA_PANEL_HALVES")) : -1;
+    const int ppb = ppb_env >= 0 ? (ppb_env ? 2 : 1) : (g >= 3 ? 1 : 2);
+    const int pro = ng > 0 ? (nblk - size(0) - (ng > 1 ? size(1) : 0)) * ppb * size(0) : 0;  // panel(0)
     for (int p = 0; p < ng; ++p) {
         it[p] = (int)pos;
         mit[p] = (int)mpos;
@@ -1327,7 +1339,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
         pos += (long long)nsz * nrest;                             // rest
         pos += (long long)(nblk - sz) * sz;                        // wb
         pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
-        pos += nsz > 0 ? (long long)(nblk - nsz - n2) * 2 * nsz : 0;  // panel(p+1), the rows outside groups p+1 and p+2
+        pos += nsz > 0 ? (long long)(nblk - nsz - n2) * ppb * nsz : 0;  // panel(p+1), the rows outside groups p+1 and p+2
         const long long pn = nblk - sz;
         tiles += (double)(pn * (pn + 1) / 2) * sz + (double)pn * sz * sz;  // tile products + the panel's (K = 128 sz, 128 sz columns)
     }
@@ -1368,6 +1380,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.total_m = (int)mpos;
     D.pro = pro;
     D.rem_tail = rem_tail;
+    D.ppb = ppb;
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once (16 CUs for single-block groups of small matrices, 8 otherwise); once the update hides the chain, 4 are enough and
