@@ -342,13 +342,13 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     CHK(ensure(ctx, ctx->G, (size_t)8 * pbytes));
     CHK(ensure(ctx, ctx->H, (size_t)8 * pbytes));
     CHK(ensure(ctx, ctx->P, (size_t)GDCA_TILE * GDCA_TILE * sizeof(double)));
-    CHK(ensure(ctx, ctx->Sg, 4 * sg + fbytes + (size_t)2 * (nblk + 2) * sizeof(int)));
-    if (ctx->item0_cap < 2 * (nblk + 2)) {
+    CHK(ensure(ctx, ctx->Sg, 4 * sg + fbytes + (size_t)3 * (nblk + 2) * sizeof(int)));
+    if (ctx->item0_cap < 3 * (nblk + 2)) {
         if (ctx->item0_host) HIPCHK(hipHostFree(ctx->item0_host));
         ctx->item0_host = nullptr;
         ctx->item0_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&ctx->item0_host, (size_t)2 * (nblk + 2) * sizeof(int), hipHostMallocDefault));
-        ctx->item0_cap = 2 * (nblk + 2);
+        HIPCHK(hipHostMalloc((void **)&ctx->item0_host, (size_t)3 * (nblk + 2) * sizeof(int), hipHostMallocDefault));
+        ctx->item0_cap = 3 * (nblk + 2);
     }
     gdca_inverse_ws ws;
     for (int w = 0; w < 8; ++w) {

@@ -630,6 +630,8 @@ struct SweepDesc {
     double *Pg0, *Pg1;     // Pg by group parity, ld = 128 sz
     double *Pw;            // 128 x 128: inverse of the current pivot block
     unsigned *gen, *rb, *mc, *done, *next, *next_m, *mcu;
+    const int *gs;         // [ng + 1]: first block of group p (groups need not have the same size: a short ramp 1, 2, .. opens
+                           // the sweep so that the first chains are short while there is little update work to hide them behind)
     const int *item0;      // [ng + 1]: first item of group p's sequence in the main list
     const int *mitem0;     // [ng + 1]: first item of M(q) in the M list
     int total, total_m;
@@ -642,6 +644,21 @@ struct SweepDesc {
     unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
     unsigned long long *dbg_main;  // optional: [0] ticks tile items waited, [1] panel items waited, [2..] ticks / counts by kind
 };
+
+__device__ __forceinline__ int g_start(const SweepDesc &D, int p)
+{
+    return D.gs[p];
+}
+__device__ __forceinline__ int g_size(const SweepDesc &D, int p)
+{
+    return D.gs[p + 1] - D.gs[p];
+}
+// tile and write-back items of group p (what done[p] counts up to)
+__device__ __forceinline__ unsigned g_done_total(const SweepDesc &D, int p)
+{
+    const int sz = g_size(D, p), pn = D.nblk - sz;
+    return (unsigned)(pn * sz + (long long)pn * (pn + 1) / 2);
+}
 
 __device__ __forceinline__ unsigned flag_load(const unsigned *p)
 {
@@ -706,14 +723,14 @@ struct MainItem {
 __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int item)
 {
     if (item < D.pro) {  // panel(0): nobody is ahead of it
-        const int sz0 = min(D.g, D.nblk), nsz0 = D.ng > 1 ? min(D.g, D.nblk - sz0) : 0;
+        const int sz0 = g_size(D, 0), nsz0 = D.ng > 1 ? g_size(D, 1) : 0;
         return MainItem{0, 0, sz0 + nsz0 + item / (D.ppb * sz0), item % (D.ppb * sz0)};
     }
     while (item - D.pro >= D.item0[p + 1]) ++p;
     int e = item - D.pro - D.item0[p];
-    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
-    const int nsz = p + 1 < D.ng ? min(D.g, D.nblk - c0) : 0, d0 = c0 + nsz;
-    const int n2 = p + 2 < D.ng ? min(D.g, D.nblk - d0) : 0;
+    const int b0 = g_start(D, p), sz = g_size(D, p), c0 = b0 + sz;
+    const int nsz = p + 1 < D.ng ? g_size(D, p + 1) : 0, d0 = c0 + nsz;
+    const int n2 = p + 2 < D.ng ? g_size(D, p + 2) : 0;
     const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
     const int n_diag2 = n2 * (n2 + 1) / 2;
     if (e < n_diag2) {
@@ -782,7 +799,7 @@ __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, doub
 __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD])
 {
     const int tid = opaque_tid();
-    const int b0 = q * D.g, sz = min(D.g, D.nblk - b0), m = sz * T;
+    const int b0 = g_start(D, q), sz = g_size(D, q), m = sz * T;
     const int n1 = 2 * (sz - 1), n2 = 2 * (sz - 1) * (sz - 1), per_w = 1 + n1 + n2, nt = sz * (sz + 1) / 2;
     const int nm = 2 * nt + sz * per_w;
     double *Agg = D.A + (size_t)b0 * T + (size_t)b0 * T * D.ld;
@@ -811,8 +828,7 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
             } else {
                 while (flag_load(mc) < (unsigned)(nm - nt)) __builtin_amdgcn_s_sleep(8);
                 if (q >= 2) {
-                    const int psz = D.g, pn = D.nblk - psz;  // group q-2 is complete (Pg parity reuse)
-                    const unsigned want = (unsigned)(pn * psz + (long long)pn * (pn + 1) / 2);
+                    const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
                     while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
                 }
             }
@@ -889,8 +905,7 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
             if (sz == 1) {
                 while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);
                 if (q >= 2) {
-                    const int pn = D.nblk - D.g;  // group q-2 is complete (Pg parity reuse)
-                    const unsigned want = (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2);
+                    const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
                     while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
                 }
             } else if (first_pivot) {
@@ -971,14 +986,13 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
+    const int b0 = g_start(D, p), sz = g_size(D, p);
     const int w = TM == 2 ? y >> 1 : y, ch = TM == 2 ? (y & 1) : 0;
     if (tid == 0) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         // Pg(p); the group's columns of row i at generation p; the panel buffers of parity p free (group p-2 complete): all
         // flags of a round are loaded together
-        const int pn = D.nblk - D.g;
-        const unsigned want = p >= 2 ? (unsigned)(pn * D.g + (long long)pn * (pn + 1) / 2) : 0u;
+        const unsigned want = p >= 2 ? g_done_total(D, p - 2) : 0u;
         const unsigned *dn = D.done + (p >= 2 ? p - 2 : 0);
         const unsigned *gp[4];
 #pragma unroll
@@ -1045,7 +1059,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0);
+    const int sz = g_size(D, p);
     unsigned *genp = D.gen + (size_t)I * D.nblk + J;
     if (tid == 0 && !ready) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
@@ -1118,7 +1132,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
             int ph = p;
             const MainItem ni = main_decode(D, ph, nxt);
             if (ni.kind == 1) {
-                const int nsz2 = min(D.g, D.nblk - ni.p * D.g);
+                const int nsz2 = g_size(D, ni.p);
                 const unsigned f1 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.a), f2 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.b),
                                f3 = flag_load(D.gen + (size_t)ni.a * D.nblk + ni.b);
                 r = (f1 >= 2u * (unsigned)nsz2) & (f2 >= 2u * (unsigned)nsz2) & (f3 >= (unsigned)ni.p);
@@ -1137,7 +1151,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
 __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, double (*Gs)[KC][LDS_LD])
 {
     const int tid = opaque_tid();
-    const int b0 = p * D.g, sz = min(D.g, D.nblk - b0), rows = D.nblk - sz;
+    const int b0 = g_start(D, p), sz = g_size(D, p), rows = D.nblk - sz;
     int i = e % rows;
     const int w = e / rows;
     if (i >= b0) i += sz;
@@ -1203,7 +1217,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             while (item >= D.mitem0[q + 1]) ++q;
             int e = item - D.mitem0[q];
             if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
-            const int b0 = q * D.g, sz = min(D.g, D.nblk - b0), c0 = b0 + sz;
+            const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
             const int nm = m_items(sz);
             if (e < nm) {
                 sweep_m_item(D, q, e, Gs, Hs);
@@ -1252,7 +1266,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
         const MainItem it = main_decode(D, p, item);
         if (it.kind == 1) {
-            if (MULTI && min(D.g, D.nblk - it.p * D.g) > 1)
+            if (MULTI && g_size(D, it.p) > 1)
                 sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
             else
                 sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
@@ -1310,12 +1324,34 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
     int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 67 ? 3 : (nblk >= 58 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
-    const int ng = (nblk + g - 1) / g;
+    // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
+    // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
+    // with a ramp 1, 2, .. g-1 (a single block is one in-place pivot item, ~70 us; each following chain is as long as the
+    // update before it), and the remainder of nblk / g joins the ramp instead of ending the sweep as a lone short group
+    // (measured at n = 10 000: 17.9-18.1 ms against 18.2-18.3 with the remainder last and 18.2 without the ramp).
+    // GDCA_RAMP=0: uniform groups, the remainder last.
+    static const int ramp_env = getenv("GDCA_RAMP") ? atoi(getenv("GDCA_RAMP")) : 1;
+    std::vector<int> sizes;
+    {
+        const int ramp_sum = g * (g - 1) / 2;
+        if (ramp_env && g > 1 && nblk >= ramp_sum + 2 * g) {
+            for (int k = 1; k < g; ++k) sizes.push_back(k);
+            const int rest = nblk - ramp_sum, rem = rest % g;
+            if (rem) sizes.insert(std::upper_bound(sizes.begin(), sizes.end(), rem), rem);
+            for (int k = 0; k < rest / g; ++k) sizes.push_back(g);
+        } else {
+            for (int b = 0; b < nblk; b += g) sizes.push_back(std::min(g, nblk - b));
+        }
+    }
+    const int ng = (int)sizes.size();
     // item table on the host, then to the device (pinned staging buffer of the workspace)
     int *it = ws.item0_host;
-    auto size = [&](int p) { return std::min(g, nblk - p * g); };
+    auto size = [&](int p) { return sizes[(size_t)p]; };
     auto m_cnt = [&](int sz) { return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)); };
     int *mit = it + (ng + 1);
+    int *gs = it + 2 * (ng + 1);
+    gs[0] = 0;
+    for (int p = 0; p < ng; ++p) gs[p + 1] = gs[p] + sizes[(size_t)p];
     long long pos = 0, mpos = 0;
     double tiles = 0.0;
     // remainder tiles of update p listed after panel(p+1): about one round of the workgroups, so that the panels are complete
@@ -1345,7 +1381,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     }
     it[ng] = (int)pos;
     mit[ng] = (int)mpos;
-    (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)2 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
+    (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)3 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
     (void)hipMemsetAsync(ws.flags, 0, ws.flags_bytes, s0);
 
     SweepDesc D{};
@@ -1376,6 +1412,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.mcu = f + 2;
     D.item0 = ws.item0_dev;
     D.mitem0 = ws.item0_dev + (ng + 1);
+    D.gs = ws.item0_dev + 2 * (ng + 1);
     D.total = pro + (int)pos;
     D.total_m = (int)mpos;
     D.pro = pro;

@@ -342,7 +342,8 @@ print(json.dumps(out))
                                  {"GDCA_GROUP": "4", "GDCA_MCUS": "3"}, {"GDCA_GROUP": "3", "GDCA_REM_TAIL": "0"},
                                  {"GDCA_GROUP": "2", "GDCA_REM_TAIL": "7"}, {"GDCA_GROUP": "4", "GDCA_REM_TAIL": "100000"},
                                  {"GDCA_GROUP": "3", "GDCA_PANEL_HALVES": "1"}, {"GDCA_GROUP": "2", "GDCA_PANEL_HALVES": "0"},
-                                 {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}])
+                                 {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}, {"GDCA_GROUP": "3", "GDCA_RAMP": "0"},
+                                 {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"}])
 def test_every_inverse_schedule_matches_lapack(env):
     """The SPD inverse is one persistent launch that sweeps pivot groups of 1-4 blocks (the group size is chosen by matrix
     size) with its serial chain on 1-16 elected compute units.  Each combination, forced through its environment switches
