@@ -1319,10 +1319,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // pivot blocks per group: more blocks per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
     // are bound by the chain itself, which is shortest with single blocks (no scratch copy, no tile jobs).  Measured on
-    // MI355X (tools/sweep_groups.py, profiles/r02_sweep_groups.log): g = 1 is fastest up to 57 blocks, 2 to 66, 3 to 89,
-    // 4 from 90 on.
+    // MI355X (tools/sweep_groups.py, profiles/r02_sweep_groups.log): g = 1 is fastest up to 57 blocks, 2 to 66, 3 to 83,
+    // 4 from 84 on.
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 90 ? 4 : (nblk >= 67 ? 3 : (nblk >= 58 ? 2 : 1)));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 84 ? 4 : (nblk >= 67 ? 3 : (nblk >= 58 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens

@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--sizes", type=int, nargs="*",
-                    default=[100, 128, 129, 384, 1000, 2560, 5000, 7424, 8320, 8448, 8576, 9000, 10000, 10112, 11000, 11600])
+                    default=[100, 128, 129, 384, 1000, 2560, 5000, 7424, 8320, 8448, 8576, 9000, 10000, 10112, 10752, 11000, 11600])
     args = ap.parse_args()
     ctx = g.Context(0)
     rng = np.random.default_rng(11)
