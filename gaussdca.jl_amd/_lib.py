@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgdca.so")
+# GDCA_LIB: another build of the same library (kernel experiments: tools/exp_*.sh build variants beside the product)
+LIB_PATH = os.environ.get("GDCA_LIB") or os.path.join(_HERE, "libgdca.so")
 
 GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV = 0, 1, 2, 3, 4, 5
 SCORE_FROB, SCORE_DI = 0, 1

@@ -506,42 +506,141 @@ __device__ __forceinline__ void cpiece_add(double4_t (&acc)[4][4], const double 
         for (int reg = 0; reg < 4; ++reg) acc[tm][2 * (CI % 2) + h][reg] += cp[h * 4 + reg];
 }
 
-// DUAL: more pivots follow in the same pass -- the k loop runs over (G, H) of the first pivot (these unrolled chunks,
-// which also bring in the C tile) and then over the panels of the other pivots of the group (a plain rolled loop in the
-// kernel): the C tile is read and written once per group of rank-128 updates.
-// The operand chunks are double-buffered in LDS (chunk c in buffer c & 1): while chunk c is multiplied, chunk c+1
-// goes registers -> LDS (after the first quarter of the MFMAs, so its global loads have had more than a chunk to
-// land) and chunk c+2's global loads are issued; ONE barrier per chunk.
 typedef double (*lds_chunk_t)[LDS_LD];
 
-template <int CI, bool DUAL>
-struct UpdateChunks {
-    static constexpr int PER = T / KC;  // chunks per operand pair
-    static __device__ __forceinline__ void run(double4_t (&acc)[4][4], StageRegs<4> &R, double (&cp)[8],
-                                               const double *__restrict__ g1, const double *__restrict__ h1,
-                                               const double *__restrict__ g2, const double *__restrict__ h2, size_t pld,
-                                               double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD],
-                                               const double *__restrict__ At, size_t ld)
-    {
-        const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
-        const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-        // on entry: LDS buffer CI & 1 holds chunk CI (barrier passed); R holds (or is receiving) chunk CI + 1
-        if constexpr (CI > 0) cpiece_add<(CI > 0 ? CI - 1 : 0)>(acc, cp);  // requested one chunk ago
-        cpiece_load<CI>(cp, At, ld, wr, wc, l15, lq);
-        chunk_mma<4, 0, 4>(acc, Gs[CI & 1], Hs[CI & 1], wr, wc, lane);
-        if constexpr (CI + 1 < PER || DUAL) stage_store<false, 4>(R, Gs[(CI + 1) & 1], Hs[(CI + 1) & 1], tid);
-        if constexpr (CI + 2 < PER)
-            stage_load<false, 4>(R, g1, pld, h1, pld, (CI + 2) * KC, tid);
-        else if constexpr (DUAL)
-            stage_load<false, 4>(R, g2, pld, h2, pld, (CI + 2 - PER) * KC, tid);
-        chunk_mma<4, 4, KC>(acc, Gs[CI & 1], Hs[CI & 1], wr, wc, lane);
-        __syncthreads();  // buffer CI & 1 is free, buffer (CI + 1) & 1 is complete
-        if constexpr (CI + 1 < PER)
-            UpdateChunks<CI + 1, DUAL>::run(acc, R, cp, g1, h1, g2, h2, pld, Gs, Hs, At, ld);
-        else
-            cpiece_add<CI>(acc, cp);
-    }
+// ---- the tile item's k loop, scheduled by hand --------------------------------------------------------------------------------
+// One k-chunk (16 deep) of a 128 x 128 tile product is, per wave, 64 MFMAs of 64 matrix-pipe clocks each.  Everything else a
+// chunk needs -- 16 LDS fragment reads, the 8 register -> LDS staging stores of the NEXT chunk, the 8 global loads of the chunk
+// after it, a piece of the C tile -- has to be issued in the shadow of those MFMAs: any stretch of more than ~64 clocks of
+// other instructions between two MFMAs of a wave leaves the pipe to the co-resident workgroup's wave alone, and when that one is
+// in the same phase the pipe idles.  hipcc's own schedule put the 8 stores, the address arithmetic and the 8 loads in ONE
+// block after the first 16 MFMAs of a chunk and started every chunk with `s_waitcnt lgkmcnt(0)` on four fresh LDS reads.  Here:
+//   * the fragments of a chunk's first k4 step are read right after the barrier that completes the chunk's LDS buffer,
+//     underneath the last 16 MFMAs of the chunk before (carried across the loop edge in `f`);
+//   * the staging goes unit by unit between PAIRS of MFMAs of the second k4 step: store unit u to LDS, then at once load unit u
+//     of the chunk after next into the same registers (prefetch distance = one whole chunk per unit);
+//   * `sched_barrier(0)` pins that order (nothing moves across it; the waitcnt pass runs later and counts exactly).
+struct Frag {
+    double a[4], b[4];
 };
+
+__device__ __forceinline__ void frag_read(Frag &f, const double (*Gs)[LDS_LD], const double (*Hs)[LDS_LD], int k4, int wr, int wc,
+                                          int l15, int lq)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.a[t] = Hs[k4 + lq][wc * 64 + t * 16 + l15];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
+}
+
+// MFMA number I of a k4 step, in an order that starts with accumulator row TM0 (the C piece added after this step belongs to
+// that row: its MFMAs are long finished when the VALU adds read the accumulators)
+template <int I, int TM0>
+__device__ __forceinline__ void mma_one(double4_t (&acc)[4][4], const Frag &f)
+{
+    constexpr int tm = (TM0 + I / 4) & 3, tn = I & 3;
+    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[tm], f.b[tn], acc[tm][tn], 0, 0, 0);
+}
+
+template <int TM0>
+__device__ __forceinline__ void mma_all(double4_t (&acc)[4][4], const Frag &f)
+{
+    mma_one<0, TM0>(acc, f);
+    mma_one<1, TM0>(acc, f);
+    mma_one<2, TM0>(acc, f);
+    mma_one<3, TM0>(acc, f);
+    mma_one<4, TM0>(acc, f);
+    mma_one<5, TM0>(acc, f);
+    mma_one<6, TM0>(acc, f);
+    mma_one<7, TM0>(acc, f);
+    mma_one<8, TM0>(acc, f);
+    mma_one<9, TM0>(acc, f);
+    mma_one<10, TM0>(acc, f);
+    mma_one<11, TM0>(acc, f);
+    mma_one<12, TM0>(acc, f);
+    mma_one<13, TM0>(acc, f);
+    mma_one<14, TM0>(acc, f);
+    mma_one<15, TM0>(acc, f);
+}
+
+// staging unit U of a chunk: U = 0..3 rows 4U.. of the G chunk, U = 4..7 rows 4(U-4).. of the H chunk (one 16-byte load / one
+// ds_write_b128 per thread; a wave moves one contiguous k-row of 128 operand rows)
+template <int U>
+__device__ __forceinline__ void stage_unit_store(const StageRegs<4> &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid)
+{
+    const int kk = (tid >> 6) + 4 * (U & 3), r2 = tid & 63;
+    if (U < 4)
+        *reinterpret_cast<double2 *>(&Gs[kk][r2 * 2]) = make_double2(R.g[2 * U], R.g[2 * U + 1]);
+    else
+        *reinterpret_cast<double2 *>(&Hs[kk][r2 * 2]) = make_double2(R.h[2 * (U - 4)], R.h[2 * (U - 4) + 1]);
+}
+
+// g, h: the operand pair's panels at the chunk's first k column (row offset included); boff: this thread's byte offset
+template <int U>
+__device__ __forceinline__ void stage_unit_load(StageRegs<4> &R, const double *__restrict__ g, const double *__restrict__ h,
+                                                size_t pld, unsigned boff)
+{
+    const char *rowbase = reinterpret_cast<const char *>((U < 4 ? g : h) + (size_t)(4 * (U & 3)) * pld);
+    const double2 v = *reinterpret_cast<const double2 *>(rowbase + boff);
+    if (U < 4) {
+        R.g[2 * U] = v.x;
+        R.g[2 * U + 1] = v.y;
+    } else {
+        R.h[2 * (U - 4)] = v.x;
+        R.h[2 * (U - 4) + 1] = v.y;
+    }
+}
+
+template <int U, bool STORE, bool LOAD>
+__device__ __forceinline__ void stage_unit(double4_t (&acc)[4][4], const Frag &f, StageRegs<4> &R, double (*Gn)[LDS_LD],
+                                           double (*Hn)[LDS_LD], const double *__restrict__ g, const double *__restrict__ h,
+                                           size_t pld, unsigned boff, int tid)
+{
+    mma_one<2 * U, 0>(acc, f);
+    mma_one<2 * U + 1, 0>(acc, f);
+    if constexpr (STORE) stage_unit_store<U>(R, Gn, Hn, tid);
+    if constexpr (LOAD) stage_unit_load<U>(R, g, h, pld, boff);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One chunk.  On entry: `f` = fragments of (Gc, Hc) at k4 = 0; R = the next chunk (loads in flight or landed).
+// STORE: R -> (Gn, Hn);  LOAD: R <- the chunk at (g, h);  NEXT: on exit `f` = fragments of (Gn, Hn) at k4 = 0.
+// CI: 0..7 = this chunk also adds C piece CI (requested one chunk earlier; piece 0 in the item's prologue) and requests piece
+// CI + 1; -1 = no C traffic.
+template <bool STORE, bool LOAD, bool NEXT, int CI>
+__device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, StageRegs<4> &R, double (&cp)[8], double (*Gc)[LDS_LD],
+                                           double (*Hc)[LDS_LD], double (*Gn)[LDS_LD], double (*Hn)[LDS_LD],
+                                           const double *__restrict__ g, const double *__restrict__ h, size_t pld, unsigned boff,
+                                           const double *__restrict__ At, size_t ld, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6, wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    Frag f1;
+    frag_read(f1, Gc, Hc, 4, wr, wc, l15, lq);
+    constexpr int TM0 = CI >= 0 ? (CI / 2) & 3 : 0;
+    mma_all<TM0>(acc, f);  // k4 = 0
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (CI >= 0) cpiece_add<(CI >= 0 ? CI : 0)>(acc, cp);
+    if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, wr, wc, l15, lq);
+    frag_read(f, Gc, Hc, 8, wr, wc, l15, lq);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_unit<0, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);  // k4 = 4, two MFMAs per unit
+    stage_unit<1, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<2, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<3, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<4, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<5, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<6, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    stage_unit<7, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
+    frag_read(f1, Gc, Hc, 12, wr, wc, l15, lq);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all<0>(acc, f);  // k4 = 8; the last fragment reads of this buffer land underneath
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();     // (Gc, Hc) is free, (Gn, Hn) is complete
+    if constexpr (NEXT) frag_read(f, Gn, Hn, 0, wr, wc, l15, lq);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all<0>(acc, f1);  // k4 = 12
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // Write-back of the new column block: A[i,k] = G_i P = -H_i  (A[k,i] = (G_i P)^T for i < k).  Not done by
 // the panel kernel because the two panel workgroups of a row block both read the OLD A[i,k] as their G
@@ -640,6 +739,7 @@ struct SweepDesc {
     int ppb;               // main-list panel items per pivot block and row: 2 (128 x 64 each) or 1 (128 x 128)
     int n_mcu;             // compute units to elect for the M list (<= 16)
     int n_real;
+    int rl;                // real (non-padding) rows of the last block, rounded up to 16: 16 .. 128
     gdca_dev_scalars *sc;
     unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
     unsigned long long *dbg_main;  // optional: [0] ticks tile items waited, [1] panel items waited, [2..] ticks / counts by kind
@@ -652,6 +752,14 @@ __device__ __forceinline__ int g_start(const SweepDesc &D, int p)
 __device__ __forceinline__ int g_size(const SweepDesc &D, int p)
 {
     return D.gs[p + 1] - D.gs[p];
+}
+// k-chunks (16 deep) of a tile item of update p: 8 per pivot block; the block at the ragged end of the matrix counts only the
+// chunks that hold real columns (rl of its 128; the padding columns of G and H are zero), rounded up to an even number
+__device__ __forceinline__ int g_chunks(const SweepDesc &D, int p)
+{
+    const int sz = g_size(D, p);
+    if (D.rl < T && D.gs[p + 1] == D.nblk && sz > 1) return (T / KC) * (sz - 1) + 2 * ((D.rl + 2 * KC - 1) / (2 * KC));
+    return (T / KC) * sz;
 }
 // tile and write-back items of group p (what done[p] counts up to)
 __device__ __forceinline__ unsigned g_done_total(const SweepDesc &D, int p)
@@ -1048,22 +1156,16 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 }
 
 // ---- one tile of update p:  A_IJ += sum_w G_w[I] H_w[J]^T ------------------------------------------------------------------
-// `ready`: the flags were seen set already (by the previous item's look-ahead, see the end of this function).
+// `ready`: the flags were seen set already (by the previous item's look-ahead, see tile_item_finish).
 // `nxt`, `s_next`, `s_ready` (main-list callers; thread 0's value / LDS words): the workgroup's NEXT item number, in flight as
 // an atomic since the start of this item.  While this item's stores drain, thread 0 looks that item up and, if it is a tile
 // item, reads its flags: the next trip then starts without the counter's and the flags' round trips (~3 us of a ~105 us item).
-template <bool MULTI>
-__device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
-                                                double (*Hs)[KC][LDS_LD], int ready = 0, int nxt = 0, int *s_next = nullptr,
-                                                int *s_ready = nullptr)
+__device__ __forceinline__ void tile_item_wait(const SweepDesc &D, int p, int I, int J, int ready)
 {
-    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    const int sz = g_size(D, p);
-    unsigned *genp = D.gen + (size_t)I * D.nblk + J;
-    if (tid == 0 && !ready) {
+    if (opaque_tid() == 0 && !ready) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
-        const unsigned need = 2u * (unsigned)sz;
+        const unsigned need = 2u * (unsigned)g_size(D, p);
+        const unsigned *genp = D.gen + (size_t)I * D.nblk + J;
         // the three flags are loaded TOGETHER (one L2 round trip, ~1.5 us under load, instead of three dependent ones)
         for (;;) {
             const unsigned f1 = flag_load(D.rb + (size_t)p * D.nblk + I), f2 = flag_load(D.rb + (size_t)p * D.nblk + J),
@@ -1074,57 +1176,12 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
         if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
     }
     acquire_end();
-    const size_t ld = D.ld, pld = D.ld;
-    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride;
-    double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
-    double4_t acc[4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    {
-        StageRegs<4> R;
-        double cp[8];
-        const size_t go = (size_t)I * T, ho = (size_t)J * T;
-        const double *g1 = Gp + go, *h1 = Hp + ho;
-        stage_load<false, 4>(R, g1, pld, h1, pld, 0, tid);
-        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
-        stage_load<false, 4>(R, g1, pld, h1, pld, KC, tid);
-        __syncthreads();
-        if constexpr (MULTI) {
-            UpdateChunks<0, true>::run(acc, R, cp, g1, h1, Gp + D.pstride + go, Hp + D.pstride + ho, pld, Gs, Hs, At, ld);
-            // pivots 2 .. sz of the group: chunk c of this loop is chunk 8 + c of the pass (LDS buffer c & 1); on entry
-            // chunk 0 is in LDS buffer 0 and chunk 1 in R
-            const int total = (T / KC) * (sz - 1);
-#pragma unroll 1
-            for (int c = 0; c < total; ++c) {
-                chunk_mma<4, 0, 4>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-#if !defined(GDCA_X_NOSTORE)
-                if (c + 1 < total) stage_store<false, 4>(R, Gs[(c + 1) & 1], Hs[(c + 1) & 1], tid);
-#endif
-#if !defined(GDCA_X_NOLOAD)
-                if (c + 2 < total) {
-                    const int op = 1 + (c + 2) / (T / KC), kc = ((c + 2) % (T / KC)) * KC;
-                    stage_load<false, 4>(R, Gp + (size_t)op * D.pstride + go, pld, Hp + (size_t)op * D.pstride + ho, pld, kc, tid);
-                }
-#endif
-                chunk_mma<4, 4, KC>(acc, Gs[c & 1], Hs[c & 1], wr, wc, lane);
-                __syncthreads();
-            }
-        } else {
-            UpdateChunks<0, false>::run(acc, R, cp, g1, h1, nullptr, nullptr, pld, Gs, Hs, At, ld);
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
-            }
+}
+
+// after the tile's (write-through) stores have been issued: look the next item up while they drain, then publish
+__device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int I, int J, int nxt, int *s_next, int *s_ready)
+{
+    const int tid = opaque_tid();
     if (s_next && tid == 0) {
         *s_next = nxt;
         int r = 0;
@@ -1142,9 +1199,143 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
     }
     publish_wt_begin();
     if (tid == 0) {
-        __hip_atomic_store(genp, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(D.gen + (size_t)I * D.nblk + J, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <bool MULTI>
+__device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
+                                                double (*Hs)[KC][LDS_LD], int ready = 0, int nxt = 0, int *s_next = nullptr,
+                                                int *s_ready = nullptr)
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    tile_item_wait(D, p, I, J, ready);
+    const size_t ld = D.ld, pld = D.ld;
+    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride;
+    double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        StageRegs<4> R;
+        double cp[8];
+        Frag f;
+        const size_t go = (size_t)I * T, ho = (size_t)J * T;
+        const unsigned boff = ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)pld) * 8u;
+        const size_t cs = (size_t)KC * pld;  // one chunk further along k
+        const double *g = Gp + go, *h = Hp + ho;
+        stage_load<false, 4>(R, g, pld, h, pld, 0, tid);
+        cpiece_load<0>(cp, At, ld, wr, wc, l15, lq);
+        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+        stage_load<false, 4>(R, g, pld, h, pld, KC, tid);
+        __syncthreads();
+        frag_read(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
+        // chunk c multiplies LDS buffer c & 1, stores chunk c+1 into the other one and loads chunk c+2; the first eight chunks
+        // (the group's first pivot block) also bring the C tile in
+        tile_chunk<true, true, true, 0>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 2 * cs, h + 2 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 3 * cs, h + 3 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 2>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 4 * cs, h + 4 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 3>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 5 * cs, h + 5 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 4>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 6 * cs, h + 6 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 5>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 7 * cs, h + 7 * cs, pld, boff, At, ld, tid);
+        if constexpr (MULTI) {
+            // the other pivot blocks of the group: operand pair w at Gp / Hp + w * pstride.  nch = chunks of the whole item (even,
+            // >= 10): 8 per pivot block, fewer for the block that holds the ragged end of the matrix (its padding columns are
+            // zero in G and H: g_chunks)
+            const int nch = g_chunks(D, p);
+            g += D.pstride;
+            h += D.pstride;
+            tile_chunk<true, true, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
+            tile_chunk<true, true, true, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + cs, h + cs, pld, boff, At, ld, tid);
+#pragma unroll 1
+            for (int c = 8; c < nch - 2; c += 2) {
+                // loads chunks c + 2 and c + 3 (the same operand pair: c is even and a pair holds 8 chunks)
+                const double *gl = Gp + (size_t)((c + 2) >> 3) * D.pstride + go + (size_t)((c + 2) & 7) * cs;
+                const double *hl = Hp + (size_t)((c + 2) >> 3) * D.pstride + ho + (size_t)((c + 2) & 7) * cs;
+                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gl, hl, pld, boff, At, ld, tid);
+                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gl + cs, hl + cs, pld, boff, At, ld, tid);
+            }
+            tile_chunk<true, false, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
+            tile_chunk<false, false, false, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, pld, boff, At, ld, tid);
+        } else {
+            tile_chunk<true, false, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
+            tile_chunk<false, false, false, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, pld, boff, At, ld, tid);
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = wr * 64 + tn * 16 + l15;
+                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
+            }
+    tile_item_finish(D, p, I, J, nxt, s_next, s_ready);
+}
+
+// ---- a tile of the LAST block row when the matrix ends inside that block (n = 10 000: 78 blocks of 128 and 16 rows) ------------
+// Only the first rl rows of the tile are real; the others are padding (zero, and they stay zero: the padding rows of H are
+// zero).  The product is done for the 16-row blocks that hold real rows only (rl = 16: 8 of the 64 MFMAs of a k4 step); a
+// plain loop (one LDS buffer, two barriers per chunk): these items are 1 / nblk of the tile items and bound by their operand
+// traffic, not by the matrix pipe.
+__device__ __forceinline__ void sweep_tile_item_ragged(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
+                                                       double (*Hs)[KC][LDS_LD], int ready, int nxt, int *s_next, int *s_ready)
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    tile_item_wait(D, p, I, J, ready);
+    const size_t ld = D.ld, pld = D.ld;
+    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride + (size_t)I * T, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride + (size_t)J * T;
+    double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
+    const int ntn = min(4, max(0, (D.rl - wr * 64) / 16));  // 16-row blocks of this wave's 64 rows that hold real rows
+    const int nch = g_chunks(D, p);
+    double4_t acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    StageRegs<4> R;
+    stage_load<false, 4>(R, Gp, pld, Hp, pld, 0, tid);
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        __syncthreads();  // the previous chunk's LDS reads are done
+        stage_store<false, 4>(R, Gs[0], Hs[0], tid);
+        __syncthreads();
+        if (c + 1 < nch)
+            stage_load<false, 4>(R, Gp + (size_t)((c + 1) >> 3) * D.pstride, pld, Hp + (size_t)((c + 1) >> 3) * D.pstride, pld,
+                                 ((c + 1) & 7) * KC, tid);
+#pragma unroll
+        for (int k4 = 0; k4 < KC; k4 += 4) {
+            double a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = Hs[0][k4 + lq][wc * 64 + t * 16 + l15];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                if (tn < ntn) {
+                    const double bq = Gs[0][k4 + lq][wr * 64 + tn * 16 + l15];
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], bq, acc[tm][tn], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+        if (tn < ntn) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    double *q = &At[(size_t)(wr * 64 + tn * 16 + l15) + (size_t)(wc * 64 + tm * 16 + lq + 4 * reg) * ld];
+                    store_wt(q, *q + acc[tm][tn][reg]);
+                }
+        }
+    tile_item_finish(D, p, I, J, nxt, s_next, s_ready);
 }
 
 // ---- wb(p): one tile of the group's new columns ----------------------------------------------------------------------------
@@ -1266,7 +1457,9 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
         const MainItem it = main_decode(D, p, item);
         if (it.kind == 1) {
-            if (MULTI && g_size(D, it.p) > 1)
+            if (D.rl < T && it.a == D.nblk - 1)
+                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+            else if (MULTI && g_size(D, it.p) > 1)
                 sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
             else
                 sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
@@ -1353,7 +1546,11 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     gs[0] = 0;
     for (int p = 0; p < ng; ++p) gs[p + 1] = gs[p] + sizes[(size_t)p];
     long long pos = 0, mpos = 0;
-    double tiles = 0.0;
+    // real rows of the last block, in 16-row MFMA blocks: the sweep treats the matrix as n rounded up to 16, not to 128 -- the
+    // tile items of the last block row and the k loop over the last pivot block skip the rest of the padding (GDCA_RAGGED=0: off)
+    static const int ragged_env = getenv("GDCA_RAGGED") ? atoi(getenv("GDCA_RAGGED")) : 1;
+    const int rl = ragged_env ? std::min(T, ((n_real - (nblk - 1) * T + 15) / 16) * 16) : T;
+    double chunks = 0.0;  // 128 x 128 x 16 MFMA chunk products issued (tile, panel and super-block items)
     // remainder tiles of update p listed after panel(p+1): about one round of the workgroups, so that the panels are complete
     // when the first tile items of update p+1 are handed out and the chain has had most of update p to produce Pg(p+1).
     // Only where the update hides the chain (groups of three and four): on a chain-bound matrix Pg(p+1) is late anyway and
@@ -1377,7 +1574,12 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
         pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
         pos += nsz > 0 ? (long long)(nblk - nsz - n2) * ppb * nsz : 0;  // panel(p+1), the rows outside groups p+1 and p+2
         const long long pn = nblk - sz;
-        tiles += (double)(pn * (pn + 1) / 2) * sz + (double)pn * sz * sz;  // tile products + the panel's (K = 128 sz, 128 sz columns)
+        const bool last = gs[p + 1] == nblk;
+        const int kch = (rl < T && last && sz > 1) ? 8 * (sz - 1) + 2 * ((rl + 31) / 32) : 8 * sz;  // = g_chunks()
+        const double nrag = (rl < T && !last) ? (double)pn : 0.0;  // tile items of the ragged block row: rl / 128 of the MFMAs
+        chunks += ((double)(pn * (pn + 1) / 2) - nrag + nrag * rl / T) * kch;  // tile items
+        chunks += (double)pn * sz * 8 * sz;                                    // panel items (K = 128 sz, 128 sz columns)
+        if (sz > 1) chunks += 0.5 * sz * (2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)) * 8;  // 128 x 64 x 128 jobs of the super-block inverse
     }
     it[ng] = (int)pos;
     mit[ng] = (int)mpos;
@@ -1425,6 +1627,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     const int mcu_rule = g == 1 ? (nblk < 28 ? 16 : 12) : ((g == 3 && nblk >= 76) || (g == 4 && nblk >= 110) ? 4 : 8);
     D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
+    D.rl = rl;
     D.sc = sc;
     // GDCA_SWEEP_TRACE=file: stamps of the M-list items of this inverse are written to `file` (debug aid; synchronises)
     static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
@@ -1484,7 +1687,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
         }
     }
     if (n_upd_launch) *n_upd_launch = 1;
-    if (upd_flops) *upd_flops = 2.0 * T * T * T * tiles;
+    if (upd_flops) *upd_flops = 2.0 * T * T * KC * chunks;
 }
 
 // -------------------------------------------------------------------------------------------------

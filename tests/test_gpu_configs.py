@@ -3,8 +3,9 @@ C-ABI (libgdca.so via ctypes) against the CPU oracle:
 
   B  N=128,  M=10k,  theta=0.2, :frob              full oracle comparison
   C  N=500,  M=50k,  theta=:auto, :frob AND :DI    full oracle comparison at the headline size (one oracle pass)
-  D  N=1000, M=100k, :frob                         properties that need no full CPU inverse
-  E  16 families of the 256-family batch through `gdca_cli --batch`, byte-equal to the single-family path
+  D  N=1000, M=100k, :frob                         full oracle comparison (LAPACK inverse at n = 20 000) + the properties of the `_dev` chain
+  E  16 families of the 256-family batch through `gdca_cli --batch`, byte-equal to the single-family path; four of them
+     (smallest, largest, two mid-size) against the oracle
 
 Bars (north_star): Hamming counts / thresholds / identity sums / ranking indices bit-exact, FN / DI scores within
 1e-6 relative.  Tolerances are written at each assert.  Seeds are SURVEY.md 8d's (0xB128, 0xC500, 0xD1000, 0xE000+f).
@@ -219,6 +220,40 @@ def test_config_D_properties_at_full_size(g, ctx, o):
     assert len(R) == (N - 5) * (N - 4) // 2 and all(R[t][2] >= R[t + 1][2] for t in range(len(R) - 1))
 
 
+def test_config_D_scores_match_oracle_at_full_size(g, ctx, o):
+    """BASELINE.json configs[3] against an INDEPENDENT inverse: the oracle's whole pipeline at N=1000, M=100k (all-pairs
+    Hamming, tallies, pseudocount, covariance, LAPACK dpotrf+dpotri at n = 20 000, FN, APC; about a minute on the GPU
+    box's host cores) against the fused device run -- 157 pivot blocks in groups of four, the largest schedule the
+    sweep kernel runs in the benchmarks.  All 100 000 neighbour counts bit-exact, theta / threshold / Meff equal,
+    scores within 1e-6 relative, top-200 contact order identical."""
+    N, M, q, pc = 1000, 100000, 21, 0.8
+    Zo = _synth(N, M, 0xD1000)
+    Z = np.asfortranarray(Zo.T)
+    S, st = ctx.run(Z, q, pc, -1.0, 0)
+    assert st["info"] == 0 and st["n"] == N * (q - 1)
+    theta = o.compute_theta(Zo)
+    thr = o.hamming_threshold(theta, N)
+    assert st["theta"] == theta and st["thresh"] == thr
+    n_k = o.neighbour_counts(Zo, thr)
+    assert np.array_equal(g.neighbour_counts(Z, thr, ctx=ctx), n_k)          # all 100 000 counts, bit-exact
+    del Z
+    W, Meff = o.weights_from_counts(n_k)
+    assert st["Meff"] == Meff
+    Pi_t, Pij_t = o.compute_frequencies(Zo, q, W, Meff)
+    Pi, Pij = o.add_pseudocount(Pi_t, Pij_t, pc, q)
+    del Pij_t
+    C = o.compute_C(Pi, Pij)
+    del Pij
+    mJ = o.spd_inverse(C)
+    del C
+    S_o = o.correct_APC(o.compute_FN(mJ, q))
+    del mJ
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
+    assert ok, (max_rel, max_abs)
+    assert _top_order_equal(g, o, S, S_o, 200)
+    assert np.array_equal(S, S.T)
+
+
 # ---- E -------------------------------------------------------------------------------------------------------------
 def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
     """BASELINE.json configs[4]: 16 families of the 256-family batch (every 16th, at their real sizes N in [134, 507],
@@ -248,6 +283,33 @@ def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
         g.printrank(str(want), R)
         got = (outdir / ("fam%03d.rank.txt" % f)).read_bytes()
         assert got == want.read_bytes(), f
+
+
+@pytest.mark.parametrize("which", ["smallest", "largest", "mid_a", "mid_b"])
+def test_config_E_families_match_oracle(g, ctx, o, which):
+    """Four of the 16 sampled batch families at their real sizes against the oracle's whole pipeline (the batch test
+    above compares the batch driver with the single-family path -- HIP against HIP; this one is the parity check at
+    config E's sizes): the family with the smallest and the largest covariance of the sample and two in between."""
+    from gaussdca.jl_amd.batch import batch_sizes
+
+    sizes = batch_sizes(256)
+    fams = sorted(range(0, 256, 16), key=lambda f: (sizes[f][0], sizes[f][1]))
+    f = {"smallest": fams[0], "largest": fams[-1], "mid_a": fams[5], "mid_b": fams[10]}[which]
+    N, M = sizes[f]
+    q, pc = 21, 0.8
+    Zo = _synth(N, M, 0xE000 + f)
+    Z = np.asfortranarray(Zo.T)
+    S, st = ctx.run(Z, q, pc, -1.0, 0)
+    theta = o.compute_theta(Zo)
+    thr = o.hamming_threshold(theta, N)
+    n_k = o.neighbour_counts(Zo, thr)
+    assert np.array_equal(g.neighbour_counts(Z, thr, ctx=ctx), n_k)          # bit-exact
+    W, Meff = o.weights_from_counts(n_k)
+    assert st["theta"] == theta and st["thresh"] == thr and st["Meff"] == Meff and st["info"] == 0
+    S_o = o.scores_from_Z(Zo, q, pc, "auto", "frob")
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
+    assert ok, (f, N, M, max_rel, max_abs)
+    assert _top_order_equal(g, o, S, S_o, 200)
 
 
 # ---- boundary behaviour added with the device-resident operators ----------------------------------------------------

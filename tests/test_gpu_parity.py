@@ -379,3 +379,26 @@ def test_mid_size_families_match_oracle(g, ctx, o, N, M, score, pc):
     assert ok, (max_rel, max_abs)
     R, R_o = g.compute_ranking(S, 5), o.compute_ranking(S_o, 5)
     assert [t[:2] for t in R[:200]] == [t[:2] for t in R_o[:200]]       # the contacts a user looks at: same order
+
+
+@pytest.mark.parametrize("seed", [99, 2024, 31337])
+def test_random_mid_size_campaign(g, ctx, o, seed):
+    """Random campaign (the body of tools/campaign_midsize.py with fixed seeds): 8 synthetic families per seed with N drawn
+    from [60, 440) -- 10 .. 69 pivot blocks, i.e. every group size the schedule rule picks below n = 9000 -- and M from
+    [600, 3000), alternating :frob / :DI, whole hot path against the oracle: theta, threshold and Meff equal, scores within
+    1e-6 relative."""
+    from gaussdca.jl_amd import synth
+
+    rng = np.random.default_rng(seed)
+    for k in range(8):
+        N = int(rng.integers(60, 440))
+        M = int(rng.integers(600, 3000))
+        score = "frob" if k % 2 == 0 else "DI"
+        pc = 0.8 if score == "frob" else 0.2
+        Zo = synth.synth_family(N, M, 21, int(rng.integers(1, 2**31 - 1)))
+        S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 1 if score == "DI" else 0)
+        W_o, Meff_o, th_o, thr_o = o.compute_weights(Zo, "auto")
+        assert st["theta"] == th_o and st["thresh"] == thr_o and st["Meff"] == Meff_o and st["info"] == 0, (seed, k, N, M)
+        S_o = o.scores_from_Z(Zo, 21, pc, "auto", score)
+        ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
+        assert ok, (seed, k, N, M, score, max_rel, max_abs)
