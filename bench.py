@@ -34,8 +34,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
-MEASURED_SHADER_GHZ = 2.10  # s_memtime / wall clock inside k_sweep's tile items (profiles/r02_sweep_trace_C.txt); spec 2.4
-PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_update_traffic.json")
+SPEC_SHADER_GHZ = 2.4  # the clock the spec peak is quoted at; the clock of the timed launches is measured by k_sweep itself
+PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_update_traffic.json")
 
 CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
     "B": dict(N=128, M=10000, theta=0.2, seed=0xB128, ref="BASELINE.json configs[1]"),
@@ -68,18 +68,37 @@ def workload(cfg, args, rank, world):
 
 
 def pmc_traffic(N, M, score):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE in separate passes, corrected with the factor measured on a copy kernel with the
-    update kernel's load mix: profiles/r02_fetch_calibration.json); None unless the workload is the profiled one."""
+    """HBM bytes per launch of the dominant kernel.  NOT measured by this run (PMC counters need rocprofv3 passes of
+    their own): the figure of the committed counter passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
+    passes, corrected with the factor measured on a copy kernel with the update kernel's load mix:
+    profiles/r02_fetch_calibration.json), returned with its provenance; (None, None) unless the workload is the
+    profiled one."""
     try:
         with open(PROFILED_TRAFFIC) as f:
             d = json.load(f)
         w = d.get("workload", {})
         if (w.get("N"), w.get("M"), w.get("score")) != (N, M, score):
-            return None
-        return float(d["hbm_bytes_per_launch"])
+            return None, None
+        return float(d["hbm_bytes_per_launch"]), os.path.relpath(PROFILED_TRAFFIC, ROOT)
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
+
+
+def probe_reference_julia():
+    """BASELINE.md 4.1 / SURVEY 8d: the preferred CPU baseline is the real reference (`julia -t N -e 'using GaussDCA'`).
+    Probe for it and say what was found; the image (and the GPU box) have no Julia, so this records "absent" and the
+    port is timed instead."""
+    import shutil
+
+    exe = shutil.which("julia")
+    if not exe:
+        return "absent (no `julia` on PATH)"
+    try:
+        v = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+        r = subprocess.run([exe, "-e", "using GaussDCA; print(1)"], capture_output=True, text=True, timeout=600)
+        return "%s; using GaussDCA: %s" % (v, "ok (not timed: see cpu_baseline.kind)" if r.returncode == 0 else "fails")
+    except Exception as e:  # noqa: BLE001
+        return "probe failed: %s" % e
 
 
 def end_to_end(Zh, q, score_name, pc, ctx):
@@ -315,6 +334,8 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "config": {"workload": args.config},
                               "shards": gathered, "max_over_ranks": tmax,
+                              "comm": {"backend": "gloo" if world > 1 else None, "world_size": world,
+                                       "data_path_collectives": 0},
                               "scaling": "strong" if args.config == "E" else "weak"}))
         return
 
@@ -330,11 +351,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl" on ROCm) for the timing barrier / max-over-ranks only; no collective on the data path.
-        # gloo is a fallback so that a communicator problem cannot take the measurement down.
-        try:
+        # GDCA_BENCH_BACKEND=gloo selects gloo explicitly; a failing RCCL init is an error, not a silent fallback
+        # (the JSON line names the backend and the world size it really ran with).
+        backend = os.environ.get("GDCA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
-        except Exception:  # noqa: BLE001
-            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group(backend)
 
     # synthetic families, resident in HBM before the timed region ((M, N) int8 == Julia's N x M column-major bytes)
     from concurrent.futures import ThreadPoolExecutor
@@ -376,7 +399,8 @@ def main():
         for c in ctxs:
             c.synchronize()
 
-    warm = max(args.warmup, 1)  # every context is warmed (workspace allocation) before the clock starts
+    # every context is warmed (workspace allocation: hipMalloc synchronises the device) before the clock starts
+    warm = max(args.warmup, 1, -(-P // max(1, len(fams))))
     run_steps(warm, [])
     barrier()
     t0 = time.perf_counter()
@@ -407,6 +431,8 @@ def main():
         alg_flops = float(np.sum([s["inverse_flops"] for s in stats]))  # F = n^3 + n^2 + n per family
         achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         N0, M0 = fams[0][1], fams[0][2]
+        ghz = float(np.mean([s["sweep_ghz"] for s in stats]))
+        traffic, traffic_src = pmc_traffic(N0, M0, args.score) if args.config != "E" else (None, None)
         if args.config == "E":
             wl = ("batch of %d synthetic Pfam-like families, N in [100,600], M in [5k,80k], q=%d, score=:%s, "
                   "theta=:auto, pseudocount=%.1f, LPT-sharded over %d rank(s) (%s)"
@@ -445,13 +471,20 @@ def main():
                 "peak": PEAK_F64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": pmc_traffic(N0, M0, args.score) if args.config != "E" else None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,  # a committed rocprofv3 counter pass of this command, not this run
                 "launches_per_step": upd_launch / K,
                 "flops_per_launch": alg_flops / max(1, upd_launch),
                 "mfma_flops_issued_per_launch": upd_flops / max(1, upd_launch),  # incl. the padding to 128-blocks
                 "avg_launch_ms": upd_ms / max(1, upd_launch),
-                "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * MEASURED_SHADER_GHZ / 2.4,
+                # shader clock of the timed launches, measured by the kernel (s_memtime / 100 MHz wall clock of one
+                # workgroup, gdca_stats.sweep_ghz), and what the matrix pipes could deliver at that clock
+                "measured_shader_ghz": ghz,
+                "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ,
+                "frac_of_attainable_at_measured_clock": (achieved / (PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ)) if ghz > 0 else None,
             },
+            "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
+                     "data_path_collectives": 0},
         }
         if args.config != "E":
             out["config"].update({"N": N0, "M": M0, "n": N0 * (q - 1)})
@@ -459,6 +492,7 @@ def main():
         if world == 1 and args.config != "E":
             out["end_to_end_gdca_sec"] = end_to_end(Zh[0], q, args.score, pc, ctxs[0])
         if world == 1 and not args.no_cpu_baseline and args.config != "E":
+            out["reference_julia"] = probe_reference_julia()
             try:
                 out["cpu_baseline"] = cpu_baseline(N0, M0, q, pc, cfg["theta"], args.score, fams[0][3])
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -413,8 +413,18 @@ static gdca_status fetch_scalars(gdca_ctx *ctx)
     return GDCA_OK;
 }
 
+// An enqueued, not yet collected run (gdca_run_dev_async) owns the ctx workspace: scalars, flags, the pinned item table
+// and the big buffers.  Every other entry point that touches the workspace refuses to run until it has been collected.
+static gdca_status not_pending(gdca_ctx *ctx)
+{
+    if (ctx->pending)
+        return fail(ctx, GDCA_EINVAL, "a run is still enqueued on this context: call gdca_run_collect first%s%s", "", "");
+    return GDCA_OK;
+}
+
 static gdca_status begin(gdca_ctx *ctx)
 {
+    CHK(not_pending(ctx));
     HIPCHK(hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->sc, sizeof(gdca_dev_scalars)));
     HIPCHK(hipMemsetAsync(ctx->sc.p, 0, sizeof(gdca_dev_scalars), ctx->stream));
@@ -447,6 +457,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->update_launches = ctx->pend_nupd;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
+        st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
         if (ctx->pend_timed) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
@@ -470,6 +481,8 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         }
     }
     if (h.bad_symbol) return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
+    if (h.info == INT32_MIN)  // the sweep kernel's watchdog (k_inverse.hip, spin_until): a dependency wait ran out of time
+        return fail(ctx, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
     if (h.info != 0) return fail(ctx, GDCA_ENOTPD, "covariance matrix is not positive definite%s%s", "", "");
     if (h.di_noconv != 0) {
         if (st) st->info = -h.di_noconv;
@@ -488,9 +501,7 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     if (!(p->theta <= 1.0)) return fail(ctx, GDCA_EINVAL, "invalid theta value%s%s", "", "");
     if (p->score != GDCA_SCORE_FROB && p->score != GDCA_SCORE_DI)
         return fail(ctx, GDCA_EINVAL, "invalid score value%s%s", "", "");
-    if (ctx->pending)  // one run may be outstanding per ctx: its scalars and events would be overwritten
-        return fail(ctx, GDCA_EINVAL, "a run is still enqueued on this context: call gdca_run_collect first%s%s", "", "");
-    CHK(begin(ctx));
+    CHK(begin(ctx));  // (one run may be outstanding per ctx: its scalars and events would be overwritten -> GDCA_EINVAL)
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
     const bool timed = ctx->timing;
@@ -746,6 +757,10 @@ gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_
     gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, A_dev, n);
     CHK(check_launch(ctx, "copy_out"));
     CHK(fetch_scalars(ctx));
+    if (ctx->sc_host->info == INT32_MIN) {
+        if (info) *info = 0;
+        return fail(ctx, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
+    }
     if (info) *info = ctx->sc_host->info;
     if (ctx->sc_host->info != 0)
         return fail(ctx, GDCA_ENOTPD, "matrix is not positive definite; Cholesky factorization failed%s%s", "", "");
@@ -764,6 +779,7 @@ gdca_status gdca_fn_dev(gdca_ctx *ctx, const double *mJ_dev, int32_t N, int32_t 
 {
     CHK(validate(ctx, N, 1, q));
     if (!mJ_dev || !S_dev) return GDCA_EINVAL;
+    CHK(not_pending(ctx));
     HIPCHK(hipSetDevice(ctx->device));
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
     CHK(stage_neg_mJ(ctx, mJ_dev, n, n_pad));
@@ -792,6 +808,7 @@ gdca_status gdca_di_dev(gdca_ctx *ctx, const double *mJ_dev, const double *C_dev
 gdca_status gdca_apc_dev(gdca_ctx *ctx, double *S_dev, int32_t N)
 {
     if (!ctx || !S_dev || N < 1) return GDCA_EINVAL;
+    CHK(not_pending(ctx));
     HIPCHK(hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
     gdca_launch_apc(ctx->stream, S_dev, N, (double *)ctx->colsum.p);

@@ -19,6 +19,7 @@ struct gdca_dev_scalars {
     int info;
     int bad_symbol;  // bit 0: a byte of Z is outside 1..q; bit 1: a caller-given weight is outside [0, 1] (GDCA_EINVAL)
     int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
+    unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
 };
 
 // ---- k_theta.hip -------------------------------------------------------------------------

@@ -524,13 +524,49 @@ struct Frag {
     double a[4], b[4];
 };
 
+// Where a chunk's operands come from.  G(r, k), r = 0..127 operand rows, k = the chunk's 16 columns:
+//   GT = false: G(r, k) = g[r + k * gld]            (panels; tiles of A below the pivot group)
+//   GT = true:  G(r, k) = g[k + r * gld]            (tiles of A above the pivot group: the stored tile is the transpose)
+// H(c, k) = h[c + k * hld] always.  goff / hoff: this thread's byte offset inside a staging unit.
+struct ChunkIO {
+    size_t gld, hld;
+    unsigned goff, hoff;
+    size_t gcopy_ld;  // GCOPY: leading dimension of the untransposed copy of G that the panel items keep
+};
+
+template <bool GT>
+__device__ __forceinline__ ChunkIO chunk_io(size_t gld, size_t hld, int tid, size_t gcopy_ld = 0)
+{
+    ChunkIO io;
+    io.gld = gld;
+    io.hld = hld;
+    io.goff = GT ? ((unsigned)((tid & 7) * 2) + (unsigned)(tid >> 3) * (unsigned)gld) * 8u
+                 : ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)gld) * 8u;
+    io.hoff = ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)hld) * 8u;
+    io.gcopy_ld = gcopy_ld;
+    return io;
+}
+
+// The LDS image of a G chunk: [k][row] with LDS_LD doubles per k-row (GT = false), or, when the source is transposed, [row][k]
+// with GT_LD doubles per row -- 16-byte global loads of two k values go to LDS as they are, and the fragment reads of a half-wave
+// (16 rows x 2 k values) fall on 32 distinct bank pairs (18 doubles = 36 words per row).  Same 18 KB either way.
+#define GT_LD 18
+static_assert(T * GT_LD <= KC * LDS_LD, "transposed G image fits the chunk buffer");
+
+template <bool GT>
 __device__ __forceinline__ void frag_read(Frag &f, const double (*Gs)[LDS_LD], const double (*Hs)[LDS_LD], int k4, int wr, int wc,
                                           int l15, int lq)
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t) f.a[t] = Hs[k4 + lq][wc * 64 + t * 16 + l15];
+    if constexpr (GT) {
+        const double *Gt = &Gs[0][0];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f.b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
+        for (int t = 0; t < 4; ++t) f.b[t] = Gt[(wr * 64 + t * 16 + l15) * GT_LD + k4 + lq];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f.b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
+    }
 }
 
 // MFMA number I of a k4 step, in an order that starts with accumulator row TM0 (the C piece added after this step belongs to
@@ -563,80 +599,125 @@ __device__ __forceinline__ void mma_all(double4_t (&acc)[4][4], const Frag &f)
     mma_one<15, TM0>(acc, f);
 }
 
-// staging unit U of a chunk: U = 0..3 rows 4U.. of the G chunk, U = 4..7 rows 4(U-4).. of the H chunk (one 16-byte load / one
-// ds_write_b128 per thread; a wave moves one contiguous k-row of 128 operand rows)
-template <int U>
-__device__ __forceinline__ void stage_unit_store(const StageRegs<4> &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid)
+// staging unit U of a chunk: one 16-byte load / one ds_write_b128 per thread.  U = 4..7: k-rows 4 (U-4) .. of the H chunk (a
+// wave moves one contiguous k-row of 128 operand rows).  U = 0..3: the same for the G chunk, or (GT) operand rows 32 U .. 32 U + 31
+// of the G chunk, two k values per thread.  gc != nullptr: the G unit also goes to gc[r + k * gcopy_ld] (k relative to the chunk).
+template <int U, bool GT>
+__device__ __forceinline__ void stage_unit_store(const StageRegs<4> &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid,
+                                                 double *__restrict__ gc, size_t gcopy_ld)
 {
-    const int kk = (tid >> 6) + 4 * (U & 3), r2 = tid & 63;
-    if (U < 4)
-        *reinterpret_cast<double2 *>(&Gs[kk][r2 * 2]) = make_double2(R.g[2 * U], R.g[2 * U + 1]);
-    else
+    if constexpr (U >= 4) {
+        const int kk = (tid >> 6) + 4 * (U - 4), r2 = tid & 63;
         *reinterpret_cast<double2 *>(&Hs[kk][r2 * 2]) = make_double2(R.h[2 * (U - 4)], R.h[2 * (U - 4) + 1]);
-}
-
-// g, h: the operand pair's panels at the chunk's first k column (row offset included); boff: this thread's byte offset
-template <int U>
-__device__ __forceinline__ void stage_unit_load(StageRegs<4> &R, const double *__restrict__ g, const double *__restrict__ h,
-                                                size_t pld, unsigned boff)
-{
-    const char *rowbase = reinterpret_cast<const char *>((U < 4 ? g : h) + (size_t)(4 * (U & 3)) * pld);
-    const double2 v = *reinterpret_cast<const double2 *>(rowbase + boff);
-    if (U < 4) {
-        R.g[2 * U] = v.x;
-        R.g[2 * U + 1] = v.y;
+    } else if constexpr (GT) {
+        const int r = (tid >> 3) + 32 * U, k2 = tid & 7;
+        *reinterpret_cast<double2 *>(&Gs[0][0] + r * GT_LD + 2 * k2) = make_double2(R.g[2 * U], R.g[2 * U + 1]);
+        if (gc) {
+            gc[(size_t)r + (size_t)(2 * k2) * gcopy_ld] = R.g[2 * U];
+            gc[(size_t)r + (size_t)(2 * k2 + 1) * gcopy_ld] = R.g[2 * U + 1];
+        }
     } else {
-        R.h[2 * (U - 4)] = v.x;
-        R.h[2 * (U - 4) + 1] = v.y;
+        const int kk = (tid >> 6) + 4 * U, r2 = tid & 63;
+        *reinterpret_cast<double2 *>(&Gs[kk][r2 * 2]) = make_double2(R.g[2 * U], R.g[2 * U + 1]);
+        if (gc)
+            *reinterpret_cast<double2 *>(gc + (size_t)(r2 * 2) + (size_t)kk * gcopy_ld) = make_double2(R.g[2 * U], R.g[2 * U + 1]);
     }
 }
 
-template <int U, bool STORE, bool LOAD>
+// g, h: the sources at the chunk's first k column
+template <int U, bool GT>
+__device__ __forceinline__ void stage_unit_load(StageRegs<4> &R, const double *__restrict__ g, const double *__restrict__ h,
+                                                const ChunkIO &io)
+{
+    if constexpr (U >= 4) {
+        const char *base = reinterpret_cast<const char *>(h + (size_t)(4 * (U - 4)) * io.hld);
+        const double2 v = *reinterpret_cast<const double2 *>(base + io.hoff);
+        R.h[2 * (U - 4)] = v.x;
+        R.h[2 * (U - 4) + 1] = v.y;
+    } else {
+        const char *base = reinterpret_cast<const char *>(g + (size_t)((GT ? 32 : 4) * U) * io.gld);
+        const double2 v = *reinterpret_cast<const double2 *>(base + io.goff);
+        R.g[2 * U] = v.x;
+        R.g[2 * U + 1] = v.y;
+    }
+}
+
+// a whole chunk at once (item prologues)
+template <bool GT>
+__device__ __forceinline__ void stage_chunk_load(StageRegs<4> &R, const double *__restrict__ g, const double *__restrict__ h,
+                                                 const ChunkIO &io)
+{
+    stage_unit_load<0, GT>(R, g, h, io);
+    stage_unit_load<1, GT>(R, g, h, io);
+    stage_unit_load<2, GT>(R, g, h, io);
+    stage_unit_load<3, GT>(R, g, h, io);
+    stage_unit_load<4, GT>(R, g, h, io);
+    stage_unit_load<5, GT>(R, g, h, io);
+    stage_unit_load<6, GT>(R, g, h, io);
+    stage_unit_load<7, GT>(R, g, h, io);
+}
+
+template <bool GT>
+__device__ __forceinline__ void stage_chunk_store(const StageRegs<4> &R, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD], int tid,
+                                                  double *__restrict__ gc, size_t gcopy_ld)
+{
+    stage_unit_store<0, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<1, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<2, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<3, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<4, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<5, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<6, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+    stage_unit_store<7, GT>(R, Gs, Hs, tid, gc, gcopy_ld);
+}
+
+template <int U, bool STORE, bool LOAD, bool GT>
 __device__ __forceinline__ void stage_unit(double4_t (&acc)[4][4], const Frag &f, StageRegs<4> &R, double (*Gn)[LDS_LD],
                                            double (*Hn)[LDS_LD], const double *__restrict__ g, const double *__restrict__ h,
-                                           size_t pld, unsigned boff, int tid)
+                                           const ChunkIO &io, int tid, double *__restrict__ gc)
 {
     mma_one<2 * U, 0>(acc, f);
     mma_one<2 * U + 1, 0>(acc, f);
-    if constexpr (STORE) stage_unit_store<U>(R, Gn, Hn, tid);
-    if constexpr (LOAD) stage_unit_load<U>(R, g, h, pld, boff);
+    if constexpr (STORE) stage_unit_store<U, GT>(R, Gn, Hn, tid, gc, io.gcopy_ld);
+    if constexpr (LOAD) stage_unit_load<U, GT>(R, g, h, io);
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // One chunk.  On entry: `f` = fragments of (Gc, Hc) at k4 = 0; R = the next chunk (loads in flight or landed).
-// STORE: R -> (Gn, Hn);  LOAD: R <- the chunk at (g, h);  NEXT: on exit `f` = fragments of (Gn, Hn) at k4 = 0.
+// STORE: R -> (Gn, Hn) (gc != nullptr: its G part also to gc);  LOAD: R <- the chunk at (g, h);  NEXT: on exit `f` = fragments of
+// (Gn, Hn) at k4 = 0.
 // CI: 0..7 = this chunk also adds C piece CI (requested one chunk earlier; piece 0 in the item's prologue) and requests piece
 // CI + 1; -1 = no C traffic.
-template <bool STORE, bool LOAD, bool NEXT, int CI>
+template <bool STORE, bool LOAD, bool NEXT, int CI, bool GT = false>
 __device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, StageRegs<4> &R, double (&cp)[8], double (*Gc)[LDS_LD],
                                            double (*Hc)[LDS_LD], double (*Gn)[LDS_LD], double (*Hn)[LDS_LD],
-                                           const double *__restrict__ g, const double *__restrict__ h, size_t pld, unsigned boff,
-                                           const double *__restrict__ At, size_t ld, int tid)
+                                           const double *__restrict__ g, const double *__restrict__ h, const ChunkIO &io,
+                                           const double *__restrict__ At, size_t ld, int tid, double *__restrict__ gc = nullptr)
 {
     const int lane = tid & 63, wv = tid >> 6, wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     Frag f1;
-    frag_read(f1, Gc, Hc, 4, wr, wc, l15, lq);
+    frag_read<GT>(f1, Gc, Hc, 4, wr, wc, l15, lq);
     constexpr int TM0 = CI >= 0 ? (CI / 2) & 3 : 0;
     mma_all<TM0>(acc, f);  // k4 = 0
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (CI >= 0) cpiece_add<(CI >= 0 ? CI : 0)>(acc, cp);
     if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, wr, wc, l15, lq);
-    frag_read(f, Gc, Hc, 8, wr, wc, l15, lq);
+    frag_read<GT>(f, Gc, Hc, 8, wr, wc, l15, lq);
     __builtin_amdgcn_sched_barrier(0);
-    stage_unit<0, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);  // k4 = 4, two MFMAs per unit
-    stage_unit<1, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<2, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<3, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<4, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<5, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<6, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    stage_unit<7, STORE, LOAD>(acc, f1, R, Gn, Hn, g, h, pld, boff, tid);
-    frag_read(f1, Gc, Hc, 12, wr, wc, l15, lq);
+    stage_unit<0, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);  // k4 = 4, two MFMAs per unit
+    stage_unit<1, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<2, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<3, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<4, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<5, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<6, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    stage_unit<7, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);
+    frag_read<GT>(f1, Gc, Hc, 12, wr, wc, l15, lq);
     __builtin_amdgcn_sched_barrier(0);
     mma_all<0>(acc, f);  // k4 = 8; the last fragment reads of this buffer land underneath
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();     // (Gc, Hc) is free, (Gn, Hn) is complete
-    if constexpr (NEXT) frag_read(f, Gn, Hn, 0, wr, wc, l15, lq);
+    if constexpr (NEXT) frag_read<GT>(f, Gn, Hn, 0, wr, wc, l15, lq);
     __builtin_amdgcn_sched_barrier(0);
     mma_all<0>(acc, f1);  // k4 = 12
     __builtin_amdgcn_sched_barrier(0);
@@ -729,6 +810,10 @@ struct SweepDesc {
     double *Pg0, *Pg1;     // Pg by group parity, ld = 128 sz
     double *Pw;            // 128 x 128: inverse of the current pivot block
     unsigned *gen, *rb, *mc, *done, *next, *next_m, *mcu;
+    unsigned *mxcc;        // XCC the chain's compute units are elected on (0 = not chosen yet, else id + 1): the first workgroup to arrive decides
+    unsigned *abort;       // set by a workgroup whose dependency wait ran out of time: everybody leaves (watchdog)
+    unsigned long long timeout_ticks;  // bound of a single dependency wait, 100 MHz ticks
+    int debug;             // GDCA_SWEEP_DEBUG bits (tests): 1 = workgroups on XCC 0 stay out of the election; 2 = nobody is elected
     const int *gs;         // [ng + 1]: first block of group p (groups need not have the same size: a short ramp 1, 2, .. opens
                            // the sweep so that the first chains are short while there is little update work to hide them behind)
     const int *item0;      // [ng + 1]: first item of group p's sequence in the main list
@@ -799,14 +884,56 @@ __device__ __forceinline__ void publish_wt_begin()
     __syncthreads();
 }
 
-// after thread 0 has seen all the flags it polled: agent-scope acquire, then the workgroup may load the data
-__device__ __forceinline__ void acquire_end()
+// ---- waiting for flags, with a way out ---------------------------------------------------------------------------------------
+// Every dependency wait of the kernel is thread 0 polling a few flags (s_sleep between polls).  A wait that never ends -- a
+// bug in the item order, a workgroup of the launch that was never scheduled, a device fault elsewhere -- would hang the whole
+// GPU behind a C-ABI that promises to return a status.  So a wait is bounded (D.timeout_ticks of the 100 MHz wall clock, seconds:
+// a healthy wait is microseconds): the workgroup that runs out of time sets the device-wide abort word and sc->info = INT_MIN,
+// every poll loop also looks at that word, and everybody leaves; the host maps it to GDCA_EHIP.  The fast path (flags already
+// set) costs nothing; a poll iteration costs one more load.
+__device__ __forceinline__ int *abort_lds()
+{
+    __shared__ int w;  // this workgroup has seen the abort (written by thread 0 before a barrier, read by all after it)
+    return &w;
+}
+
+// `ready` loads the flags of the wait and says whether they are all set; the abort word travels in the same round trip.
+// Returns false when the wait was abandoned.  (Thread 0 only.)
+template <class F>
+__device__ __forceinline__ bool spin_until(const SweepDesc &D, F ready)
+{
+    unsigned long long t0 = 0ull;
+    for (unsigned it = 0;; ++it) {
+#ifdef GDCA_X_NOPOLL
+        const unsigned ab = 0u;
+#else
+        const unsigned ab = flag_load(D.abort);
+#endif
+        const bool r = ready();
+        if (ab != 0u) return false;
+        if (r) return true;
+        if (it == 0)
+            t0 = wall_clock64();
+        else if (wall_clock64() - t0 > D.timeout_ticks) {
+            __hip_atomic_store(D.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&D.sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// after thread 0 has seen all the flags it polled (ok = none of its waits was abandoned): agent-scope acquire, then the
+// workgroup may load the data.  Returns false when a wait was abandoned (abort): the caller drops the item.
+__device__ __forceinline__ bool acquire_end(bool ok)
 {
     if (threadIdx.x == 0) {
+        *abort_lds() = ok ? 0 : 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    return *abort_lds() == 0;
 }
 
 // M(q): sz (sz+1) / 2 gather items (one lower tile each), per block w a pivot + 2 (sz-1) + 2 (sz-1)^2 tile jobs, then
@@ -930,18 +1057,19 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         }
         const int ib = jb + x;
         unsigned *genp = D.gen + (size_t)(b0 + ib) * D.nblk + (b0 + jb);
+        bool ok = true;
         if (tid == 0) {
             if (gather) {
-                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);   // the tile carries all earlier groups
+                ok = spin_until(D, [&] { return flag_load(genp) >= (unsigned)q; });   // the tile carries all earlier groups
             } else {
-                while (flag_load(mc) < (unsigned)(nm - nt)) __builtin_amdgcn_s_sleep(8);
-                if (q >= 2) {
+                ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)(nm - nt); });
+                if (ok && q >= 2) {
                     const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
-                    while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
+                    ok = spin_until(D, [&] { return flag_load(D.done + (q - 2)) >= want; });
                 }
             }
         }
-        acquire_end();
+        if (!acquire_end(ok)) return;
         double *At = Agg + (size_t)ib * T + (size_t)jb * T * D.ld;
         double(*Ts)[LDS_LD] = Gs[0];
         // the tile goes 16 columns at a time: straight copies stay contiguous along columns, and the mirror images
@@ -1009,21 +1137,22 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     if (r == 0) {
         // pivot of block w: on the scratch matrix, or -- a group of ONE block -- in place on A with Pg = its inverse
         unsigned *genp = D.gen + (size_t)b0 * D.nblk + b0;
+        bool ok = true;
         if (tid == 0) {
             if (sz == 1) {
-                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);
-                if (q >= 2) {
+                ok = spin_until(D, [&] { return flag_load(genp) >= (unsigned)q; });
+                if (ok && q >= 2) {
                     const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
-                    while (flag_load(D.done + (q - 2)) < want) __builtin_amdgcn_s_sleep(8);
+                    ok = spin_until(D, [&] { return flag_load(D.done + (q - 2)) >= want; });
                 }
             } else if (first_pivot) {
                 // (the tile at generation q implies that M(q-1) is complete: the scratch matrices and Pw are free)
-                while (flag_load(genp) < (unsigned)q) __builtin_amdgcn_s_sleep(8);
+                ok = spin_until(D, [&] { return flag_load(genp) >= (unsigned)q; });
             } else {
-                while (flag_load(mc) < (unsigned)base_w) __builtin_amdgcn_s_sleep(8);
+                ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)base_w; });
             }
         }
-        acquire_end();
+        if (!acquire_end(ok)) return;
         const size_t dd = (size_t)w * T + (size_t)w * T * m;
         const double *pin = (sz == 1 || first_pivot) ? (const double *)Agg : Sin + dd;
         double *pout = sz == 1 ? Agg : Sout + dd;
@@ -1049,9 +1178,9 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     }
     if (ii >= w) ++ii;
     if (jj >= w) ++jj;
-    if (tid == 0)
-        while (flag_load(mc) < (unsigned)(base_w + 1 + (second ? n1 : 0))) __builtin_amdgcn_s_sleep(8);
-    acquire_end();
+    bool ok = true;
+    if (tid == 0) ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)(base_w + 1 + (second ? n1 : 0)); });
+    if (!acquire_end(ok)) return;
     const double *gsrc = (second ? (const double *)Sout : Sin) + (size_t)ii * T + (size_t)w * T * m;
     const double *hsrc = second ? Sin + (size_t)jj * T + (size_t)w * T * m : D.Pw;
     const size_t hld = second ? (size_t)m : (size_t)T;
@@ -1083,6 +1212,40 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
     if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The panel product of a row block for ONE pivot block's 128 columns of H, K = 128 sz, on the tile items' chunk loop:
+//   acc(r, c) = sum_v sum_k G_v(r, k) Pg(c, 128 v + k)
+// gA: the row block's tile of the group's FIRST pivot block in A -- G_v(r, k) = gA[r + (128 v + k) ld] below the group, and
+// (GT) gA[128 v + k + r ld] above it, where the stored tile is the transpose.  hP: Pg at (row c = 0 of the wanted columns, k = 0).
+// gcopy: the item also leaves the untransposed G_v in the panel buffers (gcopy + v pstride, ld = ld).
+template <bool GT>
+__device__ __forceinline__ void panel_chunks(double4_t (&acc)[4][4], const double *__restrict__ gA, size_t ld,
+                                             const double *__restrict__ hP, size_t pgld, int sz, double (*Gs)[KC][LDS_LD],
+                                             double (*Hs)[KC][LDS_LD], double *__restrict__ gcopy, size_t pstride)
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    const ChunkIO io = chunk_io<GT>(ld, pgld, tid, ld);
+    const int nch = (T / KC) * sz;  // chunk c: k = 16 c .. 16 c + 15 of the group's 128 sz columns
+    auto gsrc = [&](int c) { return GT ? gA + (size_t)c * KC : gA + (size_t)c * KC * ld; };
+    auto hsrc = [&](int c) { return hP + (size_t)c * KC * pgld; };
+    auto gcp = [&](int c) { return gcopy ? gcopy + (size_t)(c >> 3) * pstride + (size_t)((c & 7) * KC) * ld : nullptr; };
+    StageRegs<4> R;
+    double cp[8];
+    Frag f;
+    stage_chunk_load<GT>(R, gsrc(0), hsrc(0), io);
+    stage_chunk_store<GT>(R, Gs[0], Hs[0], tid, gcp(0), ld);
+    stage_chunk_load<GT>(R, gsrc(1), hsrc(1), io);
+    __syncthreads();
+    frag_read<GT>(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
+#pragma unroll 1
+    for (int c = 0; c < nch - 2; c += 2) {
+        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gsrc(c + 2), hsrc(c + 2), io, nullptr, 0, tid, gcp(c + 1));
+        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gsrc(c + 3), hsrc(c + 3), io, nullptr, 0, tid, gcp(c + 2));
+    }
+    tile_chunk<true, false, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gA, hP, io, nullptr, 0, tid, gcp(nch - 1));
+    tile_chunk<false, false, false, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gA, hP, io, nullptr, 0, tid);
+}
+
 // ---- panel(p): G_i and 32 TM columns of H_i = -G_i Pg for one row block ---------------------------------------------------
 // (i = the row block, y = which 32 TM of the m columns of H).  TM = 2: 64 columns, two items per pivot block -- the chain's
 // form (M list), where the next group's rows are latency-critical; TM = 4: 128 columns, one item per pivot block -- the main
@@ -1096,6 +1259,7 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     const int b0 = g_start(D, p), sz = g_size(D, p);
     const int w = TM == 2 ? y >> 1 : y, ch = TM == 2 ? (y & 1) : 0;
+    bool ok = true;
     if (tid == 0) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         // Pg(p); the group's columns of row i at generation p; the panel buffers of parity p free (group p-2 complete): all
@@ -1109,15 +1273,14 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
             gp[v] = D.gen + (size_t)I * D.nblk + J;
         }
         const unsigned nmi = (unsigned)m_items(sz);
-        for (;;) {
+        ok = spin_until(D, [&] {
             const unsigned f0 = flag_load(D.mc + p), f1 = flag_load(gp[0]), f2 = flag_load(gp[1]), f3 = flag_load(gp[2]),
                            f4 = flag_load(gp[3]), f5 = flag_load(dn);
-            if ((f0 >= nmi) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= (unsigned)p) & (f4 >= (unsigned)p) & (f5 >= want)) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
+            return (f0 >= nmi) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= (unsigned)p) & (f4 >= (unsigned)p) & (f5 >= want);
+        });
         if (D.dbg) atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
     }
-    acquire_end();
+    if (!acquire_end(ok)) return;
     const size_t ld = D.ld, pgld = (size_t)sz * T;
     const double *Pg = (p & 1) ? D.Pg1 : D.Pg0;
     double *G0 = D.G0 + (size_t)4 * (p & 1) * D.pstride, *H0 = D.H0 + (size_t)4 * (p & 1) * D.pstride;
@@ -1129,7 +1292,13 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     // H operand of pivot block v: Pg(c, k) for c = w 128 + ch 64 + .., k = v 128 + ..  (Pg is symmetric)
     const double *hsrc0 = Pg + (size_t)w * T + (size_t)ch * 64;
     double *gcopy0 = (y == 0) ? G0 + (size_t)i * T : nullptr;
-    if (i > b0) {  // below the group: G_i = A[i, k]
+    if constexpr (TM == 4) {
+        // the hand-scheduled chunk loop of the tile items (tile_chunk), K = 128 sz
+        if (i > b0)
+            panel_chunks<false>(acc, D.A + (size_t)i * T + (size_t)b0 * T * ld, ld, hsrc0, pgld, sz, Gs, Hs, gcopy0, D.pstride);
+        else
+            panel_chunks<true>(acc, D.A + (size_t)b0 * T + (size_t)i * T * ld, ld, hsrc0, pgld, sz, Gs, Hs, gcopy0, D.pstride);
+    } else if (i > b0) {  // below the group: G_i = A[i, k]
 #pragma unroll 1
         for (int v = 0; v < sz; ++v)
             tile_product<false, TM>(acc, D.A + (size_t)i * T + (size_t)(b0 + v) * T * ld, ld, hsrc0 + (size_t)v * T * pgld, pgld, Gs[0],
@@ -1160,22 +1329,22 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 // `nxt`, `s_next`, `s_ready` (main-list callers; thread 0's value / LDS words): the workgroup's NEXT item number, in flight as
 // an atomic since the start of this item.  While this item's stores drain, thread 0 looks that item up and, if it is a tile
 // item, reads its flags: the next trip then starts without the counter's and the flags' round trips (~3 us of a ~105 us item).
-__device__ __forceinline__ void tile_item_wait(const SweepDesc &D, int p, int I, int J, int ready)
+__device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I, int J, int ready)
 {
+    bool ok = true;
     if (opaque_tid() == 0 && !ready) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         const unsigned need = 2u * (unsigned)g_size(D, p);
         const unsigned *genp = D.gen + (size_t)I * D.nblk + J;
         // the three flags are loaded TOGETHER (one L2 round trip, ~1.5 us under load, instead of three dependent ones)
-        for (;;) {
+        ok = spin_until(D, [&] {
             const unsigned f1 = flag_load(D.rb + (size_t)p * D.nblk + I), f2 = flag_load(D.rb + (size_t)p * D.nblk + J),
                            f3 = flag_load(genp);
-            if ((f1 >= need) & (f2 >= need) & (f3 >= (unsigned)p)) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
+            return (f1 >= need) & (f2 >= need) & (f3 >= (unsigned)p);
+        });
         if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
     }
-    acquire_end();
+    return acquire_end(ok);
 }
 
 // after the tile's (write-through) stores have been issued: look the next item up while they drain, then publish
@@ -1211,7 +1380,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    tile_item_wait(D, p, I, J, ready);
+    if (!tile_item_wait(D, p, I, J, ready)) return;
     const size_t ld = D.ld, pld = D.ld;
     const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride;
     double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
@@ -1225,7 +1394,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
         double cp[8];
         Frag f;
         const size_t go = (size_t)I * T, ho = (size_t)J * T;
-        const unsigned boff = ((unsigned)((tid & 63) * 2) + (unsigned)(tid >> 6) * (unsigned)pld) * 8u;
+        const ChunkIO io = chunk_io<false>(pld, pld, tid);
         const size_t cs = (size_t)KC * pld;  // one chunk further along k
         const double *g = Gp + go, *h = Hp + ho;
         stage_load<false, 4>(R, g, pld, h, pld, 0, tid);
@@ -1233,15 +1402,15 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
         stage_store<false, 4>(R, Gs[0], Hs[0], tid);
         stage_load<false, 4>(R, g, pld, h, pld, KC, tid);
         __syncthreads();
-        frag_read(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
+        frag_read<false>(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
         // chunk c multiplies LDS buffer c & 1, stores chunk c+1 into the other one and loads chunk c+2; the first eight chunks
         // (the group's first pivot block) also bring the C tile in
-        tile_chunk<true, true, true, 0>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 2 * cs, h + 2 * cs, pld, boff, At, ld, tid);
-        tile_chunk<true, true, true, 1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 3 * cs, h + 3 * cs, pld, boff, At, ld, tid);
-        tile_chunk<true, true, true, 2>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 4 * cs, h + 4 * cs, pld, boff, At, ld, tid);
-        tile_chunk<true, true, true, 3>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 5 * cs, h + 5 * cs, pld, boff, At, ld, tid);
-        tile_chunk<true, true, true, 4>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 6 * cs, h + 6 * cs, pld, boff, At, ld, tid);
-        tile_chunk<true, true, true, 5>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 7 * cs, h + 7 * cs, pld, boff, At, ld, tid);
+        tile_chunk<true, true, true, 0>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 2 * cs, h + 2 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 3 * cs, h + 3 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 2>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 4 * cs, h + 4 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 3>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 5 * cs, h + 5 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 4>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 6 * cs, h + 6 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 5>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 7 * cs, h + 7 * cs, io, At, ld, tid);
         if constexpr (MULTI) {
             // the other pivot blocks of the group: operand pair w at Gp / Hp + w * pstride.  nch = chunks of the whole item (even,
             // >= 10): 8 per pivot block, fewer for the block that holds the ragged end of the matrix (its padding columns are
@@ -1249,21 +1418,21 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
             const int nch = g_chunks(D, p);
             g += D.pstride;
             h += D.pstride;
-            tile_chunk<true, true, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
-            tile_chunk<true, true, true, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + cs, h + cs, pld, boff, At, ld, tid);
+            tile_chunk<true, true, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
+            tile_chunk<true, true, true, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + cs, h + cs, io, At, ld, tid);
 #pragma unroll 1
             for (int c = 8; c < nch - 2; c += 2) {
                 // loads chunks c + 2 and c + 3 (the same operand pair: c is even and a pair holds 8 chunks)
                 const double *gl = Gp + (size_t)((c + 2) >> 3) * D.pstride + go + (size_t)((c + 2) & 7) * cs;
                 const double *hl = Hp + (size_t)((c + 2) >> 3) * D.pstride + ho + (size_t)((c + 2) & 7) * cs;
-                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gl, hl, pld, boff, At, ld, tid);
-                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gl + cs, hl + cs, pld, boff, At, ld, tid);
+                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gl, hl, io, At, ld, tid);
+                tile_chunk<true, true, true, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gl + cs, hl + cs, io, At, ld, tid);
             }
-            tile_chunk<true, false, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
-            tile_chunk<false, false, false, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, pld, boff, At, ld, tid);
+            tile_chunk<true, false, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
+            tile_chunk<false, false, false, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, io, At, ld, tid);
         } else {
-            tile_chunk<true, false, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, pld, boff, At, ld, tid);
-            tile_chunk<false, false, false, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, pld, boff, At, ld, tid);
+            tile_chunk<true, false, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
+            tile_chunk<false, false, false, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, io, At, ld, tid);
         }
     }
 #pragma unroll
@@ -1289,7 +1458,7 @@ __device__ __forceinline__ void sweep_tile_item_ragged(const SweepDesc &D, int p
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    tile_item_wait(D, p, I, J, ready);
+    if (!tile_item_wait(D, p, I, J, ready)) return;
     const size_t ld = D.ld, pld = D.ld;
     const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride + (size_t)I * T, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride + (size_t)J * T;
     double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
@@ -1347,9 +1516,9 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
     const int w = e / rows;
     if (i >= b0) i += sz;
     const int k = b0 + w;
-    if (tid == 0)
-        while (flag_load(D.rb + (size_t)p * D.nblk + i) < 2u * (unsigned)sz) __builtin_amdgcn_s_sleep(8);
-    acquire_end();
+    bool ok = true;
+    if (tid == 0) ok = spin_until(D, [&] { return flag_load(D.rb + (size_t)p * D.nblk + i) >= 2u * (unsigned)sz; });
+    if (!acquire_end(ok)) return;
     panel_writeback_tile(D.A, D.ld, k, i, D.H0 + (size_t)(4 * (p & 1) + w) * D.pstride, D.ld, Gs[0]);
     publish_begin();
     if (tid == 0) {
@@ -1376,26 +1545,39 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     // ---- the M list runs on compute units of its own ----
     // The serial chain of a group (128 dependent steps per pivot block, each a handful of VALU / DPP / MFMA instructions) is
     // several times slower when its waves share their SIMDs with the MFMA stream of a tile item, and then IT sets the pace
-    // of the whole inverse.  So a few compute units of one XCD (n_mcu, up to 16) are elected at run time -- the first ones that show up;
+    // of the whole inverse.  So a few compute units of ONE XCD (n_mcu, up to 16) are elected at run time -- the first ones that show up;
     // both workgroups of an elected CU become M workers -- and take only M items (their own counter); one XCD, so that the
     // items of a chain hand their data on through one L2.  Everybody else takes the main list.  The elected CUs are lost to
     // the tiles (2 n_mcu of 512 workgroups) and join them once the M list is exhausted.
     if (threadIdx.x == 0) {
+        *abort_lds() = 0;
         unsigned xcc, hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        xcc &= 15u;
         int worker = 0;
-        if ((xcc & 15u) == 0u) {
-            const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
-            for (int k = 0; k < D.n_mcu && !worker; ++k) {
-                const unsigned old = atomicCAS(D.mcu + k, 0u, key);
-                if (old == 0u || old == key) worker = 1;
+        // the XCD of the chain is whichever one the first workgroup to get here runs on (not a fixed id: under a CU mask, in
+        // a partitioned mode or beside another tenant no workgroup of the launch may ever run on XCC 0)
+        const bool candidate = !(D.debug & 2) && !((D.debug & 1) && xcc == 0u) && !((D.debug & 4) && xcc != 0u);
+        if (candidate) {
+            const unsigned old = atomicCAS(D.mxcc, 0u, xcc + 1u);
+            if (old == 0u || old == xcc + 1u) {
+                const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
+                for (int k = 0; k < D.n_mcu && !worker; ++k) {
+                    const unsigned o2 = atomicCAS(D.mcu + k, 0u, key);
+                    if (o2 == 0u || o2 == key) worker = 1;
+                }
             }
         }
         s_item = worker;
     }
     __syncthreads();
     const bool m_worker = s_item != 0;
+    // the clock this launch really ran at (the governor moves it between 1.7 and 2.4 GHz, and not every XCD need run at the
+    // same one): every workgroup times itself, the sums give the workgroup-time-weighted average over the chip
+    const bool clock_probe = threadIdx.x == 0;
+    const unsigned long long probe_c0 = clock_probe ? (unsigned long long)clock64() : 0ull;
+    const unsigned long long probe_w0 = clock_probe ? wall_clock64() : 0ull;
     __syncthreads();
     if (m_worker) {
         int q = 0;
@@ -1404,7 +1586,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             __syncthreads();
             const int item = s_item;
             __syncthreads();
-            if (item >= D.total_m) break;
+            if (item >= D.total_m || *abort_lds()) break;
             while (item >= D.mitem0[q + 1]) ++q;
             int e = item - D.mitem0[q];
             if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
@@ -1450,7 +1632,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         __syncthreads();
         const int item = s_next, rdy = s_ready;
         __syncthreads();  // everybody has read them
-        if (item >= D.total) break;
+        if (item >= D.total || *abort_lds()) break;
         int nxt = 0;
         if (threadIdx.x == 0) nxt = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
@@ -1495,13 +1677,19 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             s_ready = 0;
         }
     }
+    if (clock_probe) {
+        atomicAdd(&D.sc->sweep_cycles, (unsigned long long)clock64() - probe_c0);
+        atomicAdd(&D.sc->sweep_ticks, wall_clock64() - probe_w0);
+    }
     if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work
 }
 
 size_t gdca_inverse_flag_bytes(int n_pad)
 {
     const size_t nblk = (size_t)(n_pad / T);
-    return (nblk * nblk + nblk * nblk + 2 * nblk + 20) * sizeof(unsigned);  // gen, rb (ng <= nblk), mc, done, next, next_m, mcu[16]
+    // gen, rb (ng <= nblk), mc, done | next, next_m, mcu[16], mxcc | the abort word on a 128-byte line of its own (every wait
+    // of the kernel reads it; the line of the item counters is busy with atomics)
+    return (nblk * nblk + nblk * nblk + 2 * nblk + 96) * sizeof(unsigned);
 }
 
 // Host side: the item table, the flags, one launch.
@@ -1612,6 +1800,14 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.next = f;
     D.next_m = f + 1;
     D.mcu = f + 2;
+    D.mxcc = f + 18;
+    D.abort = f + 64;
+    // bound of one dependency wait (GDCA_SWEEP_TIMEOUT_MS, default 4 s; a healthy wait is microseconds, a whole inverse at
+    // n = 48 000 takes 1.8 s)
+    static const long timeout_env = getenv("GDCA_SWEEP_TIMEOUT_MS") ? atol(getenv("GDCA_SWEEP_TIMEOUT_MS")) : 4000;
+    D.timeout_ticks = (unsigned long long)std::max(1L, timeout_env) * 100000ull;
+    static const int debug_env = getenv("GDCA_SWEEP_DEBUG") ? atoi(getenv("GDCA_SWEEP_DEBUG")) : 0;
+    D.debug = debug_env;
     D.item0 = ws.item0_dev;
     D.mitem0 = ws.item0_dev + (ng + 1);
     D.gs = ws.item0_dev + 2 * (ng + 1);

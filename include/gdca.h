@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define GDCA_VERSION_MAJOR 0
-#define GDCA_VERSION_MINOR 2
+#define GDCA_VERSION_MINOR 3
 
 typedef enum gdca_status {
     GDCA_OK = 0,
@@ -84,6 +84,8 @@ typedef struct gdca_stats {
     double ms_score;            /* FN or DI, + APC                                          */
     double inverse_flops;       /* n^3/3+n^2/2+n/6 + 2n^3/3+n^2/2+5n/6 (dpotrf+dpotri)      */
     double update_flops;        /* flops executed by all launches of the dominant kernel    */
+    double sweep_ghz;           /* shader clock during the SPD-inverse kernel, measured by the kernel itself
+                                   (s_memtime cycles / 100 MHz wall-clock ticks, summed over its workgroups); 0 if no inverse ran */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */

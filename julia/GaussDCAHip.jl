@@ -36,6 +36,7 @@ mutable struct GdcaStats
     ms_total::Cdouble; ms_theta::Cdouble; ms_weights::Cdouble; ms_covariance::Cdouble
     ms_inverse::Cdouble; ms_inverse_update::Cdouble; ms_score::Cdouble
     inverse_flops::Cdouble; update_flops::Cdouble
+    sweep_ghz::Cdouble
     GdcaStats() = new()
 end
 

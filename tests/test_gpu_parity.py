@@ -343,7 +343,9 @@ print(json.dumps(out))
                                  {"GDCA_GROUP": "2", "GDCA_REM_TAIL": "7"}, {"GDCA_GROUP": "4", "GDCA_REM_TAIL": "100000"},
                                  {"GDCA_GROUP": "3", "GDCA_PANEL_HALVES": "1"}, {"GDCA_GROUP": "2", "GDCA_PANEL_HALVES": "0"},
                                  {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}, {"GDCA_GROUP": "3", "GDCA_RAMP": "0"},
-                                 {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"}])
+                                 {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"},
+                                 {"GDCA_GROUP": "3", "GDCA_RAGGED": "0"}, {"GDCA_GROUP": "4", "GDCA_SWEEP_DEBUG": "1"},
+                                 {"GDCA_GROUP": "1", "GDCA_SWEEP_DEBUG": "1", "GDCA_MCUS": "16"}])
 def test_every_inverse_schedule_matches_lapack(env):
     """The SPD inverse is one persistent launch that sweeps pivot groups of 1-4 blocks (the group size is chosen by matrix
     size) with its serial chain on 1-16 elected compute units.  Each combination, forced through its environment switches
@@ -402,3 +404,60 @@ def test_random_mid_size_campaign(g, ctx, o, seed):
         S_o = o.scores_from_Z(Zo, 21, pc, "auto", score)
         ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9)    # 1e-6 relative
         assert ok, (seed, k, N, M, score, max_rel, max_abs)
+
+
+_WATCHDOG_SCRIPT = r"""
+import os, sys, json, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import gaussdca.jl_amd as g
+ctx = g.Context(0)
+rng = np.random.default_rng(5)
+n = int(sys.argv[2])
+B = rng.standard_normal((n, 40))
+A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
+out = {}
+t = time.time()
+try:
+    X = g.inv_cholesky(A, ctx=ctx)
+    out["status"] = "ok"
+    out["rel"] = float(np.max(np.abs(X - np.linalg.inv(A))) / np.max(np.abs(X)))
+except g.GdcaError as e:
+    out["status"] = "ehip"
+    out["msg"] = str(e)
+out["seconds"] = time.time() - t
+Z = np.asfortranarray(rng.integers(1, 22, size=(30, 200)).astype(np.int8))
+out["theta_after"] = float(g.compute_theta(Z, ctx=ctx))          # the context and the device are still usable
+print(json.dumps(out))
+"""
+
+
+def _run_watchdog(env, n):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _WATCHDOG_SCRIPT, root, str(n)], capture_output=True, text=True,
+                       env=dict(os.environ, **env), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("n", [1500, 9000])
+def test_chain_election_does_not_need_xcc0(n):
+    """The pivot chain's compute units are elected on whichever XCD the first workgroup of the launch runs on.
+    GDCA_SWEEP_DEBUG=1 keeps every workgroup that runs on XCC 0 out of the election (what a CU mask, a partitioned mode
+    or another tenant on that XCD would do): the inverse must still be the LAPACK inverse."""
+    out = _run_watchdog({"GDCA_SWEEP_DEBUG": "1"}, n)
+    assert out["status"] == "ok" and out["rel"] <= 1e-10, out
+
+
+def test_sweep_watchdog_returns_a_status_instead_of_hanging():
+    """GDCA_SWEEP_DEBUG=2 elects nobody for the chain: Pg(0) is never produced and every workgroup of the launch ends up
+    waiting for it.  The bounded waits (GDCA_SWEEP_TIMEOUT_MS, here 300 ms; default 4 s) must turn that into GDCA_EHIP
+    within seconds, and the context must stay usable."""
+    out = _run_watchdog({"GDCA_SWEEP_DEBUG": "2", "GDCA_SWEEP_TIMEOUT_MS": "300"}, 3000)
+    assert out["status"] == "ehip" and "timed out" in out["msg"], out
+    assert out["seconds"] < 20.0, out
+    assert 0.0 < out["theta_after"] <= 0.5
