@@ -7,7 +7,9 @@
 //
 //   gdca_cli [options] alignment.fasta[.gz] [ranking.txt]
 //   gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K]
+//   gdca_cli [options] --batch DIR --parse-only [--parsers P]     (host side alone: read + filter + map, no GPU needed)
 //   gdca_cli --synth N M SEED out.fasta[.gz]
+// GDCA_VISIBLE_DEVICES=0,2,5 restricts (and orders) the HIP devices the batch mode uses.
 // options (names and defaults of src/GaussDCA.jl:10-15):
 //   --pseudocount X (0.8)  --theta auto|X (auto)  --max_gap_fraction X (0.9)  --score frob|DI (frob)
 //   --min_separation K (5)  --remove_dups
@@ -37,6 +39,7 @@ struct Options {
     bool remove_dups = false;
     std::string batch_dir, out_dir;
     int gpus = 0, parsers = 4, inflight = 2;
+    bool parse_only = false;
     std::vector<std::string> positional;
 };
 
@@ -186,6 +189,31 @@ struct Job {
     int64_t bytes = 0;
 };
 
+// GDCA_VISIBLE_DEVICES: comma-separated HIP device ids the batch mode may use, in that order; unset = all of them.
+// Ids outside 0..ndev-1 and repeats are an error (a typo must not silently shrink the job to fewer GPUs).
+std::vector<int> visible_devices(int ndev)
+{
+    std::vector<int> ids;
+    const char *env = getenv("GDCA_VISIBLE_DEVICES");
+    if (!env || !*env) {
+        for (int g = 0; g < ndev; ++g) ids.push_back(g);
+        return ids;
+    }
+    const std::string s = env;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        const size_t comma = std::min(s.find(',', pos), s.size());
+        const std::string tok = s.substr(pos, comma - pos);
+        char *end = nullptr;
+        const long v = strtol(tok.c_str(), &end, 10);
+        if (tok.empty() || *end != 0 || v < 0 || v >= ndev || std::find(ids.begin(), ids.end(), (int)v) != ids.end())
+            die("invalid GDCA_VISIBLE_DEVICES entry '" + tok + "' (" + std::to_string(ndev) + " HIP device(s) present)");
+        ids.push_back((int)v);
+        pos = comma + 1;
+    }
+    return ids;
+}
+
 int run_batch(const Options &o)
 {
     std::vector<Job> jobs;
@@ -208,11 +236,55 @@ int run_batch(const Options &o)
     if (jobs.empty()) die("no FASTA files in " + o.batch_dir);
     // big first; name breaks ties so that the order is a function of the directory contents alone
     std::sort(jobs.begin(), jobs.end(), [](const Job &a, const Job &b) { return a.bytes != b.bytes ? a.bytes > b.bytes : a.name < b.name; });
+    // several files are parsed at once: share the host threads between the parser threads instead of letting every
+    // gdca_fasta_open start 16 of its own
+    if (!getenv("GDCA_FASTA_THREADS")) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        setenv("GDCA_FASTA_THREADS", std::to_string(std::max(1u, std::min(16u, hw / (unsigned)std::max(1, o.parsers)))).c_str(), 1);
+    }
+    if (o.parse_only) {
+        // the host side of the batch alone: P parser threads over the whole directory (read, inflate, column filter, letter
+        // map, gap filter, optional duplicate removal), results dropped.  This is the rate the GPUs of a node have to be fed
+        // at: 8 GPUs x ~70 families/s need it to be several hundred families per second.
+        std::atomic<size_t> next{0}, fails{0};
+        std::atomic<long long> seqs{0}, cells{0};
+        const double t0 = now();
+        std::vector<std::thread> th;
+        for (int p = 0; p < std::max(1, o.parsers); ++p)
+            th.emplace_back([&] {
+                for (size_t idx; (idx = next++) < jobs.size();) {
+                    Family f;
+                    f.path = jobs[idx].path;
+                    f.name = jobs[idx].name;
+                    if (!load_family(o, f)) {
+                        fprintf(stderr, "ERROR: %s\n", f.error.c_str());
+                        ++fails;
+                        continue;
+                    }
+                    seqs += f.M;
+                    cells += (long long)f.M * f.N;
+                }
+            });
+        for (auto &t : th) t.join();
+        const double wall = now() - t0;
+        long long bytes = 0;
+        for (const Job &j : jobs) {
+            struct stat sb;
+            if (stat(j.path.c_str(), &sb) == 0) bytes += (long long)sb.st_size;
+        }
+        fprintf(stderr, "parse-only: %zu families (%lld sequences, %.1f MB on disk, %.1f M symbols kept) on %d parser thread(s) in "
+                        "%.3f s = %.1f families/s, %.1f MB/s (%zu failed)\n",
+                jobs.size(), seqs.load(), bytes / 1e6, cells.load() / 1e6, std::max(1, o.parsers), wall, jobs.size() / wall,
+                bytes / 1e6 / wall, fails.load());
+        return fails.load() ? 1 : 0;
+    }
     mkdir(o.out_dir.c_str(), 0777);
 
     const int ndev = gdca_device_count();
-    const int G = o.gpus > 0 ? std::min(o.gpus, ndev) : ndev;
-    if (G < 1) die("no HIP device (there is no CPU fallback)");
+    if (ndev < 1) die("no HIP device (there is no CPU fallback)");
+    std::vector<int> devs = visible_devices(ndev);
+    if (o.gpus > 0 && (size_t)o.gpus < devs.size()) devs.resize((size_t)o.gpus);
+    const int G = (int)devs.size();
 
     // parser threads fill a bounded queue of parsed families in job order; GPU workers pull from it
     std::mutex mu;
@@ -278,10 +350,10 @@ int run_batch(const Options &o)
     const double t0 = now();
     std::vector<double> busy((size_t)G, 0.0);
     std::vector<int> count((size_t)G, 0);
-    auto worker = [&](int g) {
+    auto worker = [&](int g) {  // g = slot in `devs`
         gdca_ctx *ctx = nullptr;
-        if (gdca_ctx_create(g, &ctx) != GDCA_OK) {
-            fprintf(stderr, "ERROR: cannot create a context on GPU %d\n", g);
+        if (gdca_ctx_create(devs[(size_t)g], &ctx) != GDCA_OK) {
+            fprintf(stderr, "ERROR: cannot create a context on GPU %d\n", devs[(size_t)g]);
             ++failures;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -322,7 +394,7 @@ int run_batch(const Options &o)
                 ++failures;
                 continue;
             }
-            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", g,
+            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", devs[(size_t)g],
                     f.name.c_str(), f.N, f.M, f.q, st.theta, st.Meff, f.parse_s, st.ms_total, dt);
             res.name = f.name;
             res.N = f.N;
@@ -353,7 +425,7 @@ int run_batch(const Options &o)
     if (abort_parsers) fprintf(stderr, "ERROR: no GPU worker could start; %zu families not processed\n", jobs.size());
     fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
             (double)jobs.size() / wall, failures.load());
-    for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", g, count[(size_t)g], busy[(size_t)g]);
+    for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", devs[(size_t)g], count[(size_t)g], busy[(size_t)g]);
     return failures.load() ? 1 : 0;
 }
 
@@ -386,6 +458,7 @@ int main(int argc, char **argv)
         else if (s == "--gpus") o.gpus = atoi(val());
         else if (s == "--parsers") o.parsers = atoi(val());
         else if (s == "--inflight") o.inflight = atoi(val());
+        else if (s == "--parse-only") o.parse_only = true;
         else if (s == "--synth") {
             if (a + 4 >= argc) die("usage: --synth N M SEED out.fasta[.gz]");
             const int N = atoi(argv[a + 1]), M = atoi(argv[a + 2]);
@@ -398,6 +471,7 @@ int main(int argc, char **argv)
             printf("usage: gdca_cli [--pseudocount X] [--theta auto|X] [--max_gap_fraction X] [--score frob|DI]\n"
                    "                [--min_separation K] [--remove_dups] alignment.fasta[.gz] [ranking.txt]\n"
                    "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K]\n"
+                   "       gdca_cli [options] --batch DIR --parse-only [--parsers P]\n"
                    "       gdca_cli --synth N M SEED out.fasta[.gz]\n");
             return 0;
         } else if (!s.empty() && s[0] == '-' && s.size() > 1) die("unknown option " + s);
@@ -405,7 +479,7 @@ int main(int argc, char **argv)
     }
     check_arguments(o);
     if (!o.batch_dir.empty()) {
-        if (o.out_dir.empty()) die("--batch needs --out OUTDIR");
+        if (o.out_dir.empty() && !o.parse_only) die("--batch needs --out OUTDIR");
         return run_batch(o);
     }
     if (o.positional.empty()) die("no alignment given (see --help)");

@@ -39,6 +39,28 @@ struct LetterMap {
 };
 const LetterMap kMap;
 
+// insert columns of an aligned FASTA record: '.' and lowercase letters (dropped by the reader)
+struct InsertMap {
+    uint8_t t[256];
+    InsertMap()
+    {
+        for (int i = 0; i < 256; ++i) t[i] = (i == '.' || (i >= 'a' && i <= 'z')) ? 1 : 0;
+    }
+};
+const InsertMap kIns;
+
+// threads one gdca_fasta_open call may use on a big file: GDCA_FASTA_THREADS, default min(16, hardware threads).  The batch
+// driver, which already parses several files at once, sets it to hardware threads / parser threads.
+int fasta_threads()
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char *e = getenv("GDCA_FASTA_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1) return std::min(v, 64);
+    }
+    return (int)std::min(16u, hw);
+}
+
 // whole file into memory; gzip (magic 1f 8b) through zlib, anything else with one read
 bool slurp(const char *path, std::string &out)
 {
@@ -153,7 +175,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     std::string text;
     if (!slurp(path, text)) return GDCA_EINVAL;
     const size_t L = text.size();
-    const int T = L < (1u << 20) ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const int T = L < (1u << 20) ? 1 : fasta_threads();
 
     // pass 1: header lines (first non-space character '>'), found per chunk of whole lines
     std::vector<size_t> cut((size_t)T + 1, L);
@@ -200,6 +222,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     h->Z.resize((size_t)n * R);
     std::vector<uint8_t> keep(R, 0);
     std::atomic<bool> misaligned{false};
+    const bool all_match = cols.size() == first.size();  // the first record has no insert columns (the usual case)
     // pass 2: records in parallel: letter map + gap-fraction filter, every record into its own row
     parallel(T, [&](int t) {
         std::string scratch;
@@ -209,6 +232,25 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
             if (sq.size() != first.size()) {
                 misaligned = true;  // "inputs are not aligned"
                 return;
+            }
+            int8_t *row = h->Z.data() + r * (size_t)n;
+            if (all_match) {
+                // one pass over the record: letter map, gap count, and "inconsistent inputs" = any insert character
+                unsigned ins = 0;
+                int ngaps = 0;
+                const unsigned char *q = (const unsigned char *)sq.data();
+                for (int32_t i = 0; i < n; ++i) {
+                    const unsigned char c = q[i];
+                    ins |= kIns.t[c];
+                    ngaps += (c == '-');
+                    row[i] = kMap.t[c];
+                }
+                if (ins) {
+                    misaligned = true;
+                    return;
+                }
+                keep[r] = (double)ngaps / (double)n <= max_gap_fraction;
+                continue;
             }
             // "inconsistent inputs": the match columns of every record (neither '.' nor lowercase) must be exactly
             // those of the first one
@@ -230,7 +272,6 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
                     return;
                 }
             }
-            int8_t *row = h->Z.data() + r * (size_t)n;
             int ngaps = 0;
             for (int32_t i = 0; i < n; ++i) {
                 const unsigned char c = (unsigned char)sq[cols[(size_t)i]];

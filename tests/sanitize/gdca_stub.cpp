@@ -1,0 +1,95 @@
+// TEST INFRASTRUCTURE, not a fallback: stand-ins for the GPU-side entry points of include/gdca.h that gdca_cli.cpp calls
+// (gdca_device_count, gdca_ctx_create / destroy, gdca_run, gdca_last_error), so that the HOST code of the product --
+// gdca_host.cpp (threaded FASTA reader, duplicate removal, ranking sort, writers) and gdca_cli.cpp (parser / worker / writer
+// queues of the batch mode) -- can run under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer on a machine
+// without a GPU (sanitizers on the CPU build only).  Linked ONLY into tests/_build/gdca_cli_{asan,tsan}
+// by `make -C gaussdca.jl_amd/csrc asan tsan`; libgdca.so never contains it, and the scores it returns are not gDCA scores:
+// a cheap deterministic function of the alignment (fraction of sequences in which two columns agree) that reads every byte
+// of Z and writes every entry of S, which is what the sanitizers need.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gdca.h"
+
+struct gdca_ctx {
+    int device;
+    char err[128];
+};
+
+static std::atomic<int> g_live_contexts{0};
+
+extern "C" {
+
+int32_t gdca_device_count(void)
+{
+    const char *e = getenv("GDCA_STUB_DEVICES");  // how many "GPUs" the batch driver sees
+    return e ? atoi(e) : 1;
+}
+
+gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
+{
+    if (!out) return GDCA_EINVAL;
+    *out = nullptr;
+    if (device_id < 0 || device_id >= gdca_device_count()) return GDCA_EINVAL;
+    if (const char *bad = getenv("GDCA_STUB_FAIL_DEVICE"))  // this device cannot be opened (worker start-up failure path)
+        if (atoi(bad) == device_id) return GDCA_EHIP;
+    gdca_ctx *c = (gdca_ctx *)calloc(1, sizeof(gdca_ctx));
+    if (!c) return GDCA_ENOMEM;
+    c->device = device_id;
+    ++g_live_contexts;
+    *out = c;
+    return GDCA_OK;
+}
+
+gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
+{
+    if (!ctx) return GDCA_EINVAL;
+    --g_live_contexts;
+    free(ctx);
+    return GDCA_OK;
+}
+
+const char *gdca_last_error(gdca_ctx *ctx)
+{
+    return ctx ? ctx->err : "null context";
+}
+
+gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const gdca_params *p, double *S,
+                     gdca_stats *st)
+{
+    if (!ctx || !Z || !S || !p || N < 1 || M < 1 || q < 2 || q > 31) return GDCA_EINVAL;
+    if (p->pseudocount == 0.0) {  // the CLI's PosDefException path
+        if (st) {
+            memset(st, 0, sizeof(*st));
+            st->info = 1;
+        }
+        snprintf(ctx->err, sizeof ctx->err, "stub: not positive definite");
+        return GDCA_ENOTPD;
+    }
+    for (int32_t i = 0; i < N; ++i)
+        for (int32_t j = i; j < N; ++j) {
+            long same = 0;
+            for (int32_t k = 0; k < M; ++k) {
+                const int8_t a = Z[(size_t)k * N + i], b = Z[(size_t)k * N + j];
+                if (a < 1 || a > q || b < 1 || b > q) return GDCA_EINVAL;
+                same += (a == b);
+            }
+            const double v = i == j ? 0.0 : (double)same / (double)M + 1e-3 * ((i * 31 + j * 17) % 97);
+            S[(size_t)i + (size_t)j * N] = v;
+            S[(size_t)j + (size_t)i * N] = v;
+        }
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->theta = 0.25;
+        st->Meff = M;
+        st->N = N;
+        st->M = M;
+        st->q = q;
+        st->n = N * (q - 1);
+    }
+    return GDCA_OK;
+}
+
+}  // extern "C"
