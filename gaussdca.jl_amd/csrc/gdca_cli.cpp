@@ -38,7 +38,7 @@ struct Options {
     int score = GDCA_SCORE_FROB, min_separation = 5;
     bool remove_dups = false;
     std::string batch_dir, out_dir;
-    int gpus = 0, parsers = 4, inflight = 2;
+    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2;
     bool parse_only = false;
     std::vector<std::string> positional;
 };
@@ -79,34 +79,58 @@ void check_arguments(const Options &o)
 struct Family {
     std::string path, name;
     int32_t N = 0, M = 0, q = 0;
-    std::vector<int8_t> Z;  // [M][N]
+    gdca_fasta *h = nullptr;  // the parsed alignment, used where the reader left it ...
+    std::vector<int8_t> Zown; // ... unless duplicate removal rewrote it: [M][N]
     double parse_s = 0;
     std::string error;
+    const int8_t *Z() const { return Zown.empty() ? gdca_fasta_data(h) : Zown.data(); }
+    Family() = default;
+    Family(const Family &) = delete;
+    Family &operator=(const Family &) = delete;
+    Family(Family &&o) noexcept { *this = std::move(o); }
+    Family &operator=(Family &&o) noexcept
+    {
+        if (this != &o) {
+            if (h) gdca_fasta_close(h);
+            path = std::move(o.path);
+            name = std::move(o.name);
+            N = o.N, M = o.M, q = o.q, parse_s = o.parse_s;
+            h = o.h;
+            o.h = nullptr;
+            Zown = std::move(o.Zown);
+            error = std::move(o.error);
+        }
+        return *this;
+    }
+    ~Family()
+    {
+        if (h) gdca_fasta_close(h);
+    }
 };
 
 // src/GaussDCA.jl:20-26: read + filter, optional duplicate removal, q = maximum(Z), q < 32
 bool load_family(const Options &o, Family &f)
 {
     const double t0 = now();
-    gdca_fasta *h = nullptr;
-    if (gdca_fasta_open(f.path.c_str(), o.max_gap_fraction, &h, &f.N, &f.M) != GDCA_OK) {
+    if (gdca_fasta_open(f.path.c_str(), o.max_gap_fraction, &f.h, &f.N, &f.M) != GDCA_OK) {
         f.error = "cannot read alignment " + f.path;
         return false;
     }
-    f.Z.resize((size_t)f.N * f.M);
-    gdca_fasta_copy(h, f.Z.data());
-    gdca_fasta_close(h);
+    int q = gdca_fasta_max_symbol(f.h);  // q = maximum(Z) (src/GaussDCA.jl:25), found by the reader's threads
     if (o.remove_dups) {
+        f.Zown.resize((size_t)f.N * std::max(f.M, 1));
         int32_t m = 0;
-        if (gdca_remove_duplicates(f.Z.data(), f.N, f.M, f.Z.data(), nullptr, &m) != GDCA_OK) {
+        if (gdca_remove_duplicates(gdca_fasta_data(f.h), f.N, f.M, f.Zown.data(), nullptr, &m) != GDCA_OK) {
             f.error = "duplicate removal failed for " + f.path;
             return false;
         }
         f.M = m;
-        f.Z.resize((size_t)f.N * f.M);
+        f.Zown.resize((size_t)f.N * std::max(f.M, 1));
+        gdca_fasta_close(f.h);
+        f.h = nullptr;
+        q = 0;
+        for (size_t x = 0; x < (size_t)f.N * f.M; ++x) q = std::max(q, (int)f.Zown[x]);
     }
-    int q = 0;
-    for (int8_t a : f.Z) q = std::max(q, (int)a);
     f.q = q;
     f.parse_s = now() - t0;
     if (f.M < 1) {
@@ -125,7 +149,7 @@ bool compute(gdca_ctx *ctx, const Options &o, const Family &f, std::vector<doubl
 {
     S.resize((size_t)f.N * f.N);
     gdca_params p{o.pseudocount, o.theta, o.score, 1};
-    const gdca_status rc = gdca_run(ctx, f.Z.data(), f.N, f.M, f.q, &p, S.data(), st);
+    const gdca_status rc = gdca_run(ctx, f.Z(), f.N, f.M, f.q, &p, S.data(), st);
     if (rc == GDCA_ENOTPD) {
         *err = "PosDefException: matrix is not positive definite; Cholesky factorization failed (info " +
                std::to_string(st->info) + ")";
@@ -238,9 +262,12 @@ int run_batch(const Options &o)
     std::sort(jobs.begin(), jobs.end(), [](const Job &a, const Job &b) { return a.bytes != b.bytes ? a.bytes > b.bytes : a.name < b.name; });
     // several files are parsed at once: share the host threads between the parser threads instead of letting every
     // gdca_fasta_open start 16 of its own
+    // (measured on the 256-thread host of the GPU box, tools/parse_bench.sh: with 8 or more files in flight nested threads only
+    // add contention in the kernel's memory-map lock -- 946 families/s with one thread per file against 497 with eight)
     if (!getenv("GDCA_FASTA_THREADS")) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        setenv("GDCA_FASTA_THREADS", std::to_string(std::max(1u, std::min(16u, hw / (unsigned)std::max(1, o.parsers)))).c_str(), 1);
+        const unsigned per_file = o.parsers >= 8 ? 1u : std::max(1u, std::min(16u, hw / (unsigned)std::max(1, o.parsers)));
+        setenv("GDCA_FASTA_THREADS", std::to_string(per_file).c_str(), 1);
     }
     if (o.parse_only) {
         // the host side of the batch alone: P parser threads over the whole directory (read, inflate, column filter, letter
@@ -478,6 +505,7 @@ int main(int argc, char **argv)
         else o.positional.push_back(s);
     }
     check_arguments(o);
+    if (o.parsers <= 0) o.parsers = (int)std::min(32u, std::max(4u, std::thread::hardware_concurrency() / 8u));
     if (!o.batch_dir.empty()) {
         if (o.out_dir.empty() && !o.parse_only) die("--batch needs --out OUTDIR");
         return run_batch(o);

@@ -6,23 +6,75 @@
 // end-to-end gDCA(filename) spends its time on the GPU, not in an interpreter loop.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <string_view>
 #include <thread>
+#include <type_traits>
 #include <unordered_set>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "gdca.h"
 
+// a byte buffer that is NOT zero-filled when it grows (the reader overwrites every byte it keeps; zero-filling 50 MB per
+// family is a serial 10 ms the batch driver's parser threads can do without)
+// Big buffers come 2 MiB-aligned with a transparent-huge-page hint: a fresh 50 MB matrix is 25 page faults instead of
+// 12 000, which is what the batch driver's parser threads were queueing up on in the kernel.
+template <class Tp>
+struct default_init_alloc {
+    using value_type = Tp;
+    template <class U>
+    struct rebind {
+        using other = default_init_alloc<U>;
+    };
+    default_init_alloc() = default;
+    template <class U>
+    default_init_alloc(const default_init_alloc<U> &) noexcept {}
+    Tp *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(Tp);
+        if (bytes >= ((size_t)4 << 20)) {
+            void *q = nullptr;
+            const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign(&q, (size_t)2 << 20, len) != 0) throw std::bad_alloc();
+            (void)madvise(q, len, MADV_HUGEPAGE);
+            return static_cast<Tp *>(q);
+        }
+        void *q = malloc(bytes ? bytes : 1);
+        if (!q) throw std::bad_alloc();
+        return static_cast<Tp *>(q);
+    }
+    void deallocate(Tp *q, size_t) noexcept { free(q); }
+    template <class U>
+    bool operator==(const default_init_alloc<U> &) const noexcept { return true; }
+    template <class U>
+    bool operator!=(const default_init_alloc<U> &) const noexcept { return false; }
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+
 struct gdca_fasta {
-    int32_t N = 0, M = 0;
-    std::vector<int8_t> Z;  // [M][N]
+    int32_t N = 0, M = 0, qmax = 0;
+    std::vector<int8_t, default_init_alloc<int8_t>> Z;  // [M][N]
 };
 
 namespace {
@@ -61,46 +113,68 @@ int fasta_threads()
     return (int)std::min(16u, hw);
 }
 
-// whole file into memory; gzip (magic 1f 8b) through zlib, anything else with one read
-bool slurp(const char *path, std::string &out)
+// The text of a file: a plain file is mapped (parsed where the page cache holds it: no copy, no buffer to fault in), a gzip
+// file (magic 1f 8b) is inflated into a buffer the calling thread keeps between calls (a parser thread of the batch driver
+// inflates hundreds of files: the buffer's pages are faulted in once).
+struct FileText {
+    std::string_view text;
+    void *map = nullptr;
+    size_t maplen = 0;
+    ~FileText()
+    {
+        if (map) munmap(map, maplen);
+    }
+};
+
+std::string &inflate_buffer()
 {
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return false;
+    static thread_local std::string buf;
+    return buf;
+}
+
+bool slurp(const char *path, FileText &out)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fd);
+        return false;
+    }
+    const size_t fsz = (size_t)sb.st_size;
     unsigned char magic[2] = {0, 0};
-    const size_t got = fread(magic, 1, 2, fp);
-    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    const bool gz = fsz >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (!gz) {
-        if (fseek(fp, 0, SEEK_END) != 0) {
-            fclose(fp);
-            return false;
+        if (fsz == 0) {
+            close(fd);
+            out.text = std::string_view();
+            return true;
         }
-        const long sz = ftell(fp);
-        if (sz < 0) {
-            fclose(fp);
-            return false;
-        }
-        rewind(fp);
-        out.resize((size_t)sz);
-        const size_t n = sz ? fread(&out[0], 1, (size_t)sz, fp) : 0;
-        fclose(fp);
-        return n == (size_t)sz;
+        void *m = mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return false;
+        (void)madvise(m, fsz, MADV_SEQUENTIAL);
+        out.map = m;
+        out.maplen = fsz;
+        out.text = std::string_view((const char *)m, fsz);
+        return true;
     }
     // gzip: the trailer's ISIZE (uncompressed size mod 2^32) sizes the buffer up front
     size_t hint = 0;
-    if (fseek(fp, -4, SEEK_END) == 0) {
-        unsigned char t[4];
-        if (fread(t, 1, 4, fp) == 4) hint = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-    }
-    fclose(fp);
+    unsigned char t[4];
+    if (fsz >= 4 && pread(fd, t, 4, (off_t)fsz - 4) == 4) hint = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    close(fd);
     gzFile f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
-    out.resize(std::max<size_t>(hint, 1 << 16));
+    std::string &buf = inflate_buffer();
+    if (buf.capacity() > ((size_t)1 << 30) && hint < ((size_t)1 << 28)) std::string().swap(buf);  // do not sit on a huge one
+    if (buf.size() < std::max<size_t>(hint, 1 << 16)) buf.resize(std::max<size_t>(hint, 1 << 16));
     size_t len = 0;
     for (;;) {
-        if (len == out.size()) out.resize(out.size() * 2);
-        const unsigned want = (unsigned)std::min<size_t>(out.size() - len, 1u << 30);
-        const int n = gzread(f, &out[len], want);
+        if (len == buf.size()) buf.resize(buf.size() * 2);
+        const unsigned want = (unsigned)std::min<size_t>(buf.size() - len, 1u << 30);
+        const int n = gzread(f, &buf[len], want);
         if (n < 0) {
             gzclose(f);
             return false;
@@ -109,7 +183,7 @@ bool slurp(const char *path, std::string &out)
         len += (size_t)n;
     }
     gzclose(f);
-    out.resize(len);
+    out.text = std::string_view(buf.data(), len);
     return true;
 }
 
@@ -139,7 +213,7 @@ void parallel(int T, F fn)
 
 // the stripped non-empty lines of text[a, b), concatenated (what the reference's reader hands back as one
 // sequence); `single` is set when the body is exactly one line, in which case nothing is copied
-std::string_view body_sequence(const std::string &text, Span body, std::string &scratch)
+std::string_view body_sequence(std::string_view text, Span body, std::string &scratch)
 {
     std::string_view first;
     int pieces = 0;
@@ -155,7 +229,7 @@ std::string_view body_sequence(const std::string &text, Span body, std::string &
                 first = std::string_view(text.data() + a, b - a);
             } else {
                 if (pieces == 1) scratch.assign(first.data(), first.size());
-                scratch.append(text, a, b - a);
+                scratch.append(text.data() + a, b - a);
             }
             ++pieces;
         }
@@ -172,8 +246,14 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
 {
     if (!path || !out || !N || !M) return GDCA_EINVAL;
     *out = nullptr;
-    std::string text;
-    if (!slurp(path, text)) return GDCA_EINVAL;
+    // GDCA_FASTA_TRACE=1: per-file phase times on stderr (debug aid for the feed-rate benchmark, tools/parse_bench.sh)
+    static const bool trace = getenv("GDCA_FASTA_TRACE") != nullptr;
+    auto tick = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_open = trace ? tick() : 0.0;
+    FileText file;
+    if (!slurp(path, file)) return GDCA_EINVAL;
+    const double t_read = trace ? tick() : 0.0;
+    const std::string_view text = file.text;
     const size_t L = text.size();
     const int T = L < (1u << 20) ? 1 : fasta_threads();
 
@@ -221,6 +301,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     h->N = n;
     h->Z.resize((size_t)n * R);
     std::vector<uint8_t> keep(R, 0);
+    std::vector<int> qmax_t((size_t)T, 0);  // largest symbol among the rows each thread keeps
     std::atomic<bool> misaligned{false};
     const bool all_match = cols.size() == first.size();  // the first record has no insert columns (the usual case)
     // pass 2: records in parallel: letter map + gap-fraction filter, every record into its own row
@@ -250,6 +331,11 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
                     return;
                 }
                 keep[r] = (double)ngaps / (double)n <= max_gap_fraction;
+                if (keep[r]) {
+                    int8_t mx = 0;
+                    for (int32_t i = 0; i < n; ++i) mx = std::max(mx, row[i]);
+                    qmax_t[(size_t)t] = std::max(qmax_t[(size_t)t], (int)mx);
+                }
                 continue;
             }
             // "inconsistent inputs": the match columns of every record (neither '.' nor lowercase) must be exactly
@@ -279,6 +365,8 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
                 row[i] = kMap.t[c];
             }
             keep[r] = (double)ngaps / (double)n <= max_gap_fraction;
+            if (keep[r])
+                for (int32_t i = 0; i < n; ++i) qmax_t[(size_t)t] = std::max(qmax_t[(size_t)t], (int)row[i]);
         }
     });
     if (misaligned) {
@@ -293,6 +381,9 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
             ++m;
         }
     h->M = (int32_t)m;
+    for (int v : qmax_t) h->qmax = std::max(h->qmax, (int32_t)v);
+    if (trace)
+        fprintf(stderr, "fasta-trace %s bytes %zu threads %d read/inflate %.2f ms parse %.2f ms\n", path, L, T, t_read - t_open, tick() - t_read);
     h->Z.resize(m * (size_t)n);
     *out = h;
     *N = h->N;
@@ -305,6 +396,16 @@ gdca_status gdca_fasta_copy(const gdca_fasta *h, int8_t *Z)
     if (!h || !Z) return GDCA_EINVAL;
     if (!h->Z.empty()) memcpy(Z, h->Z.data(), h->Z.size());
     return GDCA_OK;
+}
+
+const int8_t *gdca_fasta_data(const gdca_fasta *h)
+{
+    return h ? h->Z.data() : nullptr;
+}
+
+int32_t gdca_fasta_max_symbol(const gdca_fasta *h)
+{
+    return h ? h->qmax : 0;
 }
 
 gdca_status gdca_fasta_close(gdca_fasta *h)

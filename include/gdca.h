@@ -203,6 +203,10 @@ typedef struct gdca_fasta gdca_fasta;
  * open: parse, report N and M;  copy: fill the caller's N x M int8 matrix;  close: free the handle. */
 gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fasta **out, int32_t *N, int32_t *M);
 gdca_status gdca_fasta_copy(const gdca_fasta *h, int8_t *Z);
+/* The parsed matrix in place (N x M column-major, valid until gdca_fasta_close; for callers that hand it straight to
+ * gdca_run instead of copying it into an array of their own) and its largest symbol, q = maximum(Z) (src/GaussDCA.jl:25). */
+const int8_t *gdca_fasta_data(const gdca_fasta *h);
+int32_t gdca_fasta_max_symbol(const gdca_fasta *h);
 gdca_status gdca_fasta_close(gdca_fasta *h);
 /* DCAUtils.remove_duplicate_sequences(Z) (:21-23): first occurrences, order kept.  Z_out may alias Z.
  * keep_idx (optional, M entries): 1-based indices kept. */
