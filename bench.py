@@ -294,6 +294,10 @@ def main():
                          "reweighting/tallies (VALU, LDS) overlap family f's SPD inverse (MFMA); 1 = strictly serial")
     ap.add_argument("--gate", action="store_true",
                     help="with --pipeline > 1: let the SPD-inverse stages of the families in flight take turns")
+    ap.add_argument("--phased", action="store_true",
+                    help="with --pipeline K: batch the K families in flight BY PHASE on one stream (gdca_run_dev_phased): K front "
+                         "ends, then K SPD inverses back to back, then K score stages -- the matrix pipes see one load step per "
+                         "K families instead of one per family (throughput form; --pipeline 1 stays the latency headline)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"B": 40, "C": 40, "D": 10, "E": 2}[args.config]
@@ -375,9 +379,22 @@ def main():
         ctxs.append(ctxs[0].peer() if args.gate else g.Context(local))
     busy = [False] * P
 
+    def run_steps_phased(count, sink):
+        """`count` steps, the rank's families taken P at a time and batched by phase (gdca_run_dev_phased)."""
+        work = [fi for _ in range(count) for fi in range(len(fams))]
+        for a in range(0, len(work), P):
+            grp = work[a:a + P]
+            g.run_dev_phased(ctxs[:len(grp)], [Zd[fi].data_ptr() for fi in grp], [fams[fi][1] for fi in grp],
+                             [fams[fi][2] for fi in grp], [q] * len(grp), pc, cfg["theta"], score,
+                             [Sd[c].data_ptr() for c in range(len(grp))])
+            for c in range(len(grp)):
+                sink.append(ctxs[c].collect())
+
     def run_steps(count, sink):
         """`count` steps; inside a step the rank's families go round-robin over the P contexts; a context's previous
         pass is collected (stream sync + stats) right before it is given the next one."""
+        if args.phased and P > 1:
+            return run_steps_phased(count, sink)
         t = 0
         for _ in range(count):
             for fi, (_, N, M, _) in enumerate(fams):
@@ -455,7 +472,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl, "name": args.config, "q": q,
                        "families_per_step": nfam // K, "families_per_step_rank0": len(fams),
-                       "families_in_flight_per_gpu": P},
+                       "families_in_flight_per_gpu": P,
+                       "schedule": ("phase-batched: %d front ends, %d inverses back to back, %d score stages" % (P, P, P))
+                       if (args.phased and P > 1) else ("one family after the other" if P == 1 else "independent streams")},
             "sec_per_family": dt / (nfam / world) if args.config != "E" else dt / nfam,
             "aggregate_inverse_tflops": flops / dt / 1e12,
             "latency_ms_per_family": float(np.mean([s["ms_total"] for s in stats])),

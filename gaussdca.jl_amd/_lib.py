@@ -79,6 +79,8 @@ SYMBOLS = {
                                C.POINTER(Stats)]),
     "gdca_run_dev_async": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p]),
     "gdca_run_collect": (C.c_int, [_ctx, C.POINTER(Stats)]),
+    "gdca_run_dev_phased": (C.c_int, [C.POINTER(_ctx), C.c_int32, C.POINTER(C.c_void_p), _i32p, _i32p, _i32p, C.POINTER(Params),
+                                      C.POINTER(C.c_void_p)]),
     "gdca_dbuf_alloc": (C.c_int, [_ctx, C.c_uint64, C.POINTER(C.c_void_p)]),
     "gdca_dbuf_free": (C.c_int, [C.c_void_p]),
     "gdca_dbuf_ptr": (C.c_void_p, [C.c_void_p]),
@@ -241,6 +243,19 @@ class Context:
         rc = self.lib.gdca_run_collect(self.h, C.byref(st))
         self.check(rc, st.info)
         return st.as_dict()
+
+
+def run_dev_phased(ctxs, Z_ptrs, Ns, Ms, qs, pseudocount: float, theta: float, score: int, S_ptrs, apc: bool = True):
+    """K families batched by phase on one GPU (gdca_run_dev_phased): K front ends, K inverses back to back, K score
+    stages.  Enqueues only; collect() every context afterwards."""
+    K = len(ctxs)
+    assert K >= 1 and len(Z_ptrs) == len(Ns) == len(Ms) == len(qs) == len(S_ptrs) == K
+    prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+    hs = (_ctx * K)(*[c.h for c in ctxs])
+    zp = (C.c_void_p * K)(*[C.c_void_p(int(z)) for z in Z_ptrs])
+    sp = (C.c_void_p * K)(*[C.c_void_p(int(x)) for x in S_ptrs])
+    i32 = lambda v: (C.c_int32 * K)(*[int(x) for x in v])  # noqa: E731
+    ctxs[0].check(ctxs[0].lib.gdca_run_dev_phased(hs, K, zp, i32(Ns), i32(Ms), i32(qs), C.byref(prm), sp))
 
 
 class DeviceBuffer:

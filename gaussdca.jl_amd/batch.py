@@ -3,21 +3,26 @@ process (one gdca context) per GPU, no collective on the data path (SURVEY.md 8e
 
 Every rank computes the same deterministic assignment from the (N, M) sizes alone, so no
 communication is needed to agree on it: longest-processing-time-first over the cost model
-    c = alpha (N (q-1))^3 + beta M^2 N + gamma N^2 M
-(SPD inverse + all-pairs Hamming + pair tallies), ties broken by family index.
+    c = max(alpha (N (q-1))^3, chain * blocks) + beta M^2 N + gamma N^2 M
+(SPD inverse, bound below by its pivot chain, + all-pairs Hamming + pair tallies; seconds), ties broken by family index.
 """
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
-# relative weights fitted to the MI355X stage times at N=500, M=50k, q=21 (DESIGN.md):
-# inverse 24.8 ms / 1e12, Hamming 3.4 ms / 1.25e12, tallies 5.9 ms / 1.25e10
-ALPHA, BETA, GAMMA = 24.8e-12, 2.7e-12, 4.7e-10
+# seconds, fitted to the round-3 MI355X stage times (profiles/r03_bench_*.json):
+#   SPD inverse   17.5 ms at n = 10 000 (config C), 123 ms at n = 20 000 (D)  ->  ALPHA n^3, but never less than the pivot
+#                 chain, CHAIN seconds per 128-block (config B: 20 blocks, 1.87 ms: small matrices are bound by that chain)
+#   reweighting   3.2 ms at M^2 N = 1.25e12 (C), 24.7 ms at 1e13 (D)           ->  BETA M^2 N
+#   tallies + covariance  3.3 ms at N^2 M = 1.25e10 (C), 21 ms at 1e11 (D)     ->  GAMMA N^2 M
+ALPHA, BETA, GAMMA, CHAIN = 17.0e-15, 2.5e-15, 2.4e-13, 94e-6
 
 
 def family_cost(N: int, M: int, q: int = 21) -> float:
+    """Estimated device seconds of one family (the LPT weights; only their ratios matter for the sharding)."""
     n = N * (q - 1)
-    return ALPHA * n ** 3 + BETA * float(M) * M * N + GAMMA * float(N) * N * M
+    inverse = max(ALPHA * float(n) ** 3, CHAIN * -(-n // 128))
+    return inverse + BETA * float(M) * M * N + GAMMA * float(N) * N * M
 
 
 def shard_families(sizes: Sequence[Tuple[int, int]], world: int, q: int = 21) -> List[List[int]]:

@@ -43,7 +43,7 @@ struct gdca_ctx {
     int n_ev;
     // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
     bool meff_pending;  // k_meff enqueued on the side stream, not yet joined
-    hipEvent_t ev_weights, ev_meff;
+    hipEvent_t ev_weights, ev_meff, ev_batch;
     bool pending;
     bool pend_timed;
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
@@ -138,7 +138,8 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
         return GDCA_EHIP;
     }
     if (hipEventCreateWithFlags(&ctx->ev_weights, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess) {
         gdca_ctx_destroy(ctx);
         return GDCA_EHIP;
     }
@@ -208,6 +209,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->item0_host) (void)hipHostFree(ctx->item0_host);
     if (ctx->ev_weights) (void)hipEventDestroy(ctx->ev_weights);
     if (ctx->ev_meff) (void)hipEventDestroy(ctx->ev_meff);
+    if (ctx->ev_batch) (void)hipEventDestroy(ctx->ev_batch);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
@@ -491,8 +493,12 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     return GDCA_OK;
 }
 
-gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
-                               const gdca_params *p, double *S_dev)
+}  // extern "C"
+
+// The three phases of one run, enqueued on `s` (the ctx's own stream, or the leader's when several families are batched by
+// phase): front end (theta, reweighting, tallies, covariance), SPD inverse, scores.
+static gdca_status run_check_args(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                                  double *S_dev)
 {
     CHK(validate(ctx, N, M, q));
     if (!Z_dev || !S_dev || !p) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
@@ -501,11 +507,16 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     if (!(p->theta <= 1.0)) return fail(ctx, GDCA_EINVAL, "invalid theta value%s%s", "", "");
     if (p->score != GDCA_SCORE_FROB && p->score != GDCA_SCORE_DI)
         return fail(ctx, GDCA_EINVAL, "invalid score value%s%s", "", "");
+    return GDCA_OK;
+}
+
+static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p)
+{
     CHK(begin(ctx));  // (one run may be outstanding per ctx: its scalars and events would be overwritten -> GDCA_EINVAL)
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
     const bool timed = ctx->timing;
-    if (timed) CHK(need_events(ctx, 16));
+    if (timed) CHK(need_events(ctx, 18));
     hipEvent_t *ev = ctx->ev;
     gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
 
@@ -524,12 +535,25 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     }
     CHK(check_launch(ctx, "covariance"));
     if (timed) HIPCHK(hipEventRecord(ev[3], s));
+    ctx->pend_timed = timed;
+    ctx->pend_N = N;
+    ctx->pend_M = M;
+    ctx->pend_q = q;
+    ctx->pend_n = n;
+    ctx->pend_npad = n_pad;
+    return GDCA_OK;
+}
 
+static gdca_status run_inverse(gdca_ctx *ctx)
+{
+    hipStream_t s = ctx->stream;
+    const bool timed = ctx->pend_timed;
+    hipEvent_t *ev = ctx->ev;
     int n_upd = 0;
     double upd_flops = 0.0;
     if (ctx->gate && ctx->gate->armed) HIPCHK(hipStreamWaitEvent(s, ctx->gate->ev[ctx->gate->last], 0));
     if (timed) HIPCHK(hipEventRecord(ev[6], s));  // start of this family's turn on the MFMA pipe
-    CHK(inverse_stage(ctx, n, n_pad, timed, &n_upd, &upd_flops));
+    CHK(inverse_stage(ctx, ctx->pend_n, ctx->pend_npad, timed, &n_upd, &upd_flops));
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
     if (ctx->gate) {
         gdca_gate *g = ctx->gate;
@@ -538,20 +562,78 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
         g->next = (g->next + 1) & 3;
         g->armed = 1;
     }
-
-    CHK(score_stage(ctx, N, sdim, n_pad, p->score, p->apc, S_dev));
-    if (timed) HIPCHK(hipEventRecord(ev[5], s));
-
-    ctx->pending = true;
-    ctx->pend_timed = timed;
-    ctx->pend_N = N;
-    ctx->pend_M = M;
-    ctx->pend_q = q;
-    ctx->pend_n = n;
-    ctx->pend_npad = n_pad;
     ctx->pend_nupd = n_upd;
     ctx->pend_upd_flops = upd_flops;
     return GDCA_OK;
+}
+
+static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
+{
+    CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev));
+    if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->pending = true;
+    return GDCA_OK;
+}
+
+extern "C" {
+
+gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
+                               const gdca_params *p, double *S_dev)
+{
+    CHK(run_check_args(ctx, Z_dev, N, M, q, p, S_dev));
+    CHK(run_front(ctx, Z_dev, N, M, q, p));
+    CHK(run_inverse(ctx));
+    return run_score(ctx, p, S_dev);
+}
+
+gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_dev, const int32_t *N,
+                                const int32_t *M, const int32_t *q, const gdca_params *p, double *const *S_dev)
+{
+    if (!ctxs || K < 1 || !Z_dev || !N || !M || !q || !p || !S_dev) return GDCA_EINVAL;
+    gdca_ctx *lead = ctxs[0];
+    if (!lead) return GDCA_EINVAL;
+    for (int k = 0; k < K; ++k) {
+        if (!ctxs[k]) return fail(lead, GDCA_EINVAL, "null context in the batch%s%s", "", "");
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(lead, GDCA_EINVAL, "the same context twice in one batch%s%s", "", "");
+        if (ctxs[k]->device != lead->device) return fail(lead, GDCA_EINVAL, "contexts of one batch must share a device%s%s", "", "");
+        CHK(not_pending(ctxs[k]));
+        CHK(run_check_args(ctxs[k], Z_dev[k], N[k], M[k], q[k], p, S_dev[k]));
+    }
+    // everything goes to the leader's stream, phase by phase: K front ends, K inverses back to back, K score stages.  The
+    // members keep their own workspaces, scalars and timing events; their streams are restored before returning.
+    hipStream_t own[64];
+    if (K > 64) return fail(lead, GDCA_EINVAL, "at most 64 families per batch%s%s", "", "");
+    for (int k = 0; k < K; ++k) {
+        own[k] = ctxs[k]->stream;
+        if (k > 0) (void)hipStreamSynchronize(own[k]);  // nothing of an earlier use is still in flight on the member's own stream
+        ctxs[k]->stream = lead->stream;
+    }
+    gdca_status st = GDCA_OK;
+    int done_front = 0;
+    for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
+        if (st == GDCA_OK) ++done_front;
+    }
+    for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_inverse(ctxs[k]);
+    for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
+    if (st != GDCA_OK) {
+        // a member failed to enqueue (allocation, launch): drain what was enqueued and leave nobody half-pending
+        (void)hipStreamSynchronize(lead->stream);
+        for (int k = 0; k < K; ++k) {
+            ctxs[k]->pending = false;
+            ctxs[k]->meff_pending = false;
+        }
+    }
+    for (int k = 0; k < K; ++k) ctxs[k]->stream = own[k];
+    // the members' collects synchronise THEIR stream: make it wait for the leader's (one event per member)
+    if (st == GDCA_OK)
+        for (int k = 1; k < K; ++k) {
+            if (hipEventRecord(ctxs[k]->ev_batch, lead->stream) != hipSuccess ||
+                hipStreamWaitEvent(own[k], ctxs[k]->ev_batch, 0) != hipSuccess)
+                return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
+        }
+    return st;
 }
 
 gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,

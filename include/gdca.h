@@ -123,6 +123,16 @@ gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t 
 gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q,
                                const gdca_params *p, double *S_dev);
 gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st);
+/* K independent families batched BY PHASE on one GPU (throughput form of the same path; the reference's only statement on
+ * parallelism is "independent families", README.md:92-94): the K front ends (theta, reweighting, tallies, covariance), then
+ * the K SPD inverses back to back, then the K score stages, all on the stream of ctxs[0].  The matrix pipes see one
+ * uninterrupted stretch of MFMA work per batch instead of K load steps (the clock governor answers every step from the
+ * front end's VALU/LDS work to the inverse with a dip that costs ~10 % of an inverse at n = 10 000), and results are bit for
+ * bit those of K single runs.  K distinct contexts of one device (each keeps its own workspace: K covariance matrices
+ * live at once), none with a run outstanding; arrays of K entries; one parameter set.  Enqueues only: collect every
+ * member with gdca_run_collect (any order).  K <= 64. */
+gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_dev, const int32_t *N,
+                                const int32_t *M, const int32_t *q, const gdca_params *p, double *const *S_dev);
 
 /* ---- device buffers ---------------------------------------------------------------------- */
 /* For callers without a GPU array type of their own (the Julia shim): an owned allocation in the HBM of ctx's

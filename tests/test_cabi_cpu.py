@@ -63,9 +63,9 @@ _JL_SIZES = {"Cdouble": 8, "Float64": 8, "UInt64": 8, "Int64": 8, "Int32": 4, "U
 
 
 def _julia_struct(name):
-    """Field list of `struct name ... end` in julia/GaussDCAHip.jl with the offsets Julia's C-compatible
+    """Field list of `struct name ... end` in julia/src/GaussDCAHip.jl with the offsets Julia's C-compatible
     layout gives it (natural alignment, declaration order)."""
-    src = open(os.path.join(ROOT, "julia", "GaussDCAHip.jl")).read()
+    src = open(os.path.join(ROOT, "julia", "src", "GaussDCAHip.jl")).read()
     body = re.search(r"struct\s+" + name + r"\b(.*?)\n\s*end", src, flags=re.S).group(1)
     body = re.sub(r"#.*", "", body)
     fields, off = [], 0
@@ -96,9 +96,110 @@ def test_struct_layouts_agree_across_c_ctypes_and_julia(tmp_path):
     codes = {f: off for f, off, _ in lay["status"]}
     assert codes == dict(GDCA_OK=_lib.GDCA_OK, GDCA_EINVAL=_lib.GDCA_EINVAL, GDCA_ENOTPD=_lib.GDCA_ENOTPD,
                          GDCA_EHIP=_lib.GDCA_EHIP, GDCA_ENOMEM=_lib.GDCA_ENOMEM, GDCA_ENOCONV=_lib.GDCA_ENOCONV)
-    jl = open(os.path.join(ROOT, "julia", "GaussDCAHip.jl")).read()
+    jl = open(os.path.join(ROOT, "julia", "src", "GaussDCAHip.jl")).read()
     for code, exc in ((1, "ArgumentError"), (2, "PosDefException"), (4, "OutOfMemoryError"), (5, r"LinearAlgebra\.LAPACKException")):
         assert re.search(r"st == %d && throw\(%s" % (code, exc), jl), (code, exc)
+
+
+def _header_prototypes():
+    """name -> (return type, [argument types]) of every function include/gdca.h declares, C types normalised
+    ('const int8_t *', 'gdca_ctx **', 'double', ...)."""
+    src = open(os.path.join(ROOT, "include", "gdca.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(gdca_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+
+        def norm(t):
+            t = re.sub(r"\s+", " ", t.strip())
+            t = re.sub(r"\s*\*\s*", " *", t)         # 'T * const *' -> 'T *const *'
+            t = t.replace("* *", "**").replace("*const *", "**").replace(" const *", " *")
+            return t.strip()
+
+        alist = []
+        for a in [x for x in args.split(",") if x.strip() and x.strip() != "void"]:
+            a = a.strip()
+            a = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", a).strip() if not a.endswith("*") else a   # drop the name
+            alist.append(norm(a))
+        protos[name] = (norm(ret), alist)
+    return protos
+
+
+# C type (as _header_prototypes normalises it) -> the Julia ccall types that bind it correctly
+_JL_OK = {
+    "gdca_status": {"Cint"}, "int32_t": {"Int32", "Cint"}, "int64_t": {"Int64"}, "uint64_t": {"UInt64"},
+    "double": {"Cdouble", "Float64"}, "const char *": {"Cstring", "Ptr{UInt8}"}, "void *": {"Ptr{Cvoid}"},
+    "const void *": {"Ptr{Cvoid}"},
+    "gdca_ctx *": {"Ptr{Cvoid}"}, "gdca_ctx **": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "gdca_dbuf *": {"Ptr{Cvoid}"}, "const gdca_dbuf *": {"Ptr{Cvoid}"}, "gdca_dbuf **": {"Ref{Ptr{Cvoid}}"},
+    "const int8_t *": {"Ptr{Int8}", "Ptr{Cvoid}"}, "int8_t *": {"Ptr{Int8}", "Ptr{Cvoid}"},
+    "const double *": {"Ptr{Float64}", "Ptr{Cdouble}", "Ptr{Cvoid}"},
+    "double *": {"Ptr{Float64}", "Ptr{Cdouble}", "Ref{Cdouble}", "Ref{Float64}", "Ptr{Cvoid}"},
+    "int32_t *": {"Ref{Int32}", "Ptr{Int32}", "Ptr{Cvoid}"}, "uint64_t *": {"Ref{UInt64}", "Ptr{UInt64}"},
+    "const gdca_params *": {"Ref{GdcaParams}", "Ptr{GdcaParams}"}, "gdca_stats *": {"Ref{GdcaStats}", "Ptr{GdcaStats}"},
+}
+
+
+def _split_top(s):
+    """split on commas that are not nested inside (), {} or []"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_julia_ccalls_match_the_header():
+    """Every `ccall((:sym, libgdca), Ret, (ArgTypes...), args...)` of julia/src/GaussDCAHip.jl against the prototype of
+    `sym` in include/gdca.h: the symbol exists, return type and every argument type bind the C type, and the number of
+    values passed equals the number of declared arguments.  (The shim cannot be executed in this image -- no Julia --
+    so its signatures are checked here; its structs are checked by the layout test above.)  Also: the exported surface
+    is the reference's (src/GaussDCA.jl:3: gDCA, printrank) plus the DCAUtils-named operators of :28-39, and the package
+    file names the reference's dependencies."""
+    protos = _header_prototypes()
+    assert len(protos) == len(_declared_symbols())
+    jl = open(os.path.join(ROOT, "julia", "src", "GaussDCAHip.jl")).read()
+    jl_nc = re.sub(r"#[^\n]*", "", jl)
+    calls = 0
+    for m in re.finditer(r"ccall\(\(:(gdca_[a-z0-9_]+), libgdca\),", jl_nc):
+        sym = m.group(1)
+        # the balanced argument list of this ccall
+        i, depth, start = m.end(), 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl_nc[i], 0)
+            i += 1
+        parts = _split_top(jl_nc[start:i - 1])
+        ret, argt = parts[0], parts[1]
+        values = parts[2:]
+        assert argt.startswith("(") and argt.endswith(")"), (sym, argt)
+        types = _split_top(argt[1:-1])
+        assert sym in protos, sym + " is not declared in include/gdca.h"
+        c_ret, c_args = protos[sym]
+        assert ret in _JL_OK[c_ret], (sym, "return", ret, c_ret)
+        assert len(types) == len(c_args) == len(values), (sym, types, c_args, values)
+        for k, (jt, ct) in enumerate(zip(types, c_args)):
+            assert ct in _JL_OK, (sym, k, ct)
+            assert jt in _JL_OK[ct], (sym, "argument %d" % k, jt, ct)
+        calls += 1
+    assert calls >= 20
+    exported = re.search(r"^export (.*?)\n\n", jl, flags=re.S | re.M).group(1).replace("\n", " ")
+    names = {x.strip() for x in exported.split(",")}
+    assert {"gDCA", "printrank", "compute_weights", "compute_weighted_frequencies", "add_pseudocount", "compute_FN",
+            "compute_DI_gauss"} <= names
+    proj = open(os.path.join(ROOT, "julia", "Project.toml")).read()
+    ref_deps = {"DCAUtils": "e41cd558-3099-4f6e-a65d-5336857e40aa", "LinearAlgebra": "37e2e46d-f89d-539d-b4ee-838fcccc9c8e",
+                "GaussDCA": "bc09176e-aa47-5a77-a802-92a0219fe3db"}     # uuids of /root/reference/Project.toml:2,6-7
+    for name, uuid in ref_deps.items():
+        assert re.search(r'^%s = "%s"$' % (name, uuid), proj, flags=re.M), name
 
 
 def test_no_cpu_fallback(lib_path):

@@ -255,6 +255,48 @@ def test_async_pipeline_api(g, ctx, o):
             c.close()
 
 
+def test_phase_batched_runs_equal_single_runs(g, ctx, o):
+    """gdca_run_dev_phased: K families of mixed sizes batched by phase on one stream (K front ends, K inverses back to back,
+    K score stages) -- both scores, single-block and multi-block schedules (N = 40 .. 430), collected in reverse order --
+    must give the bits of K single runs; a second batch on the same contexts reuses the workspaces; misuse is GDCA_EINVAL
+    and leaves the contexts usable."""
+    import torch
+
+    from gaussdca.jl_amd import synth
+
+    sizes = [(40, 500), (130, 2000), (75, 900), (430, 3000), (64, 64)]
+    fams = [synth.synth_family(N, M, 21, 0xF00 + N) for N, M in sizes]
+    Zd = [torch.from_numpy(z).cuda() for z in fams]
+    for score, pc in ((0, 0.8), (1, 0.2)):
+        ref, ref_st = [], []
+        for z, zd in zip(fams, Zd):
+            S = torch.empty((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda")
+            ref_st.append(ctx.run_dev(zd.data_ptr(), z.shape[1], z.shape[0], 21, pc, -1.0, score, S.data_ptr()))
+            ref.append(S.cpu())
+        cs = [g.Context(0) for _ in fams]
+        for rep in range(2):
+            outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
+            g.run_dev_phased(cs, [zd.data_ptr() for zd in Zd], [z.shape[1] for z in fams], [z.shape[0] for z in fams],
+                             [21] * len(fams), pc, -1.0, score, [x.data_ptr() for x in outs])
+            with pytest.raises(g.ArgumentError):                       # a member still has its run outstanding
+                cs[1].run_dev_async(Zd[1].data_ptr(), sizes[1][0], sizes[1][1], 21, pc, -1.0, score, outs[1].data_ptr())
+            sts = [None] * len(cs)
+            for k in reversed(range(len(cs))):
+                sts[k] = cs[k].collect()
+            for k in range(len(cs)):
+                assert torch.equal(outs[k].cpu(), ref[k]), (score, rep, k)
+                assert sts[k]["Meff"] == ref_st[k]["Meff"] and sts[k]["thresh"] == ref_st[k]["thresh"] and sts[k]["info"] == 0
+                assert sts[k]["ms_inverse"] > 0 and sts[k]["sweep_ghz"] > 1.0
+        with pytest.raises(g.ArgumentError):
+            g.run_dev_phased([cs[0], cs[0]], [Zd[0].data_ptr()] * 2, [40] * 2, [500] * 2, [21] * 2, pc, -1.0, score,
+                             [outs[0].data_ptr()] * 2)               # the same context twice
+        S1 = torch.empty((40, 40), dtype=torch.float64, device="cuda")
+        cs[0].run_dev(Zd[0].data_ptr(), 40, 500, 21, pc, -1.0, score, S1.data_ptr())   # still usable on its own stream
+        assert torch.equal(S1.cpu(), ref[0])
+        for c in cs:
+            c.close()
+
+
 # ---- BASELINE.json's full sizes: size-independent properties ----------------------------------------
 def test_headline_config_properties(g, ctx):
     """N=500, M=50k, q=21 (configs[2]): sampled bit-exact neighbour counts, invariance of the scores
