@@ -142,14 +142,47 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
     from oracle import gdca_oracle as o
 
     try:
-        cores = len(os.sched_getaffinity(0))      # the cores this process may run on (cgroup / affinity aware)
+        avail = len(os.sched_getaffinity(0))      # the cores this process may run on (cgroup / affinity aware)
     except AttributeError:
-        cores = os.cpu_count() or 1
-    o.set_threads(cores)
+        avail = os.cpu_count() or 1
     s = q - 1
     n = N * s
     t_all = time.time()
     Z = synth_family(N, M, q, seed)
+    # How many threads to use is MEASURED, not assumed: on the GPU box's 256-thread host both OpenMP loops are fastest at 32
+    # threads and 4-5x slower at 256 (tools/cpu_scaling.py, profiles/r03_cpu_scaling.log), so "all cores" would understate
+    # the CPU.  Candidates: all, 128, 64, 32, 16; the fastest on a probe wins, for the OpenMP loops and for OpenBLAS
+    # separately; `cores` in the JSON is what was used.
+    cands = sorted({c for c in (avail, 128, 64, 32, 16) if c <= avail} or {avail}, reverse=True)
+    thr0 = o.hamming_threshold(0.3, N)
+    Zs = Z[:min(M, 8000)]
+    probe_omp = {}
+    for c in cands:
+        o.set_threads(c)
+        o.neighbour_counts(Zs[:500], thr0)
+        t = time.time()
+        o.neighbour_counts(Zs, thr0)
+        probe_omp[c] = time.time() - t
+    cores = min(probe_omp, key=probe_omp.get)
+    o.set_threads(cores)
+    probe_blas = {}
+    blas_threads = avail
+    try:
+        from threadpoolctl import threadpool_limits
+
+        rng0 = np.random.default_rng(1)
+        B0 = rng0.standard_normal((max(512, n // 4), 64))
+        C0 = B0 @ B0.T / 64 + np.eye(B0.shape[0])
+        for c in cands:
+            with threadpool_limits(limits=c, user_api="blas"):
+                o.spd_inverse(np.eye(64))
+                t = time.time()
+                o.spd_inverse(C0)
+                probe_blas[c] = time.time() - t
+        blas_threads = min(probe_blas, key=probe_blas.get)
+        blas_limit = threadpool_limits(limits=blas_threads, user_api="blas")
+    except Exception:  # noqa: BLE001
+        blas_limit = None
     th = o.compute_theta(Z) if theta < 0 else float(theta)
     thr = o.hamming_threshold(th, N)
 
@@ -246,15 +279,21 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         how = ("bounded sample, the two super-linear stages SCALED: Hamming on %d of %d sequences (x pair ratio), "
                "tallies on %d (x M ratio), potrf+potri at n=%d of %d (x n^3 ratio)" % (Mh, M, Mt, ns, n))
     sec = sum(stage.values())
-    return dict(value=1.0 / sec, unit="families/s", cores=cores, kind="port", measured_in_full=bool(full),
+    if blas_limit is not None:
+        blas_limit.restore_original_limits()
+    return dict(value=1.0 / sec, unit="families/s", cores=cores, blas_threads=blas_threads, host_threads_available=avail,
+                thread_choice={"openmp_probe_sec": {str(k): round(v, 4) for k, v in probe_omp.items()},
+                               "blas_probe_sec": {str(k): round(v, 4) for k, v in probe_blas.items()}},
+                kind="port", measured_in_full=bool(full),
                 sec_per_family=sec, stage_sec={k: round(v, 4) for k, v in stage.items()},
                 thread_scaling={"hamming_pairs_per_s_1_thread": ham_rate_1, "hamming_pairs_per_s_all": ham_rate,
                                 "hamming_speedup": ham_rate / ham_rate_1,
                                 "tally_s_per_seq_1_thread": freq_1, "tally_s_per_seq_all": freq_all,
                                 "tally_speedup": freq_1 / max(freq_all, 1e-12)},
                 sample=("oracle (numpy + OpenMP/AVX2 C + OpenBLAS potrf/potri; NOT the Julia reference, which cannot run "
-                        "here) on %d host threads, N=%d M=%d q=%d score=%s: %s; wall incl. probes %.1fs"
-                        % (cores, N, M, q, score_name, how, time.time() - t_all)))
+                        "here) on %d OpenMP / %d OpenBLAS threads (the fastest of the probed counts; %d available), "
+                        "N=%d M=%d q=%d score=%s: %s; wall incl. probes %.1fs"
+                        % (cores, blas_threads, avail, N, M, q, score_name, how, time.time() - t_all)))
 
 
 def launch_ranks(n):

@@ -723,6 +723,42 @@ __device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, Stag
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The panel product of a row block for ONE pivot block's 128 columns of H, K = 128 sz, on the tile items' chunk loop:
+//   acc(r, c) = sum_v sum_k G_v(r, k) Pg(c, 128 v + k)
+// gA: the row block's tile of the group's FIRST pivot block in A -- G_v(r, k) = gA[r + (128 v + k) ld] below the group, and
+// (GT) gA[128 v + k + r ld] above it, where the stored tile is the transpose.  hP: Pg at (row c = 0 of the wanted columns, k = 0).
+// gcopy: the item also leaves the untransposed G_v in the panel buffers (gcopy + v pstride, ld = ld).
+template <bool GT>
+__device__ __forceinline__ void panel_chunks(double4_t (&acc)[4][4], const double *__restrict__ gA, size_t ld,
+                                             const double *__restrict__ hP, size_t pgld, int sz, double (*Gs)[KC][LDS_LD],
+                                             double (*Hs)[KC][LDS_LD], double *__restrict__ gcopy, size_t pstride)
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    const ChunkIO io = chunk_io<GT>(ld, pgld, tid, ld);
+    const int nch = (T / KC) * sz;  // chunk c: k = 16 c .. 16 c + 15 of the group's 128 sz columns
+    auto gsrc = [&](int c) { return GT ? gA + (size_t)c * KC : gA + (size_t)c * KC * ld; };
+    auto hsrc = [&](int c) { return hP + (size_t)c * KC * pgld; };
+    auto gcp = [&](int c) { return gcopy ? gcopy + (size_t)(c >> 3) * pstride + (size_t)((c & 7) * KC) * ld : nullptr; };
+    // (a second staging register set -- two chunks of prefetch distance -- was tried for these items, which often run alone on
+    // their compute unit with chunks shorter than a load's round trip: no gain, and the transposed-G loop then spills)
+    StageRegs<4> R;
+    double cp[8];
+    Frag f;
+    stage_chunk_load<GT>(R, gsrc(0), hsrc(0), io);
+    stage_chunk_store<GT>(R, Gs[0], Hs[0], tid, gcp(0), ld);
+    stage_chunk_load<GT>(R, gsrc(1), hsrc(1), io);
+    __syncthreads();
+    frag_read<GT>(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
+#pragma unroll 1
+    for (int c = 0; c < nch - 2; c += 2) {
+        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gsrc(c + 2), hsrc(c + 2), io, nullptr, 0, tid, gcp(c + 1));
+        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gsrc(c + 3), hsrc(c + 3), io, nullptr, 0, tid, gcp(c + 2));
+    }
+    tile_chunk<true, false, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gA, hP, io, nullptr, 0, tid, gcp(nch - 1));
+    tile_chunk<false, false, false, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gA, hP, io, nullptr, 0, tid);
+}
+
 // Write-back of the new column block: A[i,k] = G_i P = -H_i  (A[k,i] = (G_i P)^T for i < k).  Not done by
 // the panel kernel because the two panel workgroups of a row block both read the OLD A[i,k] as their G
 // operand.  A work item of its own in the sweep kernel (wb): every thread first loads all of its 64 values, then
@@ -863,10 +899,12 @@ __device__ __forceinline__ void publish_begin()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifndef GDCA_X_NORELEASE
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#endif
 }
 
 // The write-through form: every store of the published bytes was an agent-scope (sc1) store -- it goes to memory, not
@@ -1166,6 +1204,9 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         return;
     }
     // tile jobs on the scratch matrix (128 x 64 each):  J1: S_iw <- S_iw Pw (and its mirror S_wi);  J2: S_ij <- S_ij - (S_iw Pw) S_jw^T
+    // (halves, not whole tiles: the jobs of a level run side by side on the chain's workgroups, two to a compute unit, and the
+    // chain waits for the slowest -- whole 128 x 128 jobs on the hand-scheduled chunk loop left half of those workgroups idle
+    // and made the level longer: 46-73 us instead of 30-45)
     const bool second = r > n1;
     const int k = second ? r - 1 - n1 : r - 1;
     const int ch = k & 1;
@@ -1210,40 +1251,6 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
             }
     publish_begin();
     if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The panel product of a row block for ONE pivot block's 128 columns of H, K = 128 sz, on the tile items' chunk loop:
-//   acc(r, c) = sum_v sum_k G_v(r, k) Pg(c, 128 v + k)
-// gA: the row block's tile of the group's FIRST pivot block in A -- G_v(r, k) = gA[r + (128 v + k) ld] below the group, and
-// (GT) gA[128 v + k + r ld] above it, where the stored tile is the transpose.  hP: Pg at (row c = 0 of the wanted columns, k = 0).
-// gcopy: the item also leaves the untransposed G_v in the panel buffers (gcopy + v pstride, ld = ld).
-template <bool GT>
-__device__ __forceinline__ void panel_chunks(double4_t (&acc)[4][4], const double *__restrict__ gA, size_t ld,
-                                             const double *__restrict__ hP, size_t pgld, int sz, double (*Gs)[KC][LDS_LD],
-                                             double (*Hs)[KC][LDS_LD], double *__restrict__ gcopy, size_t pstride)
-{
-    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    const ChunkIO io = chunk_io<GT>(ld, pgld, tid, ld);
-    const int nch = (T / KC) * sz;  // chunk c: k = 16 c .. 16 c + 15 of the group's 128 sz columns
-    auto gsrc = [&](int c) { return GT ? gA + (size_t)c * KC : gA + (size_t)c * KC * ld; };
-    auto hsrc = [&](int c) { return hP + (size_t)c * KC * pgld; };
-    auto gcp = [&](int c) { return gcopy ? gcopy + (size_t)(c >> 3) * pstride + (size_t)((c & 7) * KC) * ld : nullptr; };
-    StageRegs<4> R;
-    double cp[8];
-    Frag f;
-    stage_chunk_load<GT>(R, gsrc(0), hsrc(0), io);
-    stage_chunk_store<GT>(R, Gs[0], Hs[0], tid, gcp(0), ld);
-    stage_chunk_load<GT>(R, gsrc(1), hsrc(1), io);
-    __syncthreads();
-    frag_read<GT>(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
-#pragma unroll 1
-    for (int c = 0; c < nch - 2; c += 2) {
-        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gsrc(c + 2), hsrc(c + 2), io, nullptr, 0, tid, gcp(c + 1));
-        tile_chunk<true, true, true, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gsrc(c + 3), hsrc(c + 3), io, nullptr, 0, tid, gcp(c + 2));
-    }
-    tile_chunk<true, false, true, -1, GT>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], gA, hP, io, nullptr, 0, tid, gcp(nch - 1));
-    tile_chunk<false, false, false, -1, GT>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], gA, hP, io, nullptr, 0, tid);
 }
 
 // ---- panel(p): G_i and 32 TM columns of H_i = -G_i Pg for one row block ---------------------------------------------------

@@ -44,7 +44,7 @@ def ctx(g):
 def o():
     from oracle import gdca_oracle as o
 
-    o.set_threads(os.cpu_count() or 1)
+    o.set_threads(min(os.cpu_count() or 1, 32))   # the OpenMP loops peak at 32 threads on the GPU box (tools/cpu_scaling.py)
     return o
 
 

@@ -54,10 +54,10 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
         # in every pair -- the 0/0 of correct_APC (src/GaussDCA.jl:78-86 divides by the sum of all scores), as the reference
         # itself would
         nan = np.isnan(S)
-        off = ~np.eye(S.shape[0], dtype=bool)
-        # NaN only as that all-or-nothing 0/0 of the APC denominator (every off-diagonal entry at once), never as isolated
-        # entries -- a NaN produced inside FN / DI on a degenerate input must not hide behind this branch
-        assert (not nan.any()) or (nan[off].all() and not nan[~off].any())
+        # NaN only as that all-or-nothing 0/0 of the APC denominator (S - (Sj * Si) / 0: every entry at once, the diagonal
+        # included, src/GaussDCA.jl:84), never as isolated entries -- a NaN produced inside FN / DI on a degenerate input must
+        # not hide behind this branch
+        assert (not nan.any()) or nan.all()
         assert np.max(np.abs(np.nan_to_num(S, nan=0.0))) < 1e-10
         return
     # DI = s/2 log(1/2) + 1/2 sum_k log(1 + sqrt(1 + 4 gamma_k)) is a difference of O(s) quantities: with a pseudocount

@@ -1,7 +1,7 @@
 #!/bin/bash
 # First half of the round's measurements (tests, bench lines of every configuration, kernel statistics); the counter
 # passes, traces and micro-benchmarks are tools/gpu_round2.sh:
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/gpu_round.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/gpu_round.sh r03'
 # Output under gpurun_out/<tag>/; the summaries are copied into profiles/ by hand afterwards (tools/prof_summary.py).
 tag=${1:-rXX}
 out=gpurun_out/$tag
@@ -9,7 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python -c "import torch" 2>/dev/null
 python __graft_entry__.py > $out/entry.log 2>&1; echo "entry rc $?" >> $out/entry.log
-( timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "rc $?" >> $out/pytest_gpu.log )
+( timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider --durations=12 > $out/pytest_gpu.log 2>&1; echo "rc $?" >> $out/pytest_gpu.log )
 tail -3 $out/pytest_gpu.log
 # bench lines (default flags = the driver's command), then the other configs
 timeout 900 python bench.py > $out/bench_C_frob.json 2> $out/bench_C_frob.err
@@ -17,14 +17,16 @@ timeout 900 python bench.py --score DI > $out/bench_C_DI.json 2> $out/bench_C_DI
 timeout 600 python bench.py --config B --steps 50 --warmup 5 > $out/bench_B.json 2> $out/bench_B.err
 timeout 900 python bench.py --config D --steps 5 --warmup 2 > $out/bench_D.json 2> $out/bench_D.err
 timeout 900 python bench.py --config E --steps 2 --warmup 1 > $out/bench_E.json 2> $out/bench_E.err
-timeout 900 python bench.py --pipeline 2 --no-cpu-baseline > $out/bench_C_p2.json 2> $out/bench_C_p2.err
+timeout 900 python bench.py --config E --steps 2 --warmup 1 --pipeline 2 > $out/bench_E_p2.json 2> $out/bench_E_p2.err
+timeout 900 python bench.py --pipeline 4 --phased --no-cpu-baseline > $out/bench_C_p4_phased.json 2> $out/bench_C_p4_phased.err
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import sys, json
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d['roofline']
     print(sys.argv[1].split('/')[-1], 'value %.3f' % d['value'], 'ms/step %.2f' % d['ms_per_step'], 'inv %.2f ms' % d['stage_ms']['ms_inverse'],
-          'roofline %.1f TF (%.3f)' % (d['roofline']['achieved'], d['roofline']['frac']),
-          'cpu %s' % (d.get('cpu_baseline') or {}).get('value'))
+          'roofline %.1f TF (%.3f) at %.3f GHz' % (r['achieved'], r['frac'], r['measured_shader_ghz']),
+          'cpu %s on %s threads' % ((d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline') or {}).get('cores')))
 except Exception as e:
     print(sys.argv[1], 'unreadable', e)
 PY
