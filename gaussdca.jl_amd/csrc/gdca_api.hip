@@ -400,7 +400,7 @@ static gdca_status validate(gdca_ctx *ctx, int N, int M, int q)
     if (!ctx) return GDCA_EINVAL;
     if (N < 1 || M < 1) return fail(ctx, GDCA_EINVAL, "invalid alignment size%s%s", "", "");
     if (q < 2 || q > GDCA_MAXQ) return fail(ctx, GDCA_EINVAL, "parameter q is too big (max 31 is allowed)%s%s", "", "");
-    if ((long long)N * (q - 1) > 60000) return fail(ctx, GDCA_EINVAL, "N*(q-1) too large%s%s", "", "");
+    if ((long long)N * (q - 1) > GDCA_MAX_N) return fail(ctx, GDCA_EINVAL, "N*(q-1) is larger than GDCA_MAX_N%s%s", "", "");
     return GDCA_OK;
 }
 
@@ -820,7 +820,7 @@ gdca_status gdca_add_pseudocount_dev(gdca_ctx *ctx, const double *Pi_true_dev, c
 
 gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const double *Pij_dev, int32_t n, double *C_dev)
 {
-    if (!ctx || !Pi_dev || !Pij_dev || !C_dev || n < 1 || n > 60000) return GDCA_EINVAL;
+    if (!ctx || !Pi_dev || !Pij_dev || !C_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     gdca_launch_covariance(ctx->stream, Pi_dev, Pij_dev, n, C_dev);
     return check_launch(ctx, "covariance");
@@ -828,7 +828,7 @@ gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const doubl
 
 gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
 {
-    if (!ctx || !A_dev || n < 1 || n > 60000) return GDCA_EINVAL;
+    if (!ctx || !A_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
     CHK(begin(ctx));
     hipStream_t s = ctx->stream;
     const int n_pad = round_up(n, GDCA_TILE);
@@ -993,7 +993,7 @@ gdca_status gdca_add_pseudocount(gdca_ctx *ctx, const double *Pi_true, const dou
 
 gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, int32_t n, double *C)
 {
-    if (!ctx || !Pi || !Pij || !C || n < 1 || n > 60000) return GDCA_EINVAL;
+    if (!ctx || !Pi || !Pij || !C || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nn = (size_t)n;
     CHK(to_dev(ctx, ctx->scratch[1], Pij, nn * nn * sizeof(double)));
@@ -1005,7 +1005,7 @@ gdca_status gdca_covariance(gdca_ctx *ctx, const double *Pi, const double *Pij, 
 
 gdca_status gdca_spd_inverse(gdca_ctx *ctx, double *A, int32_t n, int32_t *info)
 {
-    if (!ctx || !A || n < 1 || n > 60000) return GDCA_EINVAL;
+    if (!ctx || !A || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nn = (size_t)n;
     CHK(to_dev(ctx, ctx->scratch[1], A, nn * nn * sizeof(double)));

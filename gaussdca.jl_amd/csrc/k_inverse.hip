@@ -988,8 +988,9 @@ __device__ __forceinline__ int m_items(int sz)
 // (panel(p+1) covers the rows outside groups p+1 and p+2: Pg(p+1) comes from the chain, which runs a group ahead, and its
 // other inputs were produced early in this sequence -- so the panels are complete when the tile items of update p+1 are
 // handed out, instead of holding all of them up at the start of every group).
-// kind 0: panel item (group p, row block a, part b); 1: tile item (group p, tile (a, b)); 2: write-back item (group p,
-// index a); 3: nothing (a remainder slot that belongs to diag2).  `p` is the caller's running group (items ascend).
+// kind 0: panel item (group p, row block a, part b); 1: tile item (group p, tile (a, b)); 4: the same, one of the early ones the
+// chain of a later group waits for (diag2, rest); 2: write-back item (group p, index a); 3: nothing (a remainder slot that
+// belongs to diag2).  `p` is the caller's running group (items ascend).
 struct MainItem {
     int kind, p, a, b;
 };
@@ -1012,14 +1013,14 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
             first += n2 - mm;
             ++mm;
         }
-        return MainItem{1, p, d0 + mm + (e - first), d0 + mm};
+        return MainItem{4, p, d0 + mm + (e - first), d0 + mm};
     }
     e -= n_diag2;
     if (e < nsz * nrest) {
         const int mm = e / nrest, local = e % nrest;
         const int b = local < b0 ? local : local - b0 + d0;
         const int cb = c0 + mm;
-        return MainItem{1, p, b > cb ? b : cb, b > cb ? cb : b};
+        return MainItem{4, p, b > cb ? b : cb, b > cb ? cb : b};
     }
     e -= nsz * nrest;
     const int n_wb = (D.nblk - sz) * sz;
@@ -1364,7 +1365,7 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
         if (nxt < D.total) {
             int ph = p;
             const MainItem ni = main_decode(D, ph, nxt);
-            if (ni.kind == 1) {
+            if (ni.kind == 1 || ni.kind == 4) {
                 const int nsz2 = g_size(D, ni.p);
                 const unsigned f1 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.a), f2 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.b),
                                f3 = flag_load(D.gen + (size_t)ni.a * D.nblk + ni.b);
@@ -1645,7 +1646,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
         const MainItem it = main_decode(D, p, item);
-        if (it.kind == 1) {
+        if (it.kind == 1 || it.kind == 4) {
             if (D.rl < T && it.a == D.nblk - 1)
                 sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
             else if (MULTI && g_size(D, it.p) > 1)

@@ -38,6 +38,10 @@
 extern "C" {
 #endif
 
+/* Largest covariance the entry points accept: n = N (q-1) <= GDCA_MAX_N (a 60 000 x 60 000 f64 matrix is 28.8 GB of the
+ * 288 GB of HBM; the sweep kernel's item tables are 32-bit).  Exercised up to n = 48 000. */
+#define GDCA_MAX_N 60000
+
 #define GDCA_VERSION_MAJOR 0
 #define GDCA_VERSION_MINOR 3
 
