@@ -1708,10 +1708,11 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // pivot blocks per group: more blocks per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
     // are bound by the chain itself, which is shortest with single blocks (no scratch copy, no tile jobs).  Measured on
-    // MI355X (tools/sweep_groups.py, profiles/r02_sweep_groups.log): g = 1 is fastest up to 57 blocks, 2 to 66, 3 to 83,
-    // 4 from 84 on.
+    // MI355X with the round-3 tile loop (tools/sweep_groups.py, profiles/r03_sweep_groups*.log: inverse time over N x g x chain
+    // CUs): g = 1 is fastest up to 58 blocks, 2 to 64, 3 to 70, 4 from 71 on -- groups of four at n = 10 000 (79 blocks) need 12
+    // compute units for the chain (16.5 ms against 17.2 for groups of three; with 8 they lose: 17.9).
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 84 ? 4 : (nblk >= 67 ? 3 : (nblk >= 58 ? 2 : 1)));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 71 ? 4 : (nblk >= 65 ? 3 : (nblk >= 59 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
@@ -1826,9 +1827,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.ppb = ppb;
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
-    // once (16 CUs for single-block groups of small matrices, 8 otherwise); once the update hides the chain, 4 are enough and
-    // the rest go back to the tiles
-    const int mcu_rule = g == 1 ? (nblk < 28 ? 16 : 12) : ((g == 3 && nblk >= 76) || (g == 4 && nblk >= 110) ? 4 : 8);
+    // once -- the 2 (g-1)^2 half-tile jobs of a level of a four-block group are 18 -- and once the update hides the chain the
+    // workers go back to the tiles: 16 CUs for single-block groups of small matrices and for multi-block groups up to 74
+    // blocks, 12 up to 86, 8 up to 115, 4 beyond
+    const int mcu_rule = g == 1 ? (nblk < 28 ? 16 : 12) : (nblk <= 74 ? 16 : (nblk <= 86 ? 12 : (nblk <= 115 ? 8 : 4)));
     D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
     D.rl = rl;

@@ -19,9 +19,11 @@ for N in [int(x) for x in sys.argv[2].split(",")]:
     out[N] = best
 print(json.dumps(out))
 '''
-Ns = "100,128,200,300,350,400,450,500,550,600,800,1000"
+Ns = os.environ.get("SWEEP_NS", "100,128,200,300,350,400,450,500,550,600,800,1000")
 res = {}
 combos = [(gsz, m) for gsz in (1, 2, 3, 4) for m in ((8,) if "--quick" in sys.argv else (4, 8, 12, 16))]
+if os.environ.get("SWEEP_COMBOS"):   # "g:m,g:m,..."
+    combos = [tuple(int(x) for x in c.split(":")) for c in os.environ["SWEEP_COMBOS"].split(",")]
 for gsz, m in combos:
     env = dict(os.environ, GDCA_GROUP=str(gsz), GDCA_MCUS=str(m))
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, Ns], capture_output=True, text=True, env=env, timeout=900)
