@@ -1,6 +1,6 @@
 #!/bin/bash
 # Second half of the round's measurements (counter passes, calibration, in-kernel traces, micro-benchmarks):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round2.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_round2.sh r03'
 tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -9,7 +9,6 @@ R=$GRAFT_REPO_ROOT
 python -c "import torch" 2>/dev/null
 ( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "schedule" > $out/pytest_schedules.log 2>&1; tail -2 $out/pytest_schedules.log )
 timeout 600 python tools/stress_inverse.py > $out/stress_inverse.log 2>&1; tail -3 $out/stress_inverse.log
-timeout 600 python bench.py > $out/bench_C_frob.json 2> $out/bench_C_frob.err
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/pmc_$c.log 2>&1
@@ -23,5 +22,8 @@ GDCA_SWEEP_TRACE=$out/sweep_trace_B.txt timeout 300 python tools/sweep_trace.py 
 GDCA_SWEEP_TRACE=$out/clock_ramp_C.txt timeout 300 python tools/clock_ramp.py 10000 8 > $out/clock_ramp_C.log 2>&1
 head -4 $out/sweep_trace_C.log
 find $out -name "*agent_info*" -delete
-bash tools/gpu_ubench.sh $tag > $out/ubench.log 2>&1
+# host side: feed rate of the batch driver and thread scaling of the CPU port (no GPU work)
+timeout 900 bash tools/parse_bench.sh 256 /tmp/gdca_pb "1 16 32 64" > $out/parse_bench.log 2>&1
+timeout 300 python tools/cpu_scaling.py > $out/cpu_scaling.log 2>&1
+# (the dispatch micro-benchmarks of round 2 are tools/gpu_ubench.sh; the schedule sweep is tools/sweep_groups.py)
 du -sh $out
