@@ -310,5 +310,20 @@ def default_context() -> Context:
         ndev = load().gdca_device_count()
         if ndev <= 0:
             raise GdcaError("no HIP device visible: the gDCA hot path has no CPU fallback")
-        _default_ctx = Context(dev % ndev)
+        ids = visible_devices(ndev)
+        _default_ctx = Context(ids[dev % len(ids)])
     return _default_ctx
+
+
+def visible_devices(ndev: int):
+    """GDCA_VISIBLE_DEVICES=0,2,5: the HIP devices this process may use, in that order; unset = all.
+    Same rule as gdca_cli --batch: ids outside 0..ndev-1 and repeats are an error."""
+    env = os.environ.get("GDCA_VISIBLE_DEVICES", "")
+    if not env:
+        return list(range(ndev))
+    ids = []
+    for tok in env.split(","):
+        if not tok.strip().isdigit() or int(tok) >= ndev or int(tok) in ids:
+            raise ArgumentError(f"invalid GDCA_VISIBLE_DEVICES entry '{tok}' ({ndev} HIP device(s) present)")
+        ids.append(int(tok))
+    return ids

@@ -289,8 +289,14 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t), s));
-    gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M, q, sc);
-    gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
+    gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M, q, sc);  // (also the symbol-range check)
+    // GDCA_FORCE_FALLBACK (any value but "0"; read per call so that a test can switch it): the independent byte-compare kernel
+    // instead of the bit-sliced one -- the analogue of DCAUTILS_FORCE_FALLBACK in the reference's tests (test/runtests.jl:78-86)
+    const char *fb = getenv("GDCA_FORCE_FALLBACK");
+    if (fb && *fb && strcmp(fb, "0") != 0)
+        gdca_launch_hamming_fallback(s, Zd, (int32_t *)ctx->hcnt.p, N, M, sc);
+    else
+        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
     // Meff is one long dependent chain on a single CU: run it on the side stream, next to the kernels that

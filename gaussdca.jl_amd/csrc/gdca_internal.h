@@ -41,6 +41,8 @@ void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
 void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
                          const gdca_dev_scalars *sc);
+// the same counts by an independent plain byte-compare kernel straight from Z (GDCA_FORCE_FALLBACK; overwrites cnt[0..M-1])
+void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc);
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)
 void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W,
                          unsigned long long *Wfix);

@@ -226,6 +226,42 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N,
     hipLaunchKernelGGL(k_hamming, dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
 }
 
+// ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------
+// The reference tests its Hamming reweighting twice: DCAUtils' packed XOR / popcount path and, with
+// ENV["DCAUTILS_FORCE_FALLBACK"], its plain fallback, both against the same golden (test/runtests.jl:78-86).  The analogue
+// here: a plain byte-compare kernel that shares nothing with the bit-sliced one -- no bit planes, no pair tiles, no symmetry, no
+// atomics: workgroup <-> sequence k (its N bytes in LDS), thread <-> sequences l = tid, tid + 256, ..., every distance counted
+// position by position, one tree reduction per k.  M^2 N byte compares instead of M^2 N / 2 x 0.19 instructions: for tests only.
+__global__ __launch_bounds__(256) void k_hamming_bytes(const int8_t *__restrict__ Z, int32_t *__restrict__ cnt, int N, int M,
+                                                        const gdca_dev_scalars *sc)
+{
+    extern __shared__ int8_t zk[];
+    __shared__ int red[256];
+    const int k = blockIdx.x, tid = threadIdx.x, thresh = sc->thresh;
+    for (int i = tid; i < N; i += 256) zk[i] = Z[(size_t)k * N + i];
+    __syncthreads();
+    int mine = 0;
+    for (int l = tid; l < M; l += 256) {
+        if (l == k) continue;
+        const int8_t *zl = Z + (size_t)l * N;
+        int d = 0;
+        for (int i = 0; i < N; ++i) d += (zl[i] != zk[i]);
+        mine += (d < thresh);
+    }
+    red[tid] = mine;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) cnt[k] = red[0];
+}
+
+void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc)
+{
+    hipLaunchKernelGGL(k_hamming_bytes, dim3((unsigned)M), dim3(256), (size_t)N, s, Z, cnt, N, M, sc);
+}
+
 // ---- weights ------------------------------------------------------------------------------------
 int gdca_fix_shift(int M)
 {

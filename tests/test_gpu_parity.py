@@ -63,6 +63,29 @@ def test_reference_goldens_through_cabi(g, ctx, golden, refdata):
         assert st["pair_identity_sum"] == want["pair_identity_sum"]
 
 
+def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refdata, monkeypatch):
+    """test3 of the reference (test/runtests.jl:78-86) runs a golden again with ENV["DCAUTILS_FORCE_FALLBACK"], i.e. through
+    DCAUtils' second, independent Hamming implementation.  The analogue here: GDCA_FORCE_FALLBACK switches the reweighting to a
+    plain byte-compare kernel that shares nothing with the bit-sliced one.  Both must reproduce the golden (the reference's
+    case and the large one) and give identical neighbour counts, bit for bit, on random alignments with awkward sizes."""
+    monkeypatch.setenv("GDCA_FORCE_FALLBACK", "true")
+    for golden in ("small.DIRout.txt", "large.DIRout.txt"):
+        c = CASES[golden]
+        R = g.gDCA(os.path.join(refdata, c["fasta"]), ctx=ctx, **c["kw"])
+        rep = compare_with_golden(R, os.path.join(refdata, golden))
+        # (the large golden holds scores that are equal at the 7 digits it prints: order modulo those ties, as in the main test)
+        assert rep["keys_equal"] and rep["order_equal_mod_ties"] and rep["max_rel"] <= 1e-6, (golden, rep)
+    rng = np.random.default_rng(17)
+    for (M, N, q, thr) in ((301, 37, 21, 12), (1000, 130, 21, 45), (129, 33, 5, 20), (64, 7, 3, 4)):
+        Zo = random_msa(rng, M, N, q)
+        Z = np.asfortranarray(Zo.T)
+        monkeypatch.setenv("GDCA_FORCE_FALLBACK", "true")
+        n_fb = g.neighbour_counts(Z, thr, ctx=ctx)
+        monkeypatch.setenv("GDCA_FORCE_FALLBACK", "0")
+        n_bs = g.neighbour_counts(Z, thr, ctx=ctx)
+        assert np.array_equal(n_fb, n_bs) and np.array_equal(n_fb, o.neighbour_counts(Zo, thr)), (M, N, q)
+
+
 def test_gdca_matches_oracle_ranking_order(g, ctx, o, refdata):
     """Ranking indices identical to the oracle's on test/data (no ties on `small`)."""
     f = os.path.join(refdata, "small.fasta.gz")
