@@ -899,12 +899,10 @@ __device__ __forceinline__ void publish_begin()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifndef GDCA_X_NORELEASE
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#endif
 }
 
 // The write-through form: every store of the published bytes was an agent-scope (sc1) store -- it goes to memory, not
@@ -942,11 +940,7 @@ __device__ __forceinline__ bool spin_until(const SweepDesc &D, F ready)
 {
     unsigned long long t0 = 0ull;
     for (unsigned it = 0;; ++it) {
-#ifdef GDCA_X_NOPOLL
-        const unsigned ab = 0u;
-#else
         const unsigned ab = flag_load(D.abort);
-#endif
         const bool r = ready();
         if (ab != 0u) return false;
         if (r) return true;

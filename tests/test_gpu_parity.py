@@ -526,3 +526,53 @@ def test_sweep_watchdog_returns_a_status_instead_of_hanging():
     assert out["status"] == "ehip" and "timed out" in out["msg"], out
     assert out["seconds"] < 20.0, out
     assert 0.0 < out["theta_after"] <= 0.5
+
+
+_CUMASK_SCRIPT = r"""
+import ctypes, json, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import gaussdca.jl_amd as g
+lib = g.load()
+hip = ctypes.CDLL("libamdhip64.so")                       # the runtime libgdca.so is already linked against
+n = int(sys.argv[2])
+# CU-mask bit i <-> XCD i % 8 (measured in round 2, profiles/r02_ubench_cumap.log): drop every compute unit of XCC 0 and,
+# for good measure, half of XCC 3 -- no workgroup of any launch on this stream can then run on XCC 0
+words = [0] * 8
+for i in range(256):
+    if i % 8 != 0 and not (i % 8 == 3 and (i // 8) % 2 == 0):
+        words[i // 32] |= 1 << (i % 32)
+mask = (ctypes.c_uint32 * 8)(*words)
+stream = ctypes.c_void_p()
+rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), 8, mask)
+assert rc == 0, rc
+ctx = g.Context(0, stream=stream.value)
+rng = np.random.default_rng(5)
+B = rng.standard_normal((n, 40))
+A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
+t = time.time()
+X = g.inv_cholesky(A, ctx=ctx)
+out = {"rel": float(np.max(np.abs(X - np.linalg.inv(A))) / np.max(np.abs(X))), "seconds": time.time() - t,
+       "enabled_cus": sum(bin(w).count("1") for w in words)}
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("n", [2000, 9100])
+def test_inverse_on_a_cu_masked_stream_without_xcc0(n):
+    """The case the run-time election of the chain's XCD exists for: a caller's stream whose CU mask excludes every
+    compute unit of XCC 0 (gdca_ctx_create_on_stream).  The persistent sweep kernel is launched with two workgroups per
+    compute unit of the WHOLE device, so on 208 enabled units a third of them are not resident at first: items are handed
+    out in list order, an item only ever waits for items somebody already holds, and the chain's workers are elected among
+    the workgroups that do run.  Must return the LAPACK inverse (it used to spin for ever: no workgroup on XCC 0, nobody
+    elected)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CUMASK_SCRIPT, root, str(n)], capture_output=True, text=True,
+                       env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="3000"), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["enabled_cus"] == 208 and out["rel"] <= 1e-10, out
