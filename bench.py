@@ -365,6 +365,7 @@ def main():
     import torch
 
     dist = None
+    comm_fallback = None
     if args.dry_run:
         if world > 1:
             import torch.distributed as dist
@@ -400,11 +401,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl" on ROCm) for the timing barrier / max-over-ranks only; no collective on the data path.
-        # GDCA_BENCH_BACKEND=gloo selects gloo explicitly; a failing RCCL init is an error, not a silent fallback
-        # (the JSON line names the backend and the world size it really ran with).
+        # GDCA_BENCH_BACKEND=gloo selects gloo explicitly.  If the RCCL communicator cannot be created the measurement
+        # still runs over gloo -- loudly: a warning on stderr and `comm.fallback_reason` in the JSON line, which always
+        # names the backend and the world size it really ran with.
         backend = os.environ.get("GDCA_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as e:  # noqa: BLE001
+                comm_fallback = "%s: %s" % (type(e).__name__, str(e)[:300])
+                print("bench.py: RCCL init failed (%s); timing barrier over gloo instead" % comm_fallback, file=sys.stderr)
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
@@ -560,7 +567,7 @@ def main():
                 "frac_of_attainable_at_measured_clock": (achieved / (PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ)) if ghz > 0 else None,
             },
             "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
-                     "data_path_collectives": 0},
+                     "data_path_collectives": 0, "fallback_reason": comm_fallback},
         }
         if args.config != "E":
             out["config"].update({"N": N0, "M": M0, "n": N0 * (q - 1)})
