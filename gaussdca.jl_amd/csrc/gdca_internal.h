@@ -19,6 +19,8 @@ struct gdca_dev_scalars {
     int info;
     int bad_symbol;  // bit 0: a byte of Z is outside 1..q; bit 1: a caller-given weight is outside [0, 1] (GDCA_EINVAL)
     int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
+    int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement
+    int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
 };
 
@@ -39,8 +41,7 @@ size_t gdca_bitplane_bytes(int N, int M);
 void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M, int q,
                                gdca_dev_scalars *sc);
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
-                         const gdca_dev_scalars *sc);
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc);
 // the same counts by an independent plain byte-compare kernel straight from Z (GDCA_FORCE_FALLBACK; overwrites cnt[0..M-1])
 void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc);
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)

@@ -17,6 +17,9 @@
 //
 // Not HBM-bound: the bit-plane image (N*M*5/8 bytes, 16 MB at N=500, M=50k) stays in L2 /
 // Infinity Cache and every tile is re-read M/128 times; the bound is VALU issue.
+#include <algorithm>
+#include <cstdlib>
+
 #include "gdca_internal.h"
 
 #define NPLANES 5
@@ -98,23 +101,40 @@ __device__ __forceinline__ void tri_decode(int t, int Mt, int &I, int &J)
     J = i + (int)(t - start(i));
 }
 
-__global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
-                                                  int NW, int M, int Mt, const gdca_dev_scalars *__restrict__ sc)
+// NP = planes compared in the main loop.  NP = 5: exact distances (6 VALU instructions per 32 symbol compares).
+// NP = 3 (round 3): a LOWER BOUND first -- two symbols that differ in their three low bits differ, so the distance on planes
+// 0..2 alone, d3 <= d, costs 4 instructions per 32 compares; only pairs with d3 < threshold can be neighbours.  Where most
+// sequences are unrelated those are a few in ten thousand (d3 of two unrelated sequences is ~0.9 d, far beyond the threshold;
+// two planes would save more instructions but leave 0.8 % of the benchmark family's pairs to refine: measured, 3.6x slower).
+// The candidates of a tile go into a list in LDS and are then counted exactly from all five planes of the global image, 16
+// lanes per pair (one per dword of 32 positions).  The counts are the same integers either way.  Which form pays depends on
+// the family: k_hamming<3, PROBE> measures the candidate density on a sample of tiles and k_hamming_decide sets sc->ham_mode;
+// both kernels are launched and the one not chosen returns at once.
+#define HAM_BOUND_PLANES 3
+#define HAM_CAND_CAP 1024  // candidate pairs of one tile per pass of the refinement
+
+template <int NP, bool PROBE>
+__global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
+                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc, int tile_stride)
 {
     const int thresh = sc->thresh;
     if (thresh <= 0) return;  // theta == 0 (or floor(theta N) == 0): every n_k = 1
+    if (!PROBE && sc->ham_mode != (NP == NPLANES ? 0 : 1)) return;  // the other form was chosen for this family
 
-    __shared__ __attribute__((aligned(16))) uint32_t As[NPLANES][WCHUNK][GDCA_HTILE];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[NPLANES][WCHUNK][GDCA_HTILE];
+    __shared__ __attribute__((aligned(16))) uint32_t As[NP][WCHUNK][GDCA_HTILE];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[NP][WCHUNK][GDCA_HTILE];
     __shared__ int rc[GDCA_HTILE], cc[GDCA_HTILE];
+    __shared__ int ncand;
+    __shared__ unsigned short cand_list[(NP < NPLANES && !PROBE) ? HAM_CAND_CAP : 1];
 
     int I, J;
-    tri_decode(blockIdx.x, Mt, I, J);
+    tri_decode(PROBE ? (int)(((long long)blockIdx.x * tile_stride) % ((long long)Mt * (Mt + 1) / 2)) : (int)blockIdx.x, Mt, I, J);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     if (tid < GDCA_HTILE) {
         rc[tid] = 0;
         cc[tid] = 0;
     }
+    if (tid == 0) ncand = 0;
 
     uint32_t acc[8][8];
 #pragma unroll
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
         __syncthreads();
         // stage: per plane a contiguous run of WCHUNK*128 dwords = 4 KB = 256 threads x 16 B
 #pragma unroll
-        for (int p = 0; p < NPLANES; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int wl = tid >> 5;  // dword row inside the chunk (32 threads x 16 B = 128 dwords)
             uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
             if (w0 + wl < NW) {
@@ -143,9 +163,9 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
         __syncthreads();
         const int wn = min(WCHUNK, NW - w0);
         for (int w = 0; w < wn; ++w) {
-            uint32_t a[NPLANES][8], b[NPLANES][8];
+            uint32_t a[NP][8], b[NP][8];
 #pragma unroll
-            for (int p = 0; p < NPLANES; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const uint4 a0 = *reinterpret_cast<const uint4 *>(&As[p][w][ty * 8]);
                 const uint4 a1 = *reinterpret_cast<const uint4 *>(&As[p][w][ty * 8 + 4]);
                 const uint4 b0 = *reinterpret_cast<const uint4 *>(&Bs[p][w][tx * 4]);
@@ -161,14 +181,13 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
                 for (int c = 0; c < 8; ++c) {
                     uint32_t x = a[0][r] ^ b[0][c];
 #pragma unroll
-                    for (int p = 1; p < NPLANES; ++p)  // x |= a ^ b as one v_bitop3_b32 (table 0xBE)
+                    for (int p = 1; p < NP; ++p)  // x |= a ^ b as one v_bitop3_b32 (table 0xBE)
                         x = __builtin_amdgcn_bitop3_b32(a[p][r], b[p][c], x, 0xBE);
                     acc[r][c] += __builtin_popcount(x);
                 }
         }
         // early exit: distances only grow, so once every pair of the tile is at or beyond the
-        // threshold no later position can make it a neighbour (unrelated sequences differ at
-        // ~2/3 of the positions: most tiles stop after ~60 % of the alignment)
+        // threshold no later position can make it a neighbour
         if (w0 + WCHUNK < NW) {
             uint32_t mn = acc[0][0];
 #pragma unroll
@@ -179,13 +198,85 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
         }
     }
 
+    const bool diag = (I == J);
+    if constexpr (PROBE) {
+        // how many pairs of this tile would have to be refined
+        int cand = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
+                cand += (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh);
+            }
+        if (cand) atomicAdd(&rc[0], cand);
+        __syncthreads();
+        if (tid == 0 && rc[0]) atomicAdd(&sc->ham_cand, rc[0]);
+        return;
+    }
+    unsigned long long cand = 0ull;  // bit 8 r + c: pair (r, c) of this thread's micro-tile is a candidate (bound below the threshold)
+    if constexpr (NP < NPLANES) {
+        // candidates -> the tile's list in LDS (the bound can only be too small, so nothing else can be a neighbour); they are
+        // counted by the refinement below and skipped by their owner's own count.  A tile with more candidates than the list
+        // holds (a dense corner of a sparse family) takes several passes.
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
+                if ((int)acc[r][c] < thresh && gr < M && gc < M && gr != gc) cand |= 1ull << (8 * r + c);
+            }
+        unsigned long long todo = cand;
+        for (;;) {
+            while (todo) {
+                const int e = __builtin_ctzll(todo), r = e >> 3, c = e & 7;
+                const int slot = atomicAdd(&ncand, 1);
+                if (slot >= HAM_CAND_CAP) break;  // next pass
+                cand_list[slot] = (unsigned short)(((ty * 8 + r) << 8) | ((c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4))));
+                todo &= todo - 1;
+            }
+            __syncthreads();
+            const int total = ncand, nc = min(total, HAM_CAND_CAP), sub = tid & 15;
+            // exact distances of the listed pairs: 16 lanes per pair, lane <-> dword of 32 positions (dwords 16.. in further trips)
+            for (int e = tid >> 4; e < ((nc + 15) & ~15); e += 16) {  // (trip count uniform per wave: the shuffles need all lanes)
+                uint32_t d = 0;
+                int ka = 0, kb = 0;
+                if (e < nc) {
+                    const unsigned pr = cand_list[e];
+                    ka = (int)(pr >> 8);
+                    kb = (int)(pr & 255u);
+                    for (int w = sub; w < NW; w += 16) {
+                        uint32_t x = 0;
+#pragma unroll
+                        for (int p = 0; p < NPLANES; ++p)
+                            x |= Ag[((size_t)p * NW + w) * GDCA_HTILE + ka] ^ Bg[((size_t)p * NW + w) * GDCA_HTILE + kb];
+                        d += __builtin_popcount(x);
+                    }
+                }
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                d += __shfl_xor(d, 4);
+                d += __shfl_xor(d, 8);
+                if (e < nc && sub == 0 && (int)d < thresh) {
+                    atomicAdd(&rc[ka], 1);
+                    if (I != J) atomicAdd(&cc[kb], 1);
+                }
+            }
+            if (total <= HAM_CAND_CAP) break;
+            __syncthreads();  // everybody has read the count and the list
+            if (tid == 0) ncand = 0;
+            __syncthreads();
+        }
+    }
+
     // threshold, count (strict '<'), reduce over the workgroup
     int rowc[8], colc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) rowc[r] = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) colc[c] = 0;
-    const bool diag = (I == J);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int gr = I * GDCA_HTILE + ty * 8 + r;
@@ -193,7 +284,7 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
         for (int c = 0; c < 8; ++c) {
             const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
             const int gc = J * GDCA_HTILE + lc;
-            const bool ok = (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh);
+            const bool ok = (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh) && !((cand >> (8 * r + c)) & 1ull);
             rowc[r] += ok ? 1 : 0;
             colc[c] += ok ? 1 : 0;
         }
@@ -218,12 +309,31 @@ __global__ __launch_bounds__(256) void k_hamming(const uint32_t *__restrict__ Zb
     }
 }
 
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M,
-                         const gdca_dev_scalars *sc)
+// sc->ham_mode from the sample: 1 (lower bound first) if fewer than 1 pair in 1000 of the sampled tiles is a candidate -- beyond
+// that the refinement costs more than the two instructions per word the bound saves
+__global__ void k_hamming_decide(gdca_dev_scalars *sc, long long sampled_pairs, int force)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        sc->ham_mode = force >= 0 ? force : ((double)sc->ham_cand < 1e-3 * (double)sampled_pairs ? 1 : 0);
+}
+
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
     const long long ntile = (long long)Mt * (Mt + 1) / 2;
-    hipLaunchKernelGGL(k_hamming, dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+    // GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a sample of tiles
+    const char *env = getenv("GDCA_HAMMING_MODE");
+    const int force = !env ? -1 : (env[0] == 'f' ? 0 : (env[0] == 'b' ? 1 : -1));
+    const int nprobe = (int)std::min<long long>(ntile, 192);
+    if (force < 0 && ntile >= 64) {
+        // a prime stride walks the triangle's tiles evenly
+        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 7919);
+        hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1);
+    } else {
+        hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, 1ll, force < 0 ? 0 : force);  // tiny families: the exact form
+    }
+    hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 1);
+    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 1);
 }
 
 // ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------

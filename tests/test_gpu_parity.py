@@ -86,6 +86,32 @@ def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refda
         assert np.array_equal(n_fb, n_bs) and np.array_equal(n_fb, o.neighbour_counts(Zo, thr)), (M, N, q)
 
 
+def test_hamming_lower_bound_form_counts_exactly(g, ctx, o, monkeypatch):
+    """The reweighting kernel has two forms (csrc/k_hamming.hip): exact distances on all five bit planes, and a two-plane
+    lower bound followed by exact refinement of the few pairs the bound does not rule out; a sample of tiles decides per family
+    (dense families keep the exact form).  All three settings -- forced exact, forced bound, automatic -- must give the same
+    neighbour counts, bit for bit, as the oracle: on unrelated random sequences, on a clustered synthetic family (the
+    benchmark's generator), on a DENSE family in which every pair is a neighbour (every pair a candidate: the worst case of the
+    bound), on awkward sizes and at thresholds around the bound's blind spot."""
+    from gaussdca.jl_amd import synth
+
+    rng = np.random.default_rng(23)
+    root = rng.integers(1, 21, size=300).astype(np.int8)
+    dense = np.tile(root, (700, 1))
+    flip = rng.random(dense.shape) < 0.05
+    dense[flip] = rng.integers(1, 22, size=int(flip.sum())).astype(np.int8)
+    cases = [("random", random_msa(rng, 1500, 90, 21), 40), ("random_q5", random_msa(rng, 400, 33, 5), 25),
+             ("clustered", synth.synth_family(200, 9000, 21, 0xC0DE), 70), ("clustered_low_thr", synth.synth_family(64, 3000, 21, 7), 3),
+             ("dense", dense, 100), ("tiny", random_msa(rng, 70, 9, 21), 5)]
+    for name, Zo, thr in cases:
+        Z = np.asfortranarray(Zo.T)
+        want = o.neighbour_counts(Zo, thr)
+        for mode in ("full", "bound", "auto"):
+            monkeypatch.setenv("GDCA_HAMMING_MODE", mode)
+            assert np.array_equal(g.neighbour_counts(Z, thr, ctx=ctx), want), (name, mode)
+    monkeypatch.delenv("GDCA_HAMMING_MODE")
+
+
 def test_gdca_matches_oracle_ranking_order(g, ctx, o, refdata):
     """Ranking indices identical to the oracle's on test/data (no ties on `small`)."""
     f = os.path.join(refdata, "small.fasta.gz")
