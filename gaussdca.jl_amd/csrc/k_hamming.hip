@@ -115,7 +115,7 @@ __device__ __forceinline__ void tri_decode(int t, int Mt, int &I, int &J)
 
 template <int NP, bool PROBE>
 __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
-                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc, int tile_stride)
+                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc)
 {
     const int thresh = sc->thresh;
     if (thresh <= 0) return;  // theta == 0 (or floor(theta N) == 0): every n_k = 1
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
     __shared__ unsigned short cand_list[(NP < NPLANES && !PROBE) ? HAM_CAND_CAP : 1];
 
     int I, J;
-    tri_decode(PROBE ? (int)(((long long)blockIdx.x * tile_stride) % ((long long)Mt * (Mt + 1) / 2)) : (int)blockIdx.x, Mt, I, J);
+    // (PROBE: gridDim.x tiles spread evenly over the upper triangle's Mt (Mt + 1) / 2)
+    tri_decode(PROBE ? (int)(((long long)blockIdx.x * ((long long)Mt * (Mt + 1) / 2)) / gridDim.x) : (int)blockIdx.x, Mt, I, J);
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     if (tid < GDCA_HTILE) {
         rc[tid] = 0;
@@ -326,14 +327,13 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N,
     const int force = !env ? -1 : (env[0] == 'f' ? 0 : (env[0] == 'b' ? 1 : -1));
     const int nprobe = (int)std::min<long long>(ntile, 192);
     if (force < 0 && ntile >= 64) {
-        // a prime stride walks the triangle's tiles evenly
-        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 7919);
+        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1);
     } else {
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, 1ll, force < 0 ? 0 : force);  // tiny families: the exact form
     }
-    hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 1);
-    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, 1);
+    hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
 }
 
 // ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------

@@ -158,6 +158,17 @@ __device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_
     MicroStep<0>::run(v, l15, lq, colsrc, index_base, badj);
 }
 
+#ifdef GDCA_PIVOT_STAMPS
+// tools/test_pivot.hip only: shader-clock stamps of the phases of pivot_block, [micro-block + 1][phase][wave]
+__device__ long long g_pivot_stamps[9 * 8 * 12];
+#define PV_STAMP(K, ph)                                                                      \
+    do {                                                                                      \
+        if (lane == 0) g_pivot_stamps[(((K) + 1) * 8 + (ph)) * 12 + wv] = (long long)clock64(); \
+    } while (0)
+#else
+#define PV_STAMP(K, ph) do { } while (0)
+#endif
+
 // The blocked sweep as a device routine for NW waves holding NT tiles each (NW * NT = 36): NW = 12, NT = 3 (a whole CU
 // for the pivot: the stand-alone kernel) or NW = 4, NT = 9 (one 256-thread workgroup of the persistent sweep kernel).
 // Ain (ld = ldin) is read, Aout (ld = ldout) receives -P; the two may be the same tile.  Gs, Ns: MB * PV_ROW doubles of
@@ -227,6 +238,7 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
             trb[0] = tcb[0] = trb[1];
             trb[1] = tcb[1] = x;
         }
+        PV_STAMP(K, 0);
         if (K >= 0) {
             // ---- phase A: the old column block K into Gs ([kk][row]) ----
 #pragma unroll
@@ -239,7 +251,9 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
                     for (int reg = 0; reg < 4; ++reg) Gs[pv_off(l15) + MB * tcb[t] + lq + 4 * reg] = acc[t][reg];
                 }
             }
+            PV_STAMP(K, 1);
             __syncthreads();  // Gs complete; Pms[K & 1] (written in the previous update phase) visible
+            PV_STAMP(K, 2);
             // ---- phase B: Ns = -(G Pm) for the row blocks != K; the rows of micro-block K of both images ----
             for (int rb = wv; rb < NMB; rb += NW) {
                 if (rb == K) continue;
@@ -269,7 +283,9 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
                     Ns[pv_off(kk) + MB * K + l15] = -Pms[K & 1][lo][hi];       // +Pm(l15, kk)
                 }
             }
+            PV_STAMP(K, 3);
             __syncthreads();
+            PV_STAMP(K, 4);
         }
         // ---- phase C: every tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T ----
         auto update_tile = [&](int t) {
@@ -288,6 +304,7 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
             for (int reg = 0; reg < 4; ++reg) acc[t][reg] = c4[reg];
         };
         if (K >= 0) update_tile(0);
+        PV_STAMP(K, 5);
         if (K + 1 < NMB && wv == (NW == 12 ? K + 1 : ((K + 1) & 3))) {
             // look-ahead: the next micro-pivot, beside the other waves' updates
             double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
@@ -295,9 +312,11 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
         }
+        PV_STAMP(K, 6);
         if (K >= 0) {
 #pragma unroll
             for (int t = 1; t < NT; ++t) update_tile(t);
+            PV_STAMP(K, 7);
             __syncthreads();
         }
     }

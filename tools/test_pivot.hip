@@ -4,7 +4,39 @@
 #include <cmath>
 #include <vector>
 #include <random>
+#define GDCA_PIVOT_STAMPS
 #include "../gaussdca.jl_amd/csrc/k_inverse.hip"
+
+// the form the persistent sweep kernel runs: one 256-thread workgroup, nine micro-tiles per wave
+__global__ __launch_bounds__(256) void k_pivot4(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
+                                                size_t pld)
+{
+    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
+    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];
+    __shared__ int badj;
+    if (threadIdx.x == 0) badj = 0;
+    __syncthreads();
+    pivot_block<4, 9>(Ain, ldin, Aout, ldout, P, pld, Gs, Ns, Pms, &badj);
+}
+
+static void print_stamps(int nw)
+{
+    long long h[9 * 8 * 12];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pivot_stamps), sizeof(h));
+    auto at = [&](int K, int ph, int w) { return h[((K + 1) * 8 + ph) * 12 + w]; };
+    const long long t0 = at(-1, 0, 0);
+    printf("# shader-clock cycles since the loop's first stamp; phases: 0 top, 1 A stored, 2 A barrier, 3 B done, 4 B barrier, 5 tile 0 updated, 6 micro-pivot done, 7 tiles done\n");
+    for (int K = -1; K < 8; ++K) {
+        const int owner = nw == 12 ? K + 1 : ((K + 1) & 3);
+        const int other = (owner + 1) % 4;
+        printf("K %2d owner w%d:", K, owner);
+        for (int ph = 0; ph < 8; ++ph) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 4) || (K < 0 && ph == 7) ? -1 : at(K, ph, owner < nw ? owner : 0) - t0);
+        printf("   other w%d:", other);
+        for (int ph = 0; ph < 8; ++ph) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 4) || (K < 0 && ph == 7) ? -1 : at(K, ph, other) - t0);
+        printf("\n");
+    }
+}
 
 static void host_inverse(const std::vector<double> &A, std::vector<double> &X, int n)
 {
@@ -109,6 +141,29 @@ int main()
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
             printf("k_pivot: %.1f us per launch (50 back-to-back launches, idle chip)\n", ms * 1000 / 50);
+        }
+        print_stamps(12);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
+            hipEventRecord(e0, 0);
+            for (int it = 0; it < 50; ++it)
+                hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("k_pivot4 (256 threads): %.1f us per launch (50 back-to-back launches, idle chip)\n", ms * 1000 / 50);
+        }
+        print_stamps(4);
+        {
+            // the 256-thread form is correct too
+            hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n);
+            std::vector<double> P((size_t)n * n);
+            hipMemcpy(P.data(), dP2, P.size() * 8, hipMemcpyDeviceToHost);
+            double eP = 0;
+            for (size_t i = 0; i < P.size(); ++i) eP = std::fmax(eP, std::fabs(P[i] - Xr[i]));
+            printf("k_pivot4 relerr P %.2e\n", eP / xmax);
         }
     }
     return 0;
