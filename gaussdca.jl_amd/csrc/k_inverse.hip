@@ -108,26 +108,28 @@ __device__ __forceinline__ double read_lane_f64(double v)
 // the pivot row's entries D[JJ][j] by DPP broadcasts inside the lane's own row of 16, the pivot itself by v_readlane.
 template <int JJ>
 struct MicroStep {
-    static __device__ __forceinline__ void run(double (&v)[4], int l15, int lq, const int (&colsrc)[4], int index_base,
-                                               int *badj)
+    static __device__ __forceinline__ void run(double (&v)[4], int l15, int lq, int index_base, int *badj)
     {
+        // lanes with lq == JJ & 3 hold column JJ, D[l15][JJ] (= D[JJ][l15]: the tile is kept symmetric), in register JJ >> 2: they
+        // are the k = JJ & 3 slice of both MFMA operands, the other three k slices are zero -- the rank-one update
+        // v <- [row or column JJ ? 0 : v] - u w^T, u_i = (i == JJ ? -1 : D[i][JJ]), w_j = (j == JJ ? -p : D[JJ][j] p), is ONE
+        // v_mfma_f64_16x16x4_f64 and needs no cross-lane traffic beyond the v_readlane of the pivot
         const double col = v[JJ >> 2];
-        const double ui = shfl_f64(col, colsrc[JJ & 3]);
         const double d = read_lane_f64<(JJ & 3) * 16 + JJ>(col);
         if (!(d > 0.0) && *badj == 0) *badj = index_base + JJ + 1;
         double p = __builtin_amdgcn_rcp(d);
         p = fma(p, fma(-d, p, 1.0), p);
         p = fma(p, fma(-d, p, 1.0), p);
-        const double u = (l15 == JJ) ? -1.0 : ui;
+        const bool sel = lq == (JJ & 3);
+        const double b = sel ? (l15 == JJ ? 1.0 : -col) : 0.0;       // -u_i, i = l15
+        const double a = sel ? (l15 == JJ ? -p : col * p) : 0.0;     // w_j, j = l15
+        double4_t c;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int j = lq + 4 * reg;
-            const double uj = row_bcast_f64<JJ>(v[reg]);  // D[JJ][j]
-            const double w = (j == JJ) ? -p : uj * p;
-            const double base = (l15 == JJ || j == JJ) ? 0.0 : v[reg];
-            v[reg] = fma(-u, w, base);
-        }
-        if constexpr (JJ + 1 < MB) MicroStep<JJ + 1>::run(v, l15, lq, colsrc, index_base, badj);
+        for (int reg = 0; reg < 4; ++reg) c[reg] = (l15 == JJ || lq + 4 * reg == JJ) ? 0.0 : v[reg];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) v[reg] = c[reg];
+        if constexpr (JJ + 1 < MB) MicroStep<JJ + 1>::run(v, l15, lq, index_base, badj);
     }
 };
 
@@ -152,10 +154,7 @@ __device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_
         for (int reg = 0; reg < 4; ++reg)
             if (l15 < lq + 4 * reg) v[reg] = s[reg];
     }
-    int colsrc[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) colsrc[h] = h * 16 + l15;
-    MicroStep<0>::run(v, l15, lq, colsrc, index_base, badj);
+    MicroStep<0>::run(v, l15, lq, index_base, badj);
 }
 
 #ifdef GDCA_PIVOT_STAMPS
@@ -337,6 +336,280 @@ __device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, doub
                 }
             }
         }
+}
+
+// ---- the form the persistent sweep kernel runs: ONE 256-thread workgroup, the serial chain on a wave of its own ----
+// The only serial part of the blocked sweep is  micro-pivot(K) -> N_{K+1} = -(G_{K+1} Pm) -> tile (K+1, K+1) += G_{K+1} N_{K+1}^T ->
+// micro-pivot(K+1),  and all of it stays inside ONE wave's registers: -Pm in accumulator layout IS the MFMA operand of the first
+// product, its result IS the operand of the second (out(l15, lq + 4 reg) = sum_kk b(l15, kk) a(lq + 4 reg, kk) with operand element
+// (l15, kk = lq + 4 t4) in register t4: operand layout = accumulator layout).  So wave 3 (the chain wave) does nothing else, and
+// waves 0-2 (the workers, 12 of the 36 lower-triangular micro-tiles each) do everything that is not on the chain beside it:
+//      window 1 (after barrier 1):  chain: the two products for tile (K+1, K+1)      workers: Ns = -(G Pm), rows K := +Pm; Gs rows K := -I
+//      window 2 (after barrier 2):  chain: micro-pivot(K+1), -Pm(K+1) -> Pms         workers: 12 tile updates each, then column block
+//                                                                                     K+1 -> the OTHER Gs image, tile (K+2, K+2) -> Dt
+// Two barriers per micro-block; per micro-block the longer of (micro-pivot, 12 tile updates) instead of their sum plus the rest.
+// LDS (doubles): bufA = Gs image 0 | Ns rows kk < 8 | Pms | Dt | flag,  bufB = Gs image 1 | Ns rows kk >= 8  (two buffers of
+// 2 KC LDS_LD doubles: the staging arrays of the tile paths).
+#define PVC_NS_OFF (MB * PV_ROW)
+#define PVC_PMS_OFF (PVC_NS_OFF + (MB / 2) * PV_ROW)
+#define PVC_DT_OFF (PVC_PMS_OFF + MB * MB)
+#define PVC_FLAG_OFF (PVC_DT_OFF + MB * MB)
+#define PVC_NT 12
+
+// One step of the 16 x 16 sweep as ONE MFMA, bad pivots remembered in a scalar (first one wins).
+template <int JJ>
+struct ChainStep {
+    static __device__ __forceinline__ void run(double4_t &v, int l15, int lq, int index_base, int &bad)
+    {
+        // lanes with lq == JJ & 3 hold column JJ, D[l15][JJ] (= D[JJ][l15] up to rounding), in register JJ >> 2: they are the
+        // k = JJ & 3 slice of both operands, the other slices are zero:  v <- [row or column JJ ? 0 : v] - u w^T,
+        // u_i = (i == JJ ? -1 : D[i][JJ]),  w_j = (j == JJ ? -p : D[j][JJ] p)
+        const double col = v[JJ >> 2];
+        const double d = read_lane_f64<(JJ & 3) * 16 + JJ>(col);
+        bad = (bad == 0 && !(d > 0.0)) ? index_base + JJ + 1 : bad;
+        double p = __builtin_amdgcn_rcp(d);
+        p = fma(p, fma(-d, p, 1.0), p);
+        p = fma(p, fma(-d, p, 1.0), p);
+        const bool sel = lq == (JJ & 3);
+        const double cm = (l15 == JJ) ? -1.0 : col;
+        const double b = sel ? -cm : 0.0;      // -u_i, i = l15
+        const double a = sel ? cm * p : 0.0;   // w_j, j = l15
+        double4_t c;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c[reg] = (l15 == JJ || (reg == (JJ >> 2) && sel)) ? 0.0 : v[reg];
+        v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        if constexpr (JJ + 1 < MB) ChainStep<JJ + 1>::run(v, l15, lq, index_base, bad);
+    }
+};
+
+// tile e of the lower triangle <-> (rb, cb), rb >= cb, e = rb (rb + 1) / 2 + cb; worker W owns e = 3 t + W, t = 0 .. 11 (compile-time
+// per worker: the LDS addresses of its operand reads are immediates, and nothing per tile stays in registers but the tile)
+__device__ __forceinline__ constexpr int pvc_rb(int e)
+{
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    return r;
+}
+__device__ __forceinline__ constexpr int pvc_cb(int e)
+{
+    return e - pvc_rb(e) * (pvc_rb(e) + 1) / 2;
+}
+
+// bufA = base, bufB = base + 2 KC LDS_LD: ONE LDS array (so that every access stays a ds_ instruction off one base register)
+#define PVC_B_OFF (2 * KC * LDS_LD)
+struct PivotBufs {
+    double *A;
+    __device__ __forceinline__ double *gs(int K) const { return A + (K & 1) * PVC_B_OFF; }
+    // Ns(., kk): the half (kk >= 8) is known at compile time at every use
+    __device__ __forceinline__ double *ns(int hi, int kk) const
+    {
+        return A + hi * PVC_B_OFF + PVC_NS_OFF + (kk & 7) * PV_ROW + 16 * (kk & 1) + 2 * (kk >> 1);
+    }
+    __device__ __forceinline__ double *pms() const { return A + PVC_PMS_OFF; }
+    __device__ __forceinline__ double *dt() const { return A + PVC_DT_OFF; }
+};
+
+__device__ __forceinline__ double4_t pvc_load_tile(const double *Ain, size_t ldin, int rb, int cb, int l15, int lq)
+{
+    double4_t x;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        int r = MB * rb + l15, c = MB * cb + lq + 4 * reg;
+        if (r < c) {
+            const int y = r;
+            r = c;
+            c = y;
+        }
+        x[reg] = Ain[(size_t)r + (size_t)c * ldin];
+    }
+    return x;
+}
+
+__device__ __forceinline__ void pivot_chain_wave(const double *Ain, size_t ldin, const PivotBufs L, int lane, int *bad_out)
+{
+    const int l15 = lane & 15, lq = lane >> 4;
+    [[maybe_unused]] const int wv = 3;
+    double *Pms = L.pms();
+    const double *Dt = L.dt();
+    double4_t v = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double4_t dt = pvc_load_tile(Ain, ldin, 0, 0, l15, lq);
+    int bad = 0;
+#pragma unroll 1
+    for (int K = -1; K < NMB; ++K) {
+        PV_STAMP(K, 0);
+        if (K >= 0) {
+            __syncthreads();  // barrier 1
+            PV_STAMP(K, 1);
+            if (K + 1 < NMB) {
+                const double *G = L.gs(K);
+                double bb[4];
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) bb[t4] = G[pv_off(4 * t4 + lq) + MB * (K + 1) + l15];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dt[reg] = Dt[64 * reg + lane];
+                double4_t g = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) g = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t4], bb[t4], g, 0, 0, 0);
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) dt = __builtin_amdgcn_mfma_f64_16x16x4f64(g[t4], bb[t4], dt, 0, 0, 0);
+            }
+            PV_STAMP(K, 2);
+            __syncthreads();  // barrier 2
+            PV_STAMP(K, 3);
+        }
+        if (K + 1 < NMB) {
+            ChainStep<0>::run(dt, l15, lq, MB * (K + 1), bad);
+            v = dt;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Pms[(lq + 4 * reg) * MB + l15] = v[reg];  // Pms[j][i] = -Pm(i, j)
+        }
+        PV_STAMP(K, 4);
+    }
+    if (lane == 0 && bad != 0) *bad_out = bad;
+}
+
+template <int W>
+__device__ __forceinline__ void pivot_worker(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
+                                             size_t pld, const PivotBufs L, int lane)
+{
+    const int l15 = lane & 15, lq = lane >> 4;
+    [[maybe_unused]] const int wv = W;
+    const double *Pms = L.pms();
+    double *Dt = L.dt();
+    double4_t acc[PVC_NT];
+#pragma unroll
+    for (int t = 0; t < PVC_NT; ++t) acc[t] = pvc_load_tile(Ain, ldin, pvc_rb(3 * t + W), pvc_cb(3 * t + W), l15, lq);
+    // tile t, final for column block Kn, into image Kn ([kk][row]: tiles below the diagonal as they are, tiles of row Kn
+    // transposed), and tile (Kn + 1, Kn + 1) -- what the chain wave completes and inverts in the next round -- into Dt
+    auto stage_column = [&](const int Kn) {  // Kn: a literal at every call (the conditions fold, only the stores remain)
+        double *Gn = L.gs(Kn);
+#pragma unroll
+        for (int t = 0; t < PVC_NT; ++t) {
+            const int rb = pvc_rb(3 * t + W), cb = pvc_cb(3 * t + W);
+            if (cb == Kn && rb > Kn) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Gn[pv_off(lq + 4 * reg) + MB * rb + l15] = acc[t][reg];
+            } else if (rb == Kn && cb < Kn) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Gn[pv_off(l15) + MB * cb + lq + 4 * reg] = acc[t][reg];
+            } else if (rb == Kn + 1 && cb == Kn + 1) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Dt[64 * reg + lane] = acc[t][reg];
+            }
+        }
+    };
+#pragma unroll 1
+    for (int K = -1; K < NMB; ++K) {
+        PV_STAMP(K, 0);
+        if (K >= 0) {
+            double *G = L.gs(K);
+            __syncthreads();  // barrier 1: Pms(K), image K and Dt are in LDS
+            PV_STAMP(K, 1);
+            // Ns = -(G Pm) for the row blocks W, W + 3, W + 6 (independent MFMA chains, interleaved); the one of block K itself is
+            // computed on whatever the image holds there and dropped
+            {
+                constexpr int NR = (NMB - W + 2) / 3;
+                double4_t g[NR];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) g[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int kk = 4 * t4 + lq;
+                    const double a = Pms[kk * MB + l15];
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) g[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, G[pv_off(kk) + MB * (W + 3 * i) + l15], g[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if (W + 3 * i != K) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) L.ns(reg >> 1, lq + 4 * reg)[MB * (W + 3 * i) + l15] = g[i][reg];
+                    }
+            }
+            if (W == 2) {
+                // the rows of micro-block K: -I in the G image, +Pm in Ns
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int kk = lq + 4 * reg;
+                    G[pv_off(kk) + MB * K + l15] = (l15 == kk) ? -1.0 : 0.0;
+                    L.ns(reg >> 1, kk)[MB * K + l15] = -Pms[kk * MB + l15];
+                }
+            }
+            PV_STAMP(K, 2);
+            __syncthreads();  // barrier 2: Ns(K) complete
+            PV_STAMP(K, 3);
+            // tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T, two tiles at a time (independent MFMA chains)
+#pragma unroll
+            for (int t = 0; t < PVC_NT; t += 2) {
+                const int rb0 = pvc_rb(3 * t + W), cb0 = pvc_cb(3 * t + W), rb1 = pvc_rb(3 * t + 3 + W), cb1 = pvc_cb(3 * t + 3 + W);
+                const bool f0 = rb0 == K || cb0 == K, f1 = rb1 == K || cb1 == K;
+                double4_t c0, c1;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    c0[reg] = f0 ? 0.0 : acc[t][reg];
+                    c1[reg] = f1 ? 0.0 : acc[t + 1][reg];
+                }
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int kk = 4 * t4 + lq;
+                    const double *N = L.ns(t4 >> 1, kk);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(N[MB * cb0 + l15], G[pv_off(kk) + MB * rb0 + l15], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(N[MB * cb1 + l15], G[pv_off(kk) + MB * rb1 + l15], c1, 0, 0, 0);
+                }
+                acc[t] = c0;
+                acc[t + 1] = c1;
+            }
+        }
+        // column block K + 1 is final: into the other image, one straight-line store sequence per value of K
+        switch (K + 1) {
+        case 0: stage_column(0); break;
+        case 1: stage_column(1); break;
+        case 2: stage_column(2); break;
+        case 3: stage_column(3); break;
+        case 4: stage_column(4); break;
+        case 5: stage_column(5); break;
+        case 6: stage_column(6); break;
+        case 7: stage_column(7); break;
+        default: break;
+        }
+        PV_STAMP(K, 5);
+    }
+    // D = -inverse (lower-triangular tiles).  P = -D and the output tile = D, both as full symmetric matrices
+#pragma unroll
+    for (int t = 0; t < PVC_NT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = MB * pvc_rb(3 * t + W) + l15, c = MB * pvc_cb(3 * t + W) + lq + 4 * reg;
+            if (r >= c) {
+                const double x = acc[t][reg];
+                P[(size_t)r + (size_t)c * pld] = -x;
+                Aout[(size_t)r + (size_t)c * ldout] = x;
+                if (r > c) {
+                    P[(size_t)c + (size_t)r * pld] = -x;
+                    Aout[(size_t)c + (size_t)r * ldout] = x;
+                }
+            }
+        }
+}
+
+// Ain (ld = ldin) is read, Aout (ld = ldout) receives -P, P (ld = pld) the inverse; Ain and Aout may be the same tile.  buf:
+// 4 KC LDS_LD doubles of LDS; *bad_out (zeroed by the caller before a barrier) receives the 1-based local index of the first
+// non-positive pivot.  The caller puts a barrier behind the call before it reads *bad_out or reuses the buffers.
+__device__ __forceinline__ void pivot_chain(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
+                                            size_t pld, double *buf, int *bad_out)
+{
+    static_assert(PVC_FLAG_OFF < 2 * KC * LDS_LD && PVC_NS_OFF + (MB / 2) * PV_ROW <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
+    const int tid = opaque_tid(), lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PivotBufs L{buf};
+    if (wv == 3)
+        pivot_chain_wave(Ain, ldin, L, lane, bad_out);
+    else if (wv == 0)
+        pivot_worker<0>(Ain, ldin, Aout, ldout, P, pld, L, lane);
+    else if (wv == 1)
+        pivot_worker<1>(Ain, ldin, Aout, ldout, P, pld, L, lane);
+    else
+        pivot_worker<2>(Ain, ldin, Aout, ldout, P, pld, L, lane);
 }
 
 // Stand-alone form (one launch = one 128 x 128 block on a whole CU): used by tools/test_pivot.hip.
@@ -1061,19 +1334,18 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     return MainItem{1, p, ii, jj};
 }
 
-// One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: operand images in the first halves
-// of Gs / Hs, Pms and the flag behind them).  ONE call site in the kernel: the unrolled 16-step micro-sweep is long.
+// One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: Gs and Hs are the two halves of ONE array,
+// see k_sweep).  ONE call site in the kernel: the unrolled 16-step micro-sweep is long.
 __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *P,
                                                       double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD], int index0, int n_real,
                                                       gdca_dev_scalars *sc)
 {
-    double *pGs = &Gs[0][0][0], *pNs = &Hs[0][0][0];
-    static_assert(MB * PV_ROW + 2 * MB * MB <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
-    double(*Pms)[MB][MB] = reinterpret_cast<double(*)[MB][MB]>(pGs + MB * PV_ROW);
-    int *badj = reinterpret_cast<int *>(pNs + MB * PV_ROW);
+    double *buf = &Gs[0][0][0];
+    (void)Hs;
+    int *badj = reinterpret_cast<int *>(buf + PVC_FLAG_OFF);
     if (threadIdx.x == 0) *badj = 0;
     __syncthreads();
-    pivot_block<4, 9>(Ain, ldin, Aout, ldout, P, (size_t)T, pGs, pNs, Pms, badj);
+    pivot_chain(Ain, ldin, Aout, ldout, P, (size_t)T, buf, badj);
     __syncthreads();
     if (threadIdx.x == 0 && *badj != 0) {
         // pivots run one after the other (each waits for the previous one's items): the first report is the smallest index
@@ -1552,8 +1824,10 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
 template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
 {
-    __shared__ __attribute__((aligned(16))) double Gs[2][KC][LDS_LD];
-    __shared__ __attribute__((aligned(16))) double Hs[2][KC][LDS_LD];
+    // ONE array: the pivot's images (pivot_chain) span both staging buffers off one base
+    __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
+    double(*const Gs)[KC][LDS_LD] = GHs;
+    double(*const Hs)[KC][LDS_LD] = GHs + 2;
     __shared__ int s_item;
 #if defined(__HIP_DEVICE_COMPILE__)
     // the descriptor is read where it lies, in the kernel-argument segment

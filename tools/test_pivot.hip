@@ -7,17 +7,12 @@
 #define GDCA_PIVOT_STAMPS
 #include "../gaussdca.jl_amd/csrc/k_inverse.hip"
 
-// the form the persistent sweep kernel runs: one 256-thread workgroup, nine micro-tiles per wave
-__global__ __launch_bounds__(256) void k_pivot4(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
-                                                size_t pld)
+// the form the persistent sweep kernel runs: one 256-thread workgroup, the serial chain on a wave of its own
+__global__ __launch_bounds__(256, 2) void k_pivot4(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
+                                                   size_t pld, int *bad)
 {
-    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];
-    __shared__ int badj;
-    if (threadIdx.x == 0) badj = 0;
-    __syncthreads();
-    pivot_block<4, 9>(Ain, ldin, Aout, ldout, P, pld, Gs, Ns, Pms, &badj);
+    __shared__ __attribute__((aligned(16))) double buf[4 * KC * LDS_LD];
+    pivot_chain(Ain, ldin, Aout, ldout, P, pld, buf, bad);
 }
 
 static void print_stamps(int nw)
@@ -25,15 +20,21 @@ static void print_stamps(int nw)
     long long h[9 * 8 * 12];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pivot_stamps), sizeof(h));
     auto at = [&](int K, int ph, int w) { return h[((K + 1) * 8 + ph) * 12 + w]; };
-    const long long t0 = at(-1, 0, 0);
-    printf("# shader-clock cycles since the loop's first stamp; phases: 0 top, 1 A stored, 2 A barrier, 3 B done, 4 B barrier, 5 tile 0 updated, 6 micro-pivot done, 7 tiles done\n");
+    if (nw == 12) {
+        const long long t0 = at(-1, 0, 0);
+        printf("# k_pivot (12 waves), shader-clock cycles: micro-block, top of the loop, end of its update phase (wave 0)\n");
+        for (int K = 0; K < 8; ++K) printf("K %d  %6lld %6lld\n", K, at(K, 0, 0) - t0, at(K, 7, 0) - t0);
+        return;
+    }
+    const long long t0 = at(-1, 0, 3);
+    printf("# pivot_chain, shader-clock cycles since the chain wave's first stamp.  chain: top, barrier 1, products done, barrier 2, micro-pivot done;"
+           "  worker 0: top, barrier 1, Ns done, barrier 2, tiles done and next column staged\n");
     for (int K = -1; K < 8; ++K) {
-        const int owner = nw == 12 ? K + 1 : ((K + 1) & 3);
-        const int other = (owner + 1) % 4;
-        printf("K %2d owner w%d:", K, owner);
-        for (int ph = 0; ph < 8; ++ph) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 4) || (K < 0 && ph == 7) ? -1 : at(K, ph, owner < nw ? owner : 0) - t0);
-        printf("   other w%d:", other);
-        for (int ph = 0; ph < 8; ++ph) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 4) || (K < 0 && ph == 7) ? -1 : at(K, ph, other) - t0);
+        printf("K %2d chain:", K);
+        for (int ph = 0; ph < 5; ++ph) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 3) ? -1 : at(K, ph, 3) - t0);
+        printf("   worker 0:");
+        for (int ph = 0; ph < 6; ++ph)
+            if (ph != 4) printf(" %6lld", (K < 0 && ph >= 1 && ph <= 3) ? -1 : at(K, ph, 0) - t0);
         printf("\n");
     }
 }
@@ -143,11 +144,14 @@ int main()
             printf("k_pivot: %.1f us per launch (50 back-to-back launches, idle chip)\n", ms * 1000 / 50);
         }
         print_stamps(12);
+        int *dbad;
+        hipMalloc(&dbad, 4);
+        hipMemset(dbad, 0, 4);
         for (int rep = 0; rep < 3; ++rep) {
             hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
             hipEventRecord(e0, 0);
             for (int it = 0; it < 50; ++it)
-                hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n);
+                hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n, dbad);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms;
@@ -158,12 +162,48 @@ int main()
         {
             // the 256-thread form is correct too
             hipMemcpy(dA, A0.data(), A0.size() * 8, hipMemcpyHostToDevice);
-            hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n);
+            hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n, dbad);
             std::vector<double> P((size_t)n * n);
             hipMemcpy(P.data(), dP2, P.size() * 8, hipMemcpyDeviceToHost);
             double eP = 0;
             for (size_t i = 0; i < P.size(); ++i) eP = std::fmax(eP, std::fabs(P[i] - Xr[i]));
-            printf("k_pivot4 relerr P %.2e\n", eP / xmax);
+            std::vector<double> Am((size_t)n * n);
+            hipMemcpy(Am.data(), dP, Am.size() * 8, hipMemcpyDeviceToHost);
+            double eA = 0, asym = 0;
+            for (size_t i = 0; i < Am.size(); ++i) eA = std::fmax(eA, std::fabs(-Am[i] - Xr[i]));
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) asym = std::fmax(asym, std::fabs(P[(size_t)i + (size_t)j * n] - P[(size_t)j + (size_t)i * n]));
+            int hb = -1;
+            hipMemcpy(&hb, dbad, 4, hipMemcpyDeviceToHost);
+            printf("k_pivot4 relerr P %.2e  Aout %.2e  asymmetry %.1e  bad %d (want 0)\n", eP / xmax, eA / xmax, asym, hb);
+            // not positive definite: leading minor 38 fails
+            std::vector<double> Ab(A0);
+            Ab[37 + 37 * (size_t)n] = -1.0;
+            hipMemcpy(dA, Ab.data(), Ab.size() * 8, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)dA, (size_t)n, dP + 0, (size_t)n, dP2, (size_t)n, dbad);
+            hipMemcpy(&hb, dbad, 4, hipMemcpyDeviceToHost);
+            printf("k_pivot4 non-PD at local index 38: bad %d (want 38)\n", hb);
+            // in place, inside a larger matrix (ld 384, block 1)
+            const int ld = 384;
+            std::vector<double> Big((size_t)ld * ld, 7.0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= i; ++j) Big[(size_t)(n + i) + (size_t)(n + j) * ld] = A0[(size_t)i + (size_t)j * n];
+            double *dBig;
+            hipMalloc(&dBig, Big.size() * 8);
+            hipMemcpy(dBig, Big.data(), Big.size() * 8, hipMemcpyHostToDevice);
+            hipMemset(dbad, 0, 4);
+            double *Akk = dBig + n + (size_t)n * ld;
+            hipLaunchKernelGGL(k_pivot4, dim3(1), dim3(256), 0, 0, (const double *)Akk, (size_t)ld, Akk, (size_t)ld, dP2, (size_t)n, dbad);
+            hipMemcpy(Big.data(), dBig, Big.size() * 8, hipMemcpyDeviceToHost);
+            double e2 = 0, outside = 0;
+            for (int i = 0; i < ld; ++i)
+                for (int j = 0; j < ld; ++j) {
+                    if (i / n == 1 && j / n == 1)
+                        e2 = std::fmax(e2, std::fabs(-Big[(size_t)i + (size_t)j * ld] - Xr[(size_t)(i - n) + (size_t)(j - n) * n]));
+                    else
+                        outside = std::fmax(outside, std::fabs(Big[(size_t)i + (size_t)j * ld] - 7.0));
+                }
+            printf("k_pivot4 in place (ld 384, block 1): relerr %.2e  touched outside %.1e\n", e2 / xmax, outside);
         }
     }
     return 0;
