@@ -1151,6 +1151,9 @@ struct SweepDesc {
     int rem_tail;          // remainder tiles of update p that are listed AFTER panel(p+1)
     int ppb;               // main-list panel items per pivot block and row: 2 (128 x 64 each) or 1 (128 x 128)
     int n_mcu;             // compute units to elect for the M list (<= 16)
+    int ring;              // Pg / panel buffers per kind: 2 (group parity) or 8 (single-block groups), see ring_panel
+    int slab;              // single-block groups: the next pivot row's panel and diagonal tile as SLAB_ITEMS fused row-slab items (0: off)
+    unsigned *sl;          // [3 ng] slab items of group p done (row b0 + 1), its xslab items, its slab items of row b0 + 2
     int n_real;
     int rl;                // real (non-padding) rows of the last block, rounded up to 16: 16 .. 128
     gdca_dev_scalars *sc;
@@ -1179,6 +1182,18 @@ __device__ __forceinline__ unsigned g_done_total(const SweepDesc &D, int p)
 {
     const int sz = g_size(D, p), pn = D.nblk - sz;
     return (unsigned)(pn * sz + (long long)pn * (pn + 1) / 2);
+}
+
+// Pg and the G / H panels of a group live in a ring of D.ring buffers indexed by the group number: 2 (parity; multi-block groups fill
+// the four panels of a slot) or, for single-block groups, 8 one-panel slots in the same memory -- the chain may then run that many
+// groups ahead of the update instead of two (on a chain-bound matrix the wait for "group p - 2 complete" was what paced it)
+__device__ __forceinline__ size_t ring_panel(const SweepDesc &D, int p)
+{
+    return D.ring == 2 ? (size_t)4 * (p & 1) : (size_t)(p % D.ring);
+}
+__device__ __forceinline__ double *ring_pg(const SweepDesc &D, int p)
+{
+    return D.ring == 2 ? ((p & 1) ? D.Pg1 : D.Pg0) : D.Pg0 + (size_t)(p % D.ring) * T * T;
 }
 
 __device__ __forceinline__ unsigned flag_load(const unsigned *p)
@@ -1284,7 +1299,9 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
 {
     if (item < D.pro) {  // panel(0): nobody is ahead of it
         const int sz0 = g_size(D, 0), nsz0 = D.ng > 1 ? g_size(D, 1) : 0;
-        return MainItem{0, 0, sz0 + nsz0 + item / (D.ppb * sz0), item % (D.ppb * sz0)};
+        const int i0 = sz0 + nsz0 + item / (D.ppb * sz0);
+        if (D.slab && i0 == 2) return MainItem{3, 0, 0, 0};  // row block b0 + 2: the chain's (sweep_slab_item, rowoff 2)
+        return MainItem{0, 0, i0, item % (D.ppb * sz0)};
     }
     while (item - D.pro >= D.item0[p + 1]) ++p;
     int e = item - D.pro - D.item0[p];
@@ -1292,8 +1309,12 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     const int nsz = p + 1 < D.ng ? g_size(D, p + 1) : 0, d0 = c0 + nsz;
     const int n2 = p + 2 < D.ng ? g_size(D, p + 2) : 0;
     const int nrest = D.nblk - sz - nsz;  // blocks outside this group and the next
-    const int n_diag2 = n2 * (n2 + 1) / 2;
+    // (between single blocks the chain itself does tiles (b0+1, b0+1), (b0+2, b0+1), (b0+2, b0+2) and the panels of row blocks
+    // b0 + 1 and b0 + 2 -- sweep_slab_item, sweep_xslab_item -- and what it waits for a step later is row block b0 + 3: its tiles
+    // (b0+3, b0+2), (b0+3, b0+3) take the early slots here, (b0+3, b0+1) is among rest(p+1))
+    const int n_diag2 = D.slab ? (b0 + 3 < D.nblk ? 2 : 0) : n2 * (n2 + 1) / 2;
     if (e < n_diag2) {
+        if (D.slab) return MainItem{4, p, b0 + 3, b0 + 2 + e};
         int mm = 0, first = 0;
         while (e >= first + (n2 - mm)) {
             first += n2 - mm;
@@ -1306,6 +1327,7 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
         const int mm = e / nrest, local = e % nrest;
         const int b = local < b0 ? local : local - b0 + d0;
         const int cb = c0 + mm;
+        if (D.slab && b == d0) return MainItem{3, p, 0, 0};  // tile (c0 + 1, c0): done on the chain (sweep_xslab_item)
         return MainItem{4, p, b > cb ? b : cb, b > cb ? cb : b};
     }
     e -= nsz * nrest;
@@ -1320,6 +1342,7 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
             const int ep = e - n_head;
             int i = ep / (D.ppb * nsz);
             if (i >= c0) i += nsz + n2;
+            if (D.slab && i == c0 + 2) return MainItem{3, p, 0, 0};  // row block b0' + 2 of group p + 1 (b0' = c0): the chain's
             return MainItem{0, p + 1, i, ep % (D.ppb * nsz)};
         }
         e -= n_pan;
@@ -1330,7 +1353,10 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     int jj = e - (int)((long long)ii * (ii + 1) / 2);
     if (ii >= b0) ii += sz + nsz;
     if (jj >= b0) jj += sz + nsz;
-    if (jj >= d0 && ii < d0 + n2) return MainItem{3, p, 0, 0};  // inside the diagonal super-block of group p+2: done as diag2
+    if (D.slab) {
+        if (jj >= d0 && ii <= d0 + 1) return MainItem{3, p, 0, 0};  // (b0+2, b0+2): the chain's; (b0+3, b0+2), (b0+3, b0+3): early slots
+    } else if (jj >= d0 && ii < d0 + n2)
+        return MainItem{3, p, 0, 0};  // inside the diagonal super-block of group p+2: done as diag2
     return MainItem{1, p, ii, jj};
 }
 
@@ -1355,7 +1381,8 @@ __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, doub
 }
 
 // ---- M(q): one item of the super-block inverse of group q -------------------------------------------------------------
-__device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD])
+__device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD],
+                                             unsigned long long *dbg_ready = nullptr)
 {
     const int tid = opaque_tid();
     const int b0 = g_start(D, q), sz = g_size(D, q), m = sz * T;
@@ -1387,9 +1414,9 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
                 ok = spin_until(D, [&] { return flag_load(genp) >= (unsigned)q; });   // the tile carries all earlier groups
             } else {
                 ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)(nm - nt); });
-                if (ok && q >= 2) {
-                    const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
-                    ok = spin_until(D, [&] { return flag_load(D.done + (q - 2)) >= want; });
+                if (ok && q >= D.ring) {
+                    const unsigned want = g_done_total(D, q - D.ring);  // the group that used this Pg slot before is complete
+                    ok = spin_until(D, [&] { return flag_load(D.done + (q - D.ring)) >= want; });
                 }
             }
         }
@@ -1422,7 +1449,7 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         } else {
             // A_gg <- -Pg (lower-triangle tiles, diagonal tiles in full), Pg <- exactly symmetric from the lower triangle
             const double *Sf = ((sz & 1) ? D.Sg1 : D.Sg0) + (size_t)ib * T + (size_t)jb * T * m;
-            double *Pg = (q & 1) ? D.Pg1 : D.Pg0;
+            double *Pg = ring_pg(D, q);
             double *Pd = Pg + (size_t)ib * T + (size_t)jb * T * m, *Pm = Pg + (size_t)jb * T + (size_t)ib * T * m;
             for (int cb = 0; cb < T; cb += KC) {
                 __syncthreads();
@@ -1465,9 +1492,9 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         if (tid == 0) {
             if (sz == 1) {
                 ok = spin_until(D, [&] { return flag_load(genp) >= (unsigned)q; });
-                if (ok && q >= 2) {
-                    const unsigned want = g_done_total(D, q - 2);  // group q-2 is complete (Pg parity reuse)
-                    ok = spin_until(D, [&] { return flag_load(D.done + (q - 2)) >= want; });
+                if (ok && q >= D.ring) {
+                    const unsigned want = g_done_total(D, q - D.ring);  // the group that used this Pg slot before is complete
+                    ok = spin_until(D, [&] { return flag_load(D.done + (q - D.ring)) >= want; });
                 }
             } else if (first_pivot) {
                 // (the tile at generation q implies that M(q-1) is complete: the scratch matrices and Pw are free)
@@ -1477,11 +1504,12 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
             }
         }
         if (!acquire_end(ok)) return;
+        if (dbg_ready && tid == 0) *dbg_ready = wall_clock64();  // trace: a pivot's start stamp becomes the end of its wait
         const size_t dd = (size_t)w * T + (size_t)w * T * m;
         const double *pin = (sz == 1 || first_pivot) ? (const double *)Agg : Sin + dd;
         double *pout = sz == 1 ? Agg : Sout + dd;
         const size_t pld_in = (sz == 1 || first_pivot) ? D.ld : (size_t)m, pld_out = sz == 1 ? D.ld : (size_t)m;
-        sweep_pivot(pin, pld_in, pout, pld_out, sz == 1 ? ((q & 1) ? D.Pg1 : D.Pg0) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
+        sweep_pivot(pin, pld_in, pout, pld_out, sz == 1 ? ring_pg(D, q) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
         publish_begin();
         if (tid == 0) {
             if (sz == 1) __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1557,8 +1585,8 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         // Pg(p); the group's columns of row i at generation p; the panel buffers of parity p free (group p-2 complete): all
         // flags of a round are loaded together
-        const unsigned want = p >= 2 ? g_done_total(D, p - 2) : 0u;
-        const unsigned *dn = D.done + (p >= 2 ? p - 2 : 0);
+        const unsigned want = p >= D.ring ? g_done_total(D, p - D.ring) : 0u;
+        const unsigned *dn = D.done + (p >= D.ring ? p - D.ring : 0);
         const unsigned *gp[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -1575,8 +1603,8 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
     }
     if (!acquire_end(ok)) return;
     const size_t ld = D.ld, pgld = (size_t)sz * T;
-    const double *Pg = (p & 1) ? D.Pg1 : D.Pg0;
-    double *G0 = D.G0 + (size_t)4 * (p & 1) * D.pstride, *H0 = D.H0 + (size_t)4 * (p & 1) * D.pstride;
+    const double *Pg = ring_pg(D, p);
+    double *G0 = D.G0 + ring_panel(D, p) * D.pstride, *H0 = D.H0 + ring_panel(D, p) * D.pstride;
     double4_t acc[TM][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -1615,6 +1643,216 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
             }
     publish_begin();
     if (tid == 0) __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + i, (unsigned)(TM / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- single-block groups: the chain between two pivots as row slabs ------------------------------------------------------------
+// With one block per group the next pivot waits for  H = -G P  (panel of its row block c0 = b0 + 1, G = A[c0, b0], P = Pg) and then for
+// its diagonal tile  C += G H^T = H G^T  (P is symmetric): two dependent 128 x 128 x 128 products, 14 us each on one compute unit at
+// the full MFMA rate, which is what the panel and tile items took.  Rows are independent in both: slab s (16 rows) needs G's 16 rows
+// and all of P for its rows of H, then those rows of H and all of G for its rows of C -- so SLAB_ITEMS workgroups do one slab each,
+// side by side, with no hand-over between the two products but a barrier inside the workgroup.  Operands come straight from L2 in
+// MFMA operand layout (8 bytes per lane: lane (l15, lq) holds element (16 blk + l15, 4 k4 + lq)); H changes hands through LDS.
+// The last slab to finish sets the flags the panel items (rb += 2) and the tile item (gen, done) would have set.
+#define SLAB_ITEMS 8
+__device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s, int rowoff, double *lds, unsigned long long *dbg_ready = nullptr)
+{
+    const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = g_start(D, p), c0 = b0 + rowoff;  // the row block: the next pivot's (rowoff 1) or the one after it (2)
+    bool ok = true;
+    if (tid == 0) {
+        const unsigned want = p >= D.ring ? g_done_total(D, p - D.ring) : 0u;
+        const unsigned *dn = D.done + (p >= D.ring ? p - D.ring : 0);
+        const unsigned *g1 = D.gen + (size_t)c0 * D.nblk + b0, *g2 = D.gen + (size_t)c0 * D.nblk + c0;
+        ok = spin_until(D, [&] {
+            const unsigned f0 = flag_load(D.mc + p), f1 = flag_load(g1), f2 = flag_load(g2), f3 = flag_load(dn);
+            return (f0 >= 1u) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= want);
+        });
+    }
+    if (!acquire_end(ok)) return;
+    if (dbg_ready && tid == 0) *dbg_ready = wall_clock64();  // trace: the item's start stamp becomes the end of its wait
+    const size_t ld = D.ld;
+    const int R0 = MB * s;
+    const double *Gt = D.A + (size_t)c0 * T + (size_t)b0 * T * ld;       // G(r, k) = Gt[r + k ld]
+    const double *P = ring_pg(D, p);                                      // P(c, k) = P[c + k T]
+    double *Ct = D.A + (size_t)c0 * T + (size_t)c0 * T * ld;
+    double *Gc = D.G0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;  // the row block's G for the tile items: Gc[r + k ld]
+    double *Hw = D.H0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;  // and its H: Hw[r + c ld]
+    double *Hl = lds;                                                     // Hl[k][r]: 128 x 16
+    // this wave's two 16-column blocks (of H in the first product, of C in the second)
+    const int cA = 32 * wv + l15;
+    // ---- H(slab, :) = -G(slab, :) P ----
+    double4_t h0 = (double4_t){0.0, 0.0, 0.0, 0.0}, h1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        const double *gp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;   // + 4 k4 ld
+        const double *pp = P + (size_t)cA + (size_t)lq * T;             // + 4 k4 T  (+ 16 for the second block)
+        double gb[2][4], pa[2][4], pb[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            gb[0][t4] = gp[(size_t)(4 * t4) * ld];
+            pa[0][t4] = pp[(size_t)(4 * t4) * T];
+            pb[0][t4] = pp[(size_t)(4 * t4) * T + 16];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NMB; ++kb) {
+            const int cur = kb & 1, nxt = cur ^ 1;
+            if (kb + 1 < NMB) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int k = 16 * (kb + 1) + 4 * t4;
+                    gb[nxt][t4] = gp[(size_t)k * ld];
+                    pa[nxt][t4] = pp[(size_t)k * T];
+                    pb[nxt][t4] = pp[(size_t)k * T + 16];
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                h0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[cur][t4], gb[cur][t4], h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[cur][t4], gb[cur][t4], h1, 0, 0, 0);
+            }
+            // the copy of G's rows for the tile items of this row block (wave kb & 3 writes the 16 k of round kb)
+            if ((kb & 3) == wv) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) store_wt(&Gc[(size_t)(R0 + l15) + (size_t)(16 * kb + 4 * t4 + lq) * ld], gb[cur][t4]);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 32 * wv + lq + 4 * reg;
+        const double x0 = -h0[reg], x1 = -h1[reg];
+        Hl[c * MB + l15] = x0;
+        Hl[(c + 16) * MB + l15] = x1;
+        store_wt(&Hw[(size_t)(R0 + l15) + (size_t)c * ld], x0);
+        store_wt(&Hw[(size_t)(R0 + l15) + (size_t)(c + 16) * ld], x1);
+    }
+    // ---- C(slab, :) += H(slab, :) G^T ----
+    double4_t c0v, c1v;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        c0v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld];
+        c1v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld];
+    }
+    {
+        const double *gq = Gt + (size_t)cA + (size_t)lq * ld;  // G(c', k), c' = this wave's columns of C
+        double ga[2][4], gb2[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            ga[0][t4] = gq[(size_t)(4 * t4) * ld];
+            gb2[0][t4] = gq[(size_t)(4 * t4) * ld + 16];
+        }
+        __syncthreads();  // H(slab, :) of all four waves is in LDS
+#pragma unroll
+        for (int kb = 0; kb < NMB; ++kb) {
+            const int cur = kb & 1, nxt = cur ^ 1;
+            if (kb + 1 < NMB) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int k = 16 * (kb + 1) + 4 * t4;
+                    ga[nxt][t4] = gq[(size_t)k * ld];
+                    gb2[nxt][t4] = gq[(size_t)k * ld + 16];
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double hb = Hl[(16 * kb + 4 * t4 + lq) * MB + l15];
+                c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[cur][t4], hb, c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(gb2[cur][t4], hb, c1v, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        store_wt(&Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld], c0v[reg]);
+        store_wt(&Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld], c1v[reg]);
+    }
+    publish_wt_begin();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(D.sl + (rowoff == 1 ? 0 : 2 * D.ng) + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == SLAB_ITEMS - 1) {
+            // every slab's stores had been drained before its increment: the row block's panels and the tile are complete
+            __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + c0, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(D.gen + (size_t)c0 * D.nblk + c0, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- single-block groups: the tile the slab items of the NEXT group wait for, one step early ---------------------------------------
+// Slab item p + 1 reads G = A[c0 + 1, c0] with update p applied.  As a tile item of the main list that tile waits for the panel item
+// of ITS row block (which copies G into the panel buffer), and that one for Pg(p): ~40 us behind the pivot -- the chain stood still
+// for them every other group.  The tile needs neither: A[c0+1, c0] += G H^T with G = A[c0+1, b0] as it lies in A (generation p: an
+// early item of update p - 1) and H = the rows the slab items of THIS group just wrote.  So it is done here, on the chain's idle
+// workgroups, as SLAB_ITEMS row slabs like the slab items' second product, while the next pivot runs; the main list skips it.
+__device__ __forceinline__ void sweep_xslab_item(const SweepDesc &D, int p, int s, unsigned long long *dbg_ready = nullptr)
+{
+    const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = g_start(D, p), c0 = b0 + 1, I = c0 + 1;
+    bool ok = true;
+    if (tid == 0) {
+        const unsigned *g1 = D.gen + (size_t)I * D.nblk + b0, *g2 = D.gen + (size_t)I * D.nblk + c0;
+        const unsigned *rbp = D.rb + (size_t)p * D.nblk + c0;
+        ok = spin_until(D, [&] {
+            const unsigned f0 = flag_load(rbp), f1 = flag_load(g1), f2 = flag_load(g2);
+            return (f0 >= 2u) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p);
+        });
+    }
+    if (!acquire_end(ok)) return;
+    if (dbg_ready && tid == 0) *dbg_ready = wall_clock64();
+    const size_t ld = D.ld;
+    const int R0 = MB * s;
+    const double *Gt = D.A + (size_t)I * T + (size_t)b0 * T * ld;                            // G(r, k) = Gt[r + k ld]
+    const double *Hw = D.H0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;                  // H(c, k) = Hw[c + k ld]
+    double *Xt = D.A + (size_t)I * T + (size_t)c0 * T * ld;
+    double4_t x0, x1;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        x0[reg] = Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld];
+        x1[reg] = Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld];
+    }
+    {
+        const double *gp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;
+        const double *hp = Hw + (size_t)(32 * wv + l15) + (size_t)lq * ld;
+        double gb[2][4], ha[2][4], hb[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            gb[0][t4] = gp[(size_t)(4 * t4) * ld];
+            ha[0][t4] = hp[(size_t)(4 * t4) * ld];
+            hb[0][t4] = hp[(size_t)(4 * t4) * ld + 16];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NMB; ++kb) {
+            const int cur = kb & 1, nxt = cur ^ 1;
+            if (kb + 1 < NMB) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int k = 16 * (kb + 1) + 4 * t4;
+                    gb[nxt][t4] = gp[(size_t)k * ld];
+                    ha[nxt][t4] = hp[(size_t)k * ld];
+                    hb[nxt][t4] = hp[(size_t)k * ld + 16];
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[cur][t4], gb[cur][t4], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hb[cur][t4], gb[cur][t4], x1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        store_wt(&Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld], x0[reg]);
+        store_wt(&Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld], x1[reg]);
+    }
+    publish_wt_begin();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(D.sl + D.ng + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == SLAB_ITEMS - 1) {
+            __hip_atomic_store(D.gen + (size_t)I * D.nblk + c0, (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(D.done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---- one tile of update p:  A_IJ += sum_w G_w[I] H_w[J]^T ------------------------------------------------------------------
@@ -1675,7 +1913,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     if (!tile_item_wait(D, p, I, J, ready)) return;
     const size_t ld = D.ld, pld = D.ld;
-    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride;
+    const double *Gp = D.G0 + ring_panel(D, p) * D.pstride, *Hp = D.H0 + ring_panel(D, p) * D.pstride;
     double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
     double4_t acc[4][4];
 #pragma unroll
@@ -1753,7 +1991,7 @@ __device__ __forceinline__ void sweep_tile_item_ragged(const SweepDesc &D, int p
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     if (!tile_item_wait(D, p, I, J, ready)) return;
     const size_t ld = D.ld, pld = D.ld;
-    const double *Gp = D.G0 + (size_t)4 * (p & 1) * D.pstride + (size_t)I * T, *Hp = D.H0 + (size_t)4 * (p & 1) * D.pstride + (size_t)J * T;
+    const double *Gp = D.G0 + ring_panel(D, p) * D.pstride + (size_t)I * T, *Hp = D.H0 + ring_panel(D, p) * D.pstride + (size_t)J * T;
     double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
     const int ntn = min(4, max(0, (D.rl - wr * 64) / 16));  // 16-row blocks of this wave's 64 rows that hold real rows
     const int nch = g_chunks(D, p);
@@ -1810,9 +2048,17 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
     if (i >= b0) i += sz;
     const int k = b0 + w;
     bool ok = true;
-    if (tid == 0) ok = spin_until(D, [&] { return flag_load(D.rb + (size_t)p * D.nblk + i) >= 2u * (unsigned)sz; });
+    if (tid == 0) {
+        // (between single blocks the chain's xslab items of this group read row block b0 + 2 of the column in place: not before they are done)
+        const bool after_x = D.slab && i == b0 + 2;
+        const unsigned *gx = D.gen + (size_t)i * D.nblk + (after_x ? b0 + 1 : 0);
+        ok = spin_until(D, [&] {
+            const unsigned f0 = flag_load(D.rb + (size_t)p * D.nblk + i), f1 = flag_load(gx);
+            return (f0 >= 2u * (unsigned)sz) & (!after_x | (f1 >= (unsigned)(p + 1)));
+        });
+    }
     if (!acquire_end(ok)) return;
-    panel_writeback_tile(D.A, D.ld, k, i, D.H0 + (size_t)(4 * (p & 1) + w) * D.pstride, D.ld, Gs[0]);
+    panel_writeback_tile(D.A, D.ld, k, i, D.H0 + (ring_panel(D, p) + w) * D.pstride, D.ld, Gs[0]);
     publish_begin();
     if (tid == 0) {
         const int I = i > k ? i : k, J = i > k ? k : i;
@@ -1888,11 +2134,21 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
             const int nm = m_items(sz);
             if (e < nm) {
-                sweep_m_item(D, q, e, Gs, Hs);
+                sweep_m_item(D, q, e, Gs, Hs, D.dbg ? D.dbg + 2 * item : nullptr);
                 if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
                 continue;
             }
             e -= nm;
+            if (D.slab) {
+                if (e < SLAB_ITEMS)
+                    sweep_slab_item(D, q, e, 1, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
+                else if (e < 2 * SLAB_ITEMS)
+                    sweep_xslab_item(D, q, e - SLAB_ITEMS, D.dbg ? D.dbg + 2 * item : nullptr);
+                else
+                    sweep_slab_item(D, q, e - 2 * SLAB_ITEMS, 2, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
+                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+                continue;
+            }
             // the next group's rows, one after the other: the 2 sz panel items of row rr, then the tiles (rr, 0 .. rr) of its
             // diagonal super-block -- its FIRST diagonal tile, which the next group's first pivot waits for, is complete after one
             // round of panel items instead of after all of them
@@ -1982,9 +2238,9 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
 size_t gdca_inverse_flag_bytes(int n_pad)
 {
     const size_t nblk = (size_t)(n_pad / T);
-    // gen, rb (ng <= nblk), mc, done | next, next_m, mcu[16], mxcc | the abort word on a 128-byte line of its own (every wait
+    // gen, rb (ng <= nblk), mc, done, sl | next, next_m, mcu[16], mxcc | the abort word on a 128-byte line of its own (every wait
     // of the kernel reads it; the line of the item counters is busy with atomics)
-    return (nblk * nblk + nblk * nblk + 2 * nblk + 96) * sizeof(unsigned);
+    return (nblk * nblk + nblk * nblk + 5 * nblk + 96) * sizeof(unsigned);
 }
 
 // Host side: the item table, the flags, one launch.
@@ -2045,14 +2301,24 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // three and four), two 128 x 64 halves where their latency counts
     static const int ppb_env = getenv("GDCA_PANEL_HALVES") ? atoi(getenv("GDCA_PANEL_HALVES")) : -1;
     const int ppb = ppb_env >= 0 ? (ppb_env ? 2 : 1) : (g >= 3 ? 1 : 2);
+    // single-block groups: the chain between two pivots as fused row-slab items (sweep_slab_item; GDCA_SLAB=0: panel and tile items)
+    static const int slab_env = getenv("GDCA_SLAB") ? atoi(getenv("GDCA_SLAB")) : 1;
+    bool slab = slab_env != 0;
+    bool single = true;
+    for (int p = 0; p < ng; ++p) single = single && size(p) == 1;
+    slab = slab && single;
+    // buffers per kind (ring_panel): eight one-panel slots between single blocks (GDCA_RING=2: two, as for multi-block groups)
+    static const int ring_env = getenv("GDCA_RING") ? atoi(getenv("GDCA_RING")) : 8;
+    const int ring = single && ring_env >= 3 ? std::min(ring_env, 8) : 2;
     const int pro = ng > 0 ? (nblk - size(0) - (ng > 1 ? size(1) : 0)) * ppb * size(0) : 0;  // panel(0)
     for (int p = 0; p < ng; ++p) {
         it[p] = (int)pos;
         mit[p] = (int)mpos;
         const int sz = size(p), nsz = p + 1 < ng ? size(p + 1) : 0, n2 = p + 2 < ng ? size(p + 2) : 0;
         const int nrest = nblk - sz - nsz;
-        mpos += m_cnt(sz) + nsz * 2 * sz + nsz * (nsz + 1) / 2;   // M(p), the next group's panel rows, its diagonal tiles
-        pos += n2 * (n2 + 1) / 2;                                  // diag2
+        // M(p), then the next group's panel rows and its diagonal tiles -- or, between single blocks, the fused slab items
+        mpos += m_cnt(sz) + (slab ? (nsz ? SLAB_ITEMS : 0) + (n2 ? 2 * SLAB_ITEMS : 0) : nsz * 2 * sz + nsz * (nsz + 1) / 2);
+        pos += slab ? (gs[p] + 3 < nblk ? 2 : 0) : n2 * (n2 + 1) / 2;  // diag2 (between single blocks: two tiles of row block b0 + 3)
         pos += (long long)nsz * nrest;                             // rest
         pos += (long long)(nblk - sz) * sz;                        // wb
         pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
@@ -2093,6 +2359,8 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     f += ng;
     D.done = f;
     f += ng;
+    D.sl = f;
+    f += 3 * ng;
     D.next = f;
     D.next_m = f + 1;
     D.mcu = f + 2;
@@ -2112,6 +2380,8 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.pro = pro;
     D.rem_tail = rem_tail;
     D.ppb = ppb;
+    D.slab = slab ? SLAB_ITEMS : 0;
+    D.ring = ring;
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once -- the 2 (g-1)^2 half-tile jobs of a level of a four-block group are 18 -- and once the update hides the chain the
