@@ -42,23 +42,19 @@ __device__ __forceinline__ int opaque_tid()
 #define LDS_LD (T + 16)  // f64 elements per k-row in LDS (128-byte pad)
 
 // -------------------------------------------------------------------------------------------------
-// Pivot: P = inverse of a 128 x 128 SPD block by a BLOCKED symmetric sweep, one workgroup, the block's lower
-// triangle resident in MFMA accumulators for the whole kernel.
+// Pivot: P = inverse of a 128 x 128 SPD block by a BLOCKED symmetric sweep, one 256-thread workgroup, the block's lower
+// triangle resident in MFMA accumulators from the first load to the last store.
 //
-// The block is cut into 8 x 8 micro-blocks of 16 x 16; the 36 lower-triangular tiles live in the accumulators of
-// 12 waves (3 tiles each; waves 0..7 own one diagonal tile and two others).  Sweeping micro-block K
+// The block is cut into 8 x 8 micro-blocks of 16 x 16 (36 lower-triangular tiles).  Sweeping micro-block K
 //       D_ij <- D_ij - G_i Pm G_j^T   (i, j != K),   D_iK <- G_i Pm,   D_KK <- -Pm,      G = D_{.,K},  Pm = D_KK^-1
 // is, for EVERY tile, four v_mfma_f64_16x16x4_f64 on two operand images in LDS:
 //       Gs = the old column block K (128 x 16), with the rows of micro-block K replaced by -I
 //       Ns = -(G Pm)               (128 x 16), with the rows of micro-block K replaced by +Pm
 //       tile(rb, cb) <- [rb == K or cb == K ? 0 : tile] + Gs[rb] Ns[cb]^T
 // (the same -1 / -p device the scalar sweep uses for its pivot row and column), so the three kinds of tiles need
-// no special code.  The only serial part is Pm = (16 x 16 diagonal tile)^-1: a 16-step scalar sweep inside ONE
-// wave's registers (the tile is already there in accumulator layout; the pivot column travels by cross-lane
-// shuffles, no LDS round trip, no barrier), and it runs one micro-block AHEAD: in the update phase of micro-block
-// K the owner of tile (K+1, K+1) updates that tile first and inverts it at once, beside the other waves' MFMAs.
-// Per micro-block: three barriers, 12 MFMAs per wave -- 24 barrier-separated phases for the whole block instead
-// of the 128 of the element-wise sweep (measured 84 us there).
+// no special code.  The serial part -- Pm = (16 x 16 diagonal tile)^-1, sixteen dependent steps, and the two products that
+// bring the NEXT diagonal tile up to date -- runs on a wave of its own (pivot_chain below); the other three waves do every
+// other update beside it.
 //
 // Operand images are [kk][row] with a swizzled row offset (pv_off): the MFMA operand reads (16 consecutive rows of
 // two adjacent kk per 32 lanes) and the transposed stores of the tiles left of the diagonal (16 different kk, one
@@ -68,30 +64,11 @@ __device__ __forceinline__ int opaque_tid()
 // -------------------------------------------------------------------------------------------------
 #define MB 16                      // micro-block edge
 #define NMB (T / MB)               // micro-blocks per side
-#define PIVOT_THREADS 768          // 12 waves
 #define PV_ROW 160                 // doubles per kk-row of an operand image
 
 __device__ __forceinline__ int pv_off(int kk)
 {
     return kk * PV_ROW + 16 * (kk & 1) + 2 * (kk >> 1);
-}
-
-__device__ __forceinline__ double shfl_f64(double v, int src_lane)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
-    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Broadcast, inside every row of 16 lanes, the value lane J of that row holds (DPP row_newbcast: VALU speed, no LDS).
-template <int J>
-__device__ __forceinline__ double row_bcast_f64(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + J, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + J, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 template <int L>
@@ -103,62 +80,8 @@ __device__ __forceinline__ double read_lane_f64(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// One step of the 16 x 16 sweep on v[reg] = D[i = lane & 15][j = (lane >> 4) + 4 reg] (full storage).  The pivot
-// column reaches lane (i, .) by one cross-row shuffle (ds_bpermute, address colsrc[JJ & 3] = lane (JJ & 3) * 16 + i),
-// the pivot row's entries D[JJ][j] by DPP broadcasts inside the lane's own row of 16, the pivot itself by v_readlane.
-template <int JJ>
-struct MicroStep {
-    static __device__ __forceinline__ void run(double (&v)[4], int l15, int lq, int index_base, int *badj)
-    {
-        // lanes with lq == JJ & 3 hold column JJ, D[l15][JJ] (= D[JJ][l15]: the tile is kept symmetric), in register JJ >> 2: they
-        // are the k = JJ & 3 slice of both MFMA operands, the other three k slices are zero -- the rank-one update
-        // v <- [row or column JJ ? 0 : v] - u w^T, u_i = (i == JJ ? -1 : D[i][JJ]), w_j = (j == JJ ? -p : D[JJ][j] p), is ONE
-        // v_mfma_f64_16x16x4_f64 and needs no cross-lane traffic beyond the v_readlane of the pivot
-        const double col = v[JJ >> 2];
-        const double d = read_lane_f64<(JJ & 3) * 16 + JJ>(col);
-        if (!(d > 0.0) && *badj == 0) *badj = index_base + JJ + 1;
-        double p = __builtin_amdgcn_rcp(d);
-        p = fma(p, fma(-d, p, 1.0), p);
-        p = fma(p, fma(-d, p, 1.0), p);
-        const bool sel = lq == (JJ & 3);
-        const double b = sel ? (l15 == JJ ? 1.0 : -col) : 0.0;       // -u_i, i = l15
-        const double a = sel ? (l15 == JJ ? -p : col * p) : 0.0;     // w_j, j = l15
-        double4_t c;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) c[reg] = (l15 == JJ || lq + 4 * reg == JJ) ? 0.0 : v[reg];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) v[reg] = c[reg];
-        if constexpr (JJ + 1 < MB) MicroStep<JJ + 1>::run(v, l15, lq, index_base, badj);
-    }
-};
-
-// Inverse of the 16 x 16 SPD tile held by one wave as v[reg] = D[i = lane & 15][j = (lane >> 4) + 4 reg] (lower
-// triangle authoritative): on return v = -D^-1 (full storage, equal to its transpose up to rounding).
-__device__ __forceinline__ void micro_pivot(double (&v)[4], int lane, int index_base, int *badj)
-{
-    const int l15 = lane & 15, lq = lane >> 4;
-    {
-        // upper triangle := mirror of the lower: element (j, i) sits in lane (i & 3) * 16 + j, register i >> 2
-        double s[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) s[reg] = v[reg];
-#pragma unroll
-        for (int r2 = 0; r2 < 4; ++r2)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const double cand = shfl_f64(v[r2], (l15 & 3) * 16 + lq + 4 * reg);
-                if ((l15 >> 2) == r2) s[reg] = cand;
-            }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            if (l15 < lq + 4 * reg) v[reg] = s[reg];
-    }
-    MicroStep<0>::run(v, l15, lq, index_base, badj);
-}
-
 #ifdef GDCA_PIVOT_STAMPS
-// tools/test_pivot.hip only: shader-clock stamps of the phases of pivot_block, [micro-block + 1][phase][wave]
+// tools/test_pivot.hip only: shader-clock stamps of the phases of pivot_chain, [micro-block + 1][phase][wave]
 __device__ long long g_pivot_stamps[9 * 8 * 12];
 #define PV_STAMP(K, ph)                                                                      \
     do {                                                                                      \
@@ -167,176 +90,6 @@ __device__ long long g_pivot_stamps[9 * 8 * 12];
 #else
 #define PV_STAMP(K, ph) do { } while (0)
 #endif
-
-// The blocked sweep as a device routine for NW waves holding NT tiles each (NW * NT = 36): NW = 12, NT = 3 (a whole CU
-// for the pivot: the stand-alone kernel) or NW = 4, NT = 9 (one 256-thread workgroup of the persistent sweep kernel).
-// Ain (ld = ldin) is read, Aout (ld = ldout) receives -P; the two may be the same tile.  Gs, Ns: MB * PV_ROW doubles of
-// LDS each; Pms: 2 * MB * MB doubles; badj: one int, zeroed by the caller before a barrier.
-template <int NW, int NT>
-__device__ __forceinline__ void pivot_block(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
-                                            size_t pld, double *Gs, double *Ns, double (*Pms)[MB][MB], int *badj)
-{
-    static_assert(NW * NT == 36 && (NW == 12 || NW == 4), "36 lower-triangular micro-tiles");
-    const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // off-diagonal tile e <-> (rb, cb), rb > cb, e = rb (rb-1) / 2 + cb
-    auto offdiag = [](int e, int &rb, int &cb) {
-        int r = 1;
-        while ((r + 1) * r / 2 <= e) ++r;
-        rb = r;
-        cb = e - r * (r - 1) / 2;
-    };
-    // tile ownership.  NW = 12: waves 0..7 own (w, w) + off-diagonal tiles 2w, 2w+1; waves 8..11 three off-diagonal tiles.
-    // NW = 4: wave w owns (w, w), (w+4, w+4) and off-diagonal tiles 7w .. 7w+6.  Slot 0 is always the diagonal tile whose
-    // micro-pivot this wave computes next (NW = 4: slots 0 and 1 are swapped once the first one has been used).
-    int trb[NT], tcb[NT];
-    if (NW == 12) {
-        if (wv < NMB) {
-            trb[0] = tcb[0] = wv;
-            offdiag(2 * wv, trb[1], tcb[1]);
-            offdiag(2 * wv + 1, trb[2], tcb[2]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) offdiag(16 + 3 * (wv - NMB) + t, trb[t], tcb[t]);
-        }
-    } else {
-        trb[0] = tcb[0] = wv;
-        trb[1] = tcb[1] = wv + 4;
-#pragma unroll
-        for (int t = 2; t < NT; ++t) offdiag(7 * wv + t - 2, trb[t], tcb[t]);
-    }
-
-    // load: acc[t][reg] = D[16 rb + l15][16 cb + lq + 4 reg]; diagonal tiles mirror their lower triangle
-    double acc[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
-            if (r < c) {
-                const int x = r;
-                r = c;
-                c = x;
-            }
-            acc[t][reg] = Ain[(size_t)r + (size_t)c * ldin];
-        }
-
-    // K = -1 is the prologue: only the micro-pivot of micro-block 0 (no update precedes it); the same code as the
-    // look-ahead micro-pivots of the loop, so that there is ONE copy of the unrolled 16-step sweep
-#pragma unroll 1
-    for (int K = -1; K < NMB; ++K) {
-        if (NW == 4 && K == 3) {
-            // from now on the look-ahead micro-pivots are those of the second diagonal tile of each wave
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const double x = acc[0][reg];
-                acc[0][reg] = acc[1][reg];
-                acc[1][reg] = x;
-            }
-            const int x = trb[0];
-            trb[0] = tcb[0] = trb[1];
-            trb[1] = tcb[1] = x;
-        }
-        PV_STAMP(K, 0);
-        if (K >= 0) {
-            // ---- phase A: the old column block K into Gs ([kk][row]) ----
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (tcb[t] == K && trb[t] > K) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) Gs[pv_off(lq + 4 * reg) + MB * trb[t] + l15] = acc[t][reg];
-                } else if (trb[t] == K && tcb[t] < K) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) Gs[pv_off(l15) + MB * tcb[t] + lq + 4 * reg] = acc[t][reg];
-                }
-            }
-            PV_STAMP(K, 1);
-            __syncthreads();  // Gs complete; Pms[K & 1] (written in the previous update phase) visible
-            PV_STAMP(K, 2);
-            // ---- phase B: Ns = -(G Pm) for the row blocks != K; the rows of micro-block K of both images ----
-            for (int rb = wv; rb < NMB; rb += NW) {
-                if (rb == K) continue;
-                double4_t g = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int kk = 4 * t4 + lq;
-                    const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
-                    const double a = Pms[K & 1][lo][hi];                       // -Pm(l15, kk), lower triangle authoritative
-                    const double b = Gs[pv_off(kk) + MB * rb + l15];           // G(16 rb + l15, kk)
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, g, 0, 0, 0);
-                }
-                // lane holds -(G Pm)(16 rb + l15, lq + 4 reg)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Ns[pv_off(lq + 4 * reg) + MB * rb + l15] = g[reg];
-            }
-            if (wv == (NW == 12 ? NMB : (K & 3))) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    Gs[pv_off(lq + 4 * reg) + MB * K + l15] = (l15 == lq + 4 * reg) ? -1.0 : 0.0;
-            }
-            if (wv == (NW == 12 ? NMB + 1 : (K & 3))) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int kk = lq + 4 * reg;
-                    const int hi = l15 > kk ? l15 : kk, lo = l15 > kk ? kk : l15;
-                    Ns[pv_off(kk) + MB * K + l15] = -Pms[K & 1][lo][hi];       // +Pm(l15, kk)
-                }
-            }
-            PV_STAMP(K, 3);
-            __syncthreads();
-            PV_STAMP(K, 4);
-        }
-        // ---- phase C: every tile <- [in row or column K ? 0 : tile] + Gs[rb] Ns[cb]^T ----
-        auto update_tile = [&](int t) {
-            double4_t c4;
-            const bool fresh = trb[t] == K || tcb[t] == K;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) c4[reg] = fresh ? 0.0 : acc[t][reg];
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const int kk = 4 * t4 + lq;
-                const double a = Ns[pv_off(kk) + MB * tcb[t] + l15];
-                const double b = Gs[pv_off(kk) + MB * trb[t] + l15];
-                c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc[t][reg] = c4[reg];
-        };
-        if (K >= 0) update_tile(0);
-        PV_STAMP(K, 5);
-        if (K + 1 < NMB && wv == (NW == 12 ? K + 1 : ((K + 1) & 3))) {
-            // look-ahead: the next micro-pivot, beside the other waves' updates
-            double v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
-            micro_pivot(v, lane, MB * (K + 1), badj);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Pms[(K + 1) & 1][lq + 4 * reg][l15] = v[reg];  // [j][i] = -Pm(i, j)
-        }
-        PV_STAMP(K, 6);
-        if (K >= 0) {
-#pragma unroll
-            for (int t = 1; t < NT; ++t) update_tile(t);
-            PV_STAMP(K, 7);
-            __syncthreads();
-        }
-    }
-
-    // D = -inverse (lower-triangular tiles).  P = -D and the output tile = D, both as full symmetric matrices
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = MB * trb[t] + l15, c = MB * tcb[t] + lq + 4 * reg;
-            if (r >= c) {
-                const double v = acc[t][reg];
-                P[(size_t)r + (size_t)c * pld] = -v;
-                Aout[(size_t)r + (size_t)c * ldout] = v;
-                if (r > c) {
-                    P[(size_t)c + (size_t)r * pld] = -v;
-                    Aout[(size_t)c + (size_t)r * ldout] = v;
-                }
-            }
-        }
-}
 
 // ---- the form the persistent sweep kernel runs: ONE 256-thread workgroup, the serial chain on a wave of its own ----
 // The only serial part of the blocked sweep is  micro-pivot(K) -> N_{K+1} = -(G_{K+1} Pm) -> tile (K+1, K+1) += G_{K+1} N_{K+1}^T ->
@@ -425,7 +178,8 @@ __device__ __forceinline__ double4_t pvc_load_tile(const double *Ain, size_t ldi
     return x;
 }
 
-__device__ __forceinline__ void pivot_chain_wave(const double *Ain, size_t ldin, const PivotBufs L, int lane, int *bad_out)
+template <class Mid>
+__device__ __forceinline__ void pivot_chain_wave(const double *Ain, size_t ldin, const PivotBufs L, int lane, int *bad_out, Mid &mid)
 {
     const int l15 = lane & 15, lq = lane >> 4;
     [[maybe_unused]] const int wv = 3;
@@ -466,14 +220,19 @@ __device__ __forceinline__ void pivot_chain_wave(const double *Ain, size_t ldin,
         PV_STAMP(K, 4);
     }
     if (lane == 0 && bad != 0) *bad_out = bad;
+    __syncthreads();  // the workers' "LDS is free" barrier
+    mid();
 }
 
-template <int W>
+__device__ __forceinline__ void store_wt(double *p, double v);
+
+template <int W, class Mid>
 __device__ __forceinline__ void pivot_worker(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
-                                             size_t pld, const PivotBufs L, int lane)
+                                             size_t pld, const PivotBufs L, int lane, Mid &mid, unsigned long long *ph = nullptr)
 {
     const int l15 = lane & 15, lq = lane >> 4;
     [[maybe_unused]] const int wv = W;
+    if (W == 0 && ph && lane == 0) ph[0] = wall_clock64();
     const double *Pms = L.pms();
     double *Dt = L.dt();
     double4_t acc[PVC_NT];
@@ -505,6 +264,7 @@ __device__ __forceinline__ void pivot_worker(const double *Ain, size_t ldin, dou
             double *G = L.gs(K);
             __syncthreads();  // barrier 1: Pms(K), image K and Dt are in LDS
             PV_STAMP(K, 1);
+            if (W == 0 && ph && lane == 0 && K == 0) ph[1] = wall_clock64();
             // Ns = -(G Pm) for the row blocks W, W + 3, W + 6 (independent MFMA chains, interleaved); the one of block K itself is
             // computed on whatever the image holds there and dropped
             {
@@ -574,60 +334,58 @@ __device__ __forceinline__ void pivot_worker(const double *Ain, size_t ldin, dou
         }
         PV_STAMP(K, 5);
     }
-    // D = -inverse (lower-triangular tiles).  P = -D and the output tile = D, both as full symmetric matrices
+    if (W == 0 && ph && lane == 0) ph[2] = wall_clock64();
+    __syncthreads();  // the last update's operand reads are done (the chain wave joins): LDS is free
+    // D = -inverse (lower-triangular tiles).  P = -D and the output tile = D, both as full symmetric matrices; write-through stores
+    // (store_wt): the caller publishes them by draining its stores, without an L2 write-back.  The mirror image of a tile goes through
+    // a 16 x 17 scratch of this wave's in LDS, so that its stores are 128-byte row segments too (element by element they were 64
+    // different cache lines per instruction and a third of the whole pivot item)
+    double *X = L.A + W * (MB * (MB + 1));
+    // first P, then mid() -- the caller may publish P there: the next pivot row's items wait for nothing else --, then the output tile
+    auto emit = [&](double *O, size_t ldo, const double sgn) {
 #pragma unroll
-    for (int t = 0; t < PVC_NT; ++t)
+        for (int t = 0; t < PVC_NT; ++t) {
+            const int rb = pvc_rb(3 * t + W), cb = pvc_cb(3 * t + W);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = MB * pvc_rb(3 * t + W) + l15, c = MB * pvc_cb(3 * t + W) + lq + 4 * reg;
-            if (r >= c) {
-                const double x = acc[t][reg];
-                P[(size_t)r + (size_t)c * pld] = -x;
-                Aout[(size_t)r + (size_t)c * ldout] = x;
-                if (r > c) {
-                    P[(size_t)c + (size_t)r * pld] = -x;
-                    Aout[(size_t)c + (size_t)r * ldout] = x;
-                }
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lq + 4 * reg;
+                const double x = sgn * acc[t][reg];
+                X[j * (MB + 1) + l15] = x;
+                if (rb > cb || l15 >= j) store_wt(&O[(size_t)(MB * rb + l15) + (size_t)(MB * cb + j) * ldo], x);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lq + 4 * reg;
+                const double y = X[l15 * (MB + 1) + j];  // tile element (row j, column l15): to (16 cb + l15, 16 rb + j)
+                if (rb > cb || l15 < j) store_wt(&O[(size_t)(MB * cb + l15) + (size_t)(MB * rb + j) * ldo], y);
             }
         }
+    };
+    emit(P, pld, -1.0);
+    mid();
+    emit(Aout, ldout, 1.0);
 }
 
 // Ain (ld = ldin) is read, Aout (ld = ldout) receives -P, P (ld = pld) the inverse; Ain and Aout may be the same tile.  buf:
 // 4 KC LDS_LD doubles of LDS; *bad_out (zeroed by the caller before a barrier) receives the 1-based local index of the first
-// non-positive pivot.  The caller puts a barrier behind the call before it reads *bad_out or reuses the buffers.
+// non-positive pivot.  The caller puts a barrier behind the call before it reads *bad_out or reuses the buffers.  mid(): called once by
+// every wave, between the stores of P and those of the output tile (it may hold a barrier).
+template <class Mid>
 __device__ __forceinline__ void pivot_chain(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *__restrict__ P,
-                                            size_t pld, double *buf, int *bad_out)
+                                            size_t pld, double *buf, int *bad_out, Mid mid, unsigned long long *ph = nullptr)
 {
     static_assert(PVC_FLAG_OFF < 2 * KC * LDS_LD && PVC_NS_OFF + (MB / 2) * PV_ROW <= 2 * KC * LDS_LD, "pivot images fit the staging buffers");
     const int tid = opaque_tid(), lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const PivotBufs L{buf};
     if (wv == 3)
-        pivot_chain_wave(Ain, ldin, L, lane, bad_out);
+        pivot_chain_wave(Ain, ldin, L, lane, bad_out, mid);
     else if (wv == 0)
-        pivot_worker<0>(Ain, ldin, Aout, ldout, P, pld, L, lane);
+        pivot_worker<0>(Ain, ldin, Aout, ldout, P, pld, L, lane, mid, ph);
     else if (wv == 1)
-        pivot_worker<1>(Ain, ldin, Aout, ldout, P, pld, L, lane);
+        pivot_worker<1>(Ain, ldin, Aout, ldout, P, pld, L, lane, mid);
     else
-        pivot_worker<2>(Ain, ldin, Aout, ldout, P, pld, L, lane);
-}
-
-// Stand-alone form (one launch = one 128 x 128 block on a whole CU): used by tools/test_pivot.hip.
-__global__ __launch_bounds__(PIVOT_THREADS) void k_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout,
-                                                          double *__restrict__ P, size_t pld, gdca_dev_scalars *sc, int index0,
-                                                          int n_real)
-{
-    __shared__ __attribute__((aligned(16))) double Gs[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Ns[MB * PV_ROW];
-    __shared__ __attribute__((aligned(16))) double Pms[2][MB][MB];  // -Pm of micro-block K in Pms[K & 1]
-    __shared__ int badj;
-    if (threadIdx.x == 0) badj = 0;
-    __syncthreads();
-    pivot_block<12, 3>(Ain, ldin, Aout, ldout, P, pld, Gs, Ns, Pms, &badj);
-    __syncthreads();
-    if (threadIdx.x == 0 && badj != 0 && (index0 + badj) <= n_real) {
-        if (sc->info == 0) sc->info = index0 + badj;
-    }
+        pivot_worker<2>(Ain, ldin, Aout, ldout, P, pld, L, lane, mid);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1362,16 +1120,17 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
 
 // One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: Gs and Hs are the two halves of ONE array,
 // see k_sweep).  ONE call site in the kernel: the unrolled 16-step micro-sweep is long.
+template <class Mid>
 __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, double *Aout, size_t ldout, double *P,
                                                       double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD], int index0, int n_real,
-                                                      gdca_dev_scalars *sc)
+                                                      gdca_dev_scalars *sc, Mid mid, unsigned long long *ph = nullptr)
 {
     double *buf = &Gs[0][0][0];
     (void)Hs;
     int *badj = reinterpret_cast<int *>(buf + PVC_FLAG_OFF);
     if (threadIdx.x == 0) *badj = 0;
     __syncthreads();
-    pivot_chain(Ain, ldin, Aout, ldout, P, (size_t)T, buf, badj);
+    pivot_chain(Ain, ldin, Aout, ldout, P, (size_t)T, buf, badj, mid, ph);
     __syncthreads();
     if (threadIdx.x == 0 && *badj != 0) {
         // pivots run one after the other (each waits for the previous one's items): the first report is the smallest index
@@ -1509,11 +1268,29 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         const double *pin = (sz == 1 || first_pivot) ? (const double *)Agg : Sin + dd;
         double *pout = sz == 1 ? Agg : Sout + dd;
         const size_t pld_in = (sz == 1 || first_pivot) ? D.ld : (size_t)m, pld_out = sz == 1 ? D.ld : (size_t)m;
-        sweep_pivot(pin, pld_in, pout, pld_out, sz == 1 ? ring_pg(D, q) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc);
-        publish_begin();
+        // trace: where a pivot item's time goes (thread 0's stamps: entry, loads and first micro-pivot done, sweep done)
+        __shared__ unsigned long long ph[3];
+        // a single block's Pg is published as soon as ITS stores have drained (the slab / panel items of the next pivot row wait for
+        // mc only), the block's own tile -Pg behind it; inside a multi-block group the scratch copy is read under mc too: one publication
+        auto mid = [&] {
+            if (sz == 1) {
+                publish_wt_begin();
+                if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        sweep_pivot(pin, pld_in, pout, pld_out, sz == 1 ? ring_pg(D, q) : D.Pw, Gs, Hs, (b0 + w) * T, D.n_real, D.sc, mid, D.dbg ? ph : nullptr);
+        publish_wt_begin();  // the pivot's outputs are write-through stores
         if (tid == 0) {
-            if (sz == 1) __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sz == 1)
+                __hip_atomic_store(genp, (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (D.dbg) {
+                atomicAdd(D.dbg_main + 8 + 600, ph[1] - ph[0]);
+                atomicAdd(D.dbg_main + 8 + 601, ph[2] - ph[1]);
+                atomicAdd(D.dbg_main + 8 + 602, wall_clock64() - ph[2]);
+                atomicAdd(D.dbg_main + 8 + 603, 1ull);
+            }
         }
         return;
     }
@@ -1654,19 +1431,70 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 // MFMA operand layout (8 bytes per lane: lane (l15, lq) holds element (16 blk + l15, 4 k4 + lq)); H changes hands through LDS.
 // The last slab to finish sets the flags the panel items (rb += 2) and the tile item (gen, done) would have set.
 #define SLAB_ITEMS 8
+#define SLAB_PD 4  // rounds of 16 k in flight: a round's MFMAs take 0.4 us, a load from L2 / HBM one to two
+
+// x0, x1 (two 16 x 16 blocks of one 16-row slab) += sum_k b(r, k) a(c, k): operand elements straight from memory in MFMA operand
+// layout -- b(l15, 4 k4 + lq) = bp[(4 k4) ldb], a(l15, 4 k4 + lq) = ap[(4 k4) lda] and ap[(4 k4) lda + 16] with the lane's (l15, lq)
+// part already in bp / ap -- SLAB_PD rounds of 16 k ahead of the MFMAs.  B_LDS: b comes from LDS and is read where it is used.
+template <bool B_LDS>
+struct SlabPipe {
+    double b[SLAB_PD][4], a0[SLAB_PD][4], a1[SLAB_PD][4];
+    const double *bp, *ap;
+    size_t ldb, lda;
+    __device__ __forceinline__ void load(int kb, int st)
+    {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const size_t k = (size_t)(16 * kb + 4 * t4);
+            if (!B_LDS) b[st][t4] = bp[k * ldb];
+            a0[st][t4] = ap[k * lda];
+            a1[st][t4] = ap[k * lda + 16];
+        }
+    }
+    __device__ __forceinline__ void prologue()
+    {
+#pragma unroll
+        for (int st = 0; st < SLAB_PD - 1; ++st) load(st, st);
+    }
+    // COPY: the b elements also go to cp[(4 k4) ldc] (write-through), the 16 k of round kb by wave kb & 3
+    template <bool COPY>
+    __device__ __forceinline__ void run(double4_t &x0, double4_t &x1, double *cp, size_t ldc, int wv)
+    {
+#pragma unroll
+        for (int kb = 0; kb < NMB; ++kb) {
+            if (kb + SLAB_PD - 1 < NMB) load(kb + SLAB_PD - 1, (kb + SLAB_PD - 1) % SLAB_PD);
+            const int st = kb % SLAB_PD;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double bv = B_LDS ? bp[(size_t)(16 * kb + 4 * t4) * ldb] : b[st][t4];
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[st][t4], bv, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[st][t4], bv, x1, 0, 0, 0);
+            }
+            if (COPY && (kb & 3) == wv) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) store_wt(&cp[(size_t)(16 * kb + 4 * t4) * ldc], b[st][t4]);
+            }
+        }
+    }
+};
+
+// rowoff 1: the next pivot's row block; 2: the one after it (so that what the chain needs from the main list is a step further away)
 __device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s, int rowoff, double *lds, unsigned long long *dbg_ready = nullptr)
 {
     const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = g_start(D, p), c0 = b0 + rowoff;  // the row block: the next pivot's (rowoff 1) or the one after it (2)
+    const int b0 = g_start(D, p), c0 = b0 + rowoff;
     bool ok = true;
     if (tid == 0) {
         const unsigned want = p >= D.ring ? g_done_total(D, p - D.ring) : 0u;
         const unsigned *dn = D.done + (p >= D.ring ? p - D.ring : 0);
         const unsigned *g1 = D.gen + (size_t)c0 * D.nblk + b0, *g2 = D.gen + (size_t)c0 * D.nblk + c0;
+        // (the slabs of the second row block have a whole step of float: they start behind those of the first, which the next
+        // pivot waits for, instead of sharing the chain's compute units with them)
+        const unsigned *r1 = D.rb + (size_t)p * D.nblk + b0 + 1;
         ok = spin_until(D, [&] {
-            const unsigned f0 = flag_load(D.mc + p), f1 = flag_load(g1), f2 = flag_load(g2), f3 = flag_load(dn);
-            return (f0 >= 1u) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= want);
+            const unsigned f0 = flag_load(D.mc + p), f1 = flag_load(g1), f2 = flag_load(g2), f3 = flag_load(dn), f4 = flag_load(r1);
+            return (f0 >= 1u) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= want) & ((rowoff == 1) | (f4 >= 2u));
         });
     }
     if (!acquire_end(ok)) return;
@@ -1679,43 +1507,29 @@ __device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s
     double *Gc = D.G0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;  // the row block's G for the tile items: Gc[r + k ld]
     double *Hw = D.H0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;  // and its H: Hw[r + c ld]
     double *Hl = lds;                                                     // Hl[k][r]: 128 x 16
-    // this wave's two 16-column blocks (of H in the first product, of C in the second)
-    const int cA = 32 * wv + l15;
-    // ---- H(slab, :) = -G(slab, :) P ----
+    // ---- H(slab, :) = -G(slab, :) P: this wave's two 16-column blocks ----
     double4_t h0 = (double4_t){0.0, 0.0, 0.0, 0.0}, h1 = (double4_t){0.0, 0.0, 0.0, 0.0};
     {
-        const double *gp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;   // + 4 k4 ld
-        const double *pp = P + (size_t)cA + (size_t)lq * T;             // + 4 k4 T  (+ 16 for the second block)
-        double gb[2][4], pa[2][4], pb[2][4];
+        SlabPipe<false> pipe;
+        pipe.bp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;
+        pipe.ldb = ld;
+        pipe.ap = P + (size_t)(32 * wv + l15) + (size_t)lq * T;
+        pipe.lda = T;
+        pipe.prologue();
+        pipe.run<true>(h0, h1, Gc + (size_t)(R0 + l15) + (size_t)lq * ld, ld, wv);
+    }
+    // ---- C(slab, :) += H(slab, :) G^T: the operand of G goes on its way before H changes hands ----
+    SlabPipe<true> pipe2;
+    pipe2.bp = Hl + lq * MB + l15;
+    pipe2.ldb = MB;
+    pipe2.ap = Gt + (size_t)(32 * wv + l15) + (size_t)lq * ld;  // G(c', k), c' = this wave's columns of C
+    pipe2.lda = ld;
+    pipe2.prologue();
+    double4_t c0v, c1v;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            gb[0][t4] = gp[(size_t)(4 * t4) * ld];
-            pa[0][t4] = pp[(size_t)(4 * t4) * T];
-            pb[0][t4] = pp[(size_t)(4 * t4) * T + 16];
-        }
-#pragma unroll
-        for (int kb = 0; kb < NMB; ++kb) {
-            const int cur = kb & 1, nxt = cur ^ 1;
-            if (kb + 1 < NMB) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int k = 16 * (kb + 1) + 4 * t4;
-                    gb[nxt][t4] = gp[(size_t)k * ld];
-                    pa[nxt][t4] = pp[(size_t)k * T];
-                    pb[nxt][t4] = pp[(size_t)k * T + 16];
-                }
-            }
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                h0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[cur][t4], gb[cur][t4], h0, 0, 0, 0);
-                h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[cur][t4], gb[cur][t4], h1, 0, 0, 0);
-            }
-            // the copy of G's rows for the tile items of this row block (wave kb & 3 writes the 16 k of round kb)
-            if ((kb & 3) == wv) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) store_wt(&Gc[(size_t)(R0 + l15) + (size_t)(16 * kb + 4 * t4 + lq) * ld], gb[cur][t4]);
-            }
-        }
+    for (int reg = 0; reg < 4; ++reg) {
+        c0v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld];
+        c1v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld];
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -1726,41 +1540,8 @@ __device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s
         store_wt(&Hw[(size_t)(R0 + l15) + (size_t)c * ld], x0);
         store_wt(&Hw[(size_t)(R0 + l15) + (size_t)(c + 16) * ld], x1);
     }
-    // ---- C(slab, :) += H(slab, :) G^T ----
-    double4_t c0v, c1v;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        c0v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld];
-        c1v[reg] = Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld];
-    }
-    {
-        const double *gq = Gt + (size_t)cA + (size_t)lq * ld;  // G(c', k), c' = this wave's columns of C
-        double ga[2][4], gb2[2][4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            ga[0][t4] = gq[(size_t)(4 * t4) * ld];
-            gb2[0][t4] = gq[(size_t)(4 * t4) * ld + 16];
-        }
-        __syncthreads();  // H(slab, :) of all four waves is in LDS
-#pragma unroll
-        for (int kb = 0; kb < NMB; ++kb) {
-            const int cur = kb & 1, nxt = cur ^ 1;
-            if (kb + 1 < NMB) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int k = 16 * (kb + 1) + 4 * t4;
-                    ga[nxt][t4] = gq[(size_t)k * ld];
-                    gb2[nxt][t4] = gq[(size_t)k * ld + 16];
-                }
-            }
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const double hb = Hl[(16 * kb + 4 * t4 + lq) * MB + l15];
-                c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[cur][t4], hb, c0v, 0, 0, 0);
-                c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(gb2[cur][t4], hb, c1v, 0, 0, 0);
-            }
-        }
-    }
+    __syncthreads();  // H(slab, :) of all four waves is in LDS
+    pipe2.run<false>(c0v, c1v, nullptr, 0, wv);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         store_wt(&Ct[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld], c0v[reg]);
@@ -1783,7 +1564,8 @@ __device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s
 // of ITS row block (which copies G into the panel buffer), and that one for Pg(p): ~40 us behind the pivot -- the chain stood still
 // for them every other group.  The tile needs neither: A[c0+1, c0] += G H^T with G = A[c0+1, b0] as it lies in A (generation p: an
 // early item of update p - 1) and H = the rows the slab items of THIS group just wrote.  So it is done here, on the chain's idle
-// workgroups, as SLAB_ITEMS row slabs like the slab items' second product, while the next pivot runs; the main list skips it.
+// workgroups, as SLAB_ITEMS row slabs like the slab items' second product, while the next pivot runs; the main list skips it (and its
+// write-back item of that row block of column b0 waits for these items: they read it in place).
 __device__ __forceinline__ void sweep_xslab_item(const SweepDesc &D, int p, int s, unsigned long long *dbg_ready = nullptr)
 {
     const int tid = opaque_tid(), lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
@@ -1805,41 +1587,19 @@ __device__ __forceinline__ void sweep_xslab_item(const SweepDesc &D, int p, int 
     const double *Gt = D.A + (size_t)I * T + (size_t)b0 * T * ld;                            // G(r, k) = Gt[r + k ld]
     const double *Hw = D.H0 + ring_panel(D, p) * D.pstride + (size_t)c0 * T;                  // H(c, k) = Hw[c + k ld]
     double *Xt = D.A + (size_t)I * T + (size_t)c0 * T * ld;
+    SlabPipe<false> pipe;
+    pipe.bp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;
+    pipe.ldb = ld;
+    pipe.ap = Hw + (size_t)(32 * wv + l15) + (size_t)lq * ld;
+    pipe.lda = ld;
+    pipe.prologue();
     double4_t x0, x1;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         x0[reg] = Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld];
         x1[reg] = Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + 16 + lq + 4 * reg) * ld];
     }
-    {
-        const double *gp = Gt + (size_t)(R0 + l15) + (size_t)lq * ld;
-        const double *hp = Hw + (size_t)(32 * wv + l15) + (size_t)lq * ld;
-        double gb[2][4], ha[2][4], hb[2][4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            gb[0][t4] = gp[(size_t)(4 * t4) * ld];
-            ha[0][t4] = hp[(size_t)(4 * t4) * ld];
-            hb[0][t4] = hp[(size_t)(4 * t4) * ld + 16];
-        }
-#pragma unroll
-        for (int kb = 0; kb < NMB; ++kb) {
-            const int cur = kb & 1, nxt = cur ^ 1;
-            if (kb + 1 < NMB) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int k = 16 * (kb + 1) + 4 * t4;
-                    gb[nxt][t4] = gp[(size_t)k * ld];
-                    ha[nxt][t4] = hp[(size_t)k * ld];
-                    hb[nxt][t4] = hp[(size_t)k * ld + 16];
-                }
-            }
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[cur][t4], gb[cur][t4], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(hb[cur][t4], gb[cur][t4], x1, 0, 0, 0);
-            }
-        }
-    }
+    pipe.run<false>(x0, x1, nullptr, 0, wv);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         store_wt(&Xt[(size_t)(R0 + l15) + (size_t)(32 * wv + lq + 4 * reg) * ld], x0[reg]);
@@ -1860,18 +1620,21 @@ __device__ __forceinline__ void sweep_xslab_item(const SweepDesc &D, int p, int 
 // `nxt`, `s_next`, `s_ready` (main-list callers; thread 0's value / LDS words): the workgroup's NEXT item number, in flight as
 // an atomic since the start of this item.  While this item's stores drain, thread 0 looks that item up and, if it is a tile
 // item, reads its flags: the next trip then starts without the counter's and the flags' round trips (~3 us of a ~105 us item).
-__device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I, int J, int ready)
+// `inplace` (between single blocks, early tiles below the pivot): the G operand is read where it lies, A[I, b0] at generation p, not
+// from the copy the panel item of row block I makes -- the tile then does not wait for that panel item
+__device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I, int J, int ready, bool inplace = false)
 {
     bool ok = true;
-    if (opaque_tid() == 0 && !ready) {
+    if (opaque_tid() == 0 && (!ready || inplace)) {
         const unsigned long long t0 = D.dbg ? wall_clock64() : 0ull;
         const unsigned need = 2u * (unsigned)g_size(D, p);
         const unsigned *genp = D.gen + (size_t)I * D.nblk + J;
+        const unsigned *f1p = inplace ? D.gen + (size_t)I * D.nblk + g_start(D, p) : D.rb + (size_t)p * D.nblk + I;
+        const unsigned need1 = inplace ? (unsigned)p : need;
         // the three flags are loaded TOGETHER (one L2 round trip, ~1.5 us under load, instead of three dependent ones)
         ok = spin_until(D, [&] {
-            const unsigned f1 = flag_load(D.rb + (size_t)p * D.nblk + I), f2 = flag_load(D.rb + (size_t)p * D.nblk + J),
-                           f3 = flag_load(genp);
-            return (f1 >= need) & (f2 >= need) & (f3 >= (unsigned)p);
+            const unsigned f1 = flag_load(f1p), f2 = flag_load(D.rb + (size_t)p * D.nblk + J), f3 = flag_load(genp);
+            return (f1 >= need1) & (f2 >= need) & (f3 >= (unsigned)p);
         });
         if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
     }
@@ -1907,13 +1670,15 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
 template <bool MULTI>
 __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
                                                 double (*Hs)[KC][LDS_LD], int ready = 0, int nxt = 0, int *s_next = nullptr,
-                                                int *s_ready = nullptr)
+                                                int *s_ready = nullptr, bool inplace = false)
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    if (!tile_item_wait(D, p, I, J, ready)) return;
+    if (!tile_item_wait(D, p, I, J, ready, inplace)) return;
     const size_t ld = D.ld, pld = D.ld;
-    const double *Gp = D.G0 + ring_panel(D, p) * D.pstride, *Hp = D.H0 + ring_panel(D, p) * D.pstride;
+    // (in place: the group's column of A has the panel copy's layout, G(r, k) = A[r + k ld], the row block I rows down)
+    const double *Gp = inplace ? D.A + (size_t)g_start(D, p) * T * D.ld : D.G0 + ring_panel(D, p) * D.pstride;
+    const double *Hp = D.H0 + ring_panel(D, p) * D.pstride;
     double *At = D.A + (size_t)I * T + (size_t)J * T * ld;
     double4_t acc[4][4];
 #pragma unroll
@@ -2050,11 +1815,12 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
     bool ok = true;
     if (tid == 0) {
         // (between single blocks the chain's xslab items of this group read row block b0 + 2 of the column in place: not before they are done)
-        const bool after_x = D.slab && i == b0 + 2;
-        const unsigned *gx = D.gen + (size_t)i * D.nblk + (after_x ? b0 + 1 : 0);
+        // and so do the early tiles (i, b0 + 1) and (b0 + 3, b0 + 2) of this update (sweep_tile_item, inplace)
+        const bool after_x = D.slab && i >= b0 + 2, after_y = D.slab && i == b0 + 3;
+        const unsigned *gx = D.gen + (size_t)i * D.nblk + (after_x ? b0 + 1 : 0), *gy = D.gen + (size_t)i * D.nblk + (after_y ? b0 + 2 : 0);
         ok = spin_until(D, [&] {
-            const unsigned f0 = flag_load(D.rb + (size_t)p * D.nblk + i), f1 = flag_load(gx);
-            return (f0 >= 2u * (unsigned)sz) & (!after_x | (f1 >= (unsigned)(p + 1)));
+            const unsigned f0 = flag_load(D.rb + (size_t)p * D.nblk + i), f1 = flag_load(gx), f2 = flag_load(gy);
+            return (f0 >= 2u * (unsigned)sz) & (!after_x | (f1 >= (unsigned)(p + 1))) & (!after_y | (f2 >= (unsigned)(p + 1)));
         });
     }
     if (!acquire_end(ok)) return;
@@ -2195,7 +1961,8 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             else if (MULTI && g_size(D, it.p) > 1)
                 sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
             else
-                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready,
+                                       D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 7, 1ull);
@@ -2432,6 +2199,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
                     idle_end / grid, (double)(tend - tmin) / 100.0);
             fprintf(fp, "# shader clock during tile items: %.3f GHz (s_memtime cycles / 100 MHz wall clock)\n",
                     hm[6] ? (double)hm[8 + 1023] / (double)hm[6] * 0.1 : 0.0);
+            if (hm[8 + 603])
+                fprintf(fp, "# pivot items: %llu; loads and first micro-pivot %.1f us, blocked sweep %.1f us, stores and publication %.1f us each\n", hm[8 + 603],
+                        hm[8 + 600] / 100.0 / hm[8 + 603], hm[8 + 601] / 100.0 / hm[8 + 603], hm[8 + 602] / 100.0 / hm[8 + 603]);
             fprintf(fp, "# per group: tile items, us each, shader clock GHz:");
             for (int p = 0; p < ng; ++p) {
                 const unsigned long long *gp = &hm[8 + 1024 + 3 * (size_t)p];

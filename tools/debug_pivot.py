@@ -1,4 +1,4 @@
-"""Debug aid for k_pivot: the SPD inverse of one 128 x 128 block (a single pivot launch) against numpy, with the
+"""Debug aid for the pivot of the sweep kernel: the SPD inverse of one 128 x 128 block (a one-block inverse) against numpy, with the
 error reported per 16 x 16 micro-tile."""
 import sys, os
 import numpy as np
