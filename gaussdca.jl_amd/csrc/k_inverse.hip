@@ -1070,9 +1070,11 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     // (between single blocks the chain itself does tiles (b0+1, b0+1), (b0+2, b0+1), (b0+2, b0+2) and the panels of row blocks
     // b0 + 1 and b0 + 2 -- sweep_slab_item, sweep_xslab_item -- and what it waits for a step later is row block b0 + 3: its tiles
     // (b0+3, b0+2), (b0+3, b0+3) take the early slots here, (b0+3, b0+1) is among rest(p+1))
-    const int n_diag2 = D.slab ? (b0 + 3 < D.nblk ? 2 : 0) : n2 * (n2 + 1) / 2;
+    // ... and the tiles (i, b0+2), i > b0+3, follow them: column b0 + 2 is the next step's column b0 + 1, whose tiles must carry
+    // this update before they can take the next one early -- as ordinary remainder tiles they were what the chain ended up waiting for
+    const int n_diag2 = D.slab ? (b0 + 3 < D.nblk ? 2 : 0) + max(0, D.nblk - b0 - 4) : n2 * (n2 + 1) / 2;
     if (e < n_diag2) {
-        if (D.slab) return MainItem{4, p, b0 + 3, b0 + 2 + e};
+        if (D.slab) return e < 2 ? MainItem{4, p, b0 + 3, b0 + 2 + e} : MainItem{4, p, b0 + 2 + e, b0 + 2};
         int mm = 0, first = 0;
         while (e >= first + (n2 - mm)) {
             first += n2 - mm;
@@ -1112,7 +1114,8 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     if (ii >= b0) ii += sz + nsz;
     if (jj >= b0) jj += sz + nsz;
     if (D.slab) {
-        if (jj >= d0 && ii <= d0 + 1) return MainItem{3, p, 0, 0};  // (b0+2, b0+2): the chain's; (b0+3, b0+2), (b0+3, b0+3): early slots
+        // (b0+2, b0+2): the chain's; (b0+3, b0+3) and column b0 + 2 below the diagonal: early slots
+        if ((jj >= d0 && ii <= d0 + 1) || jj == d0) return MainItem{3, p, 0, 0};
     } else if (jj >= d0 && ii < d0 + n2)
         return MainItem{3, p, 0, 0};  // inside the diagonal super-block of group p+2: done as diag2
     return MainItem{1, p, ii, jj};
@@ -1376,7 +1379,10 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
                            f4 = flag_load(gp[3]), f5 = flag_load(dn);
             return (f0 >= nmi) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= (unsigned)p) & (f4 >= (unsigned)p) & (f5 >= want);
         });
-        if (D.dbg) atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
+        if (D.dbg) {
+            atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
+            if (D.slab && i == b0 + 3) atomicMax(D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * p + 9, wall_clock64());  // trace: last half ready
+        }
     }
     if (!acquire_end(ok)) return;
     const size_t ld = D.ld, pgld = (size_t)sz * T;
@@ -1636,7 +1642,11 @@ __device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I,
             const unsigned f1 = flag_load(f1p), f2 = flag_load(D.rb + (size_t)p * D.nblk + J), f3 = flag_load(genp);
             return (f1 >= need1) & (f2 >= need) & (f3 >= (unsigned)p);
         });
-        if (D.dbg) atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
+        if (D.dbg) {
+            atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
+            const int r3 = g_start(D, p) + 3;
+            if (D.slab && I == r3 && J >= r3 - 2) D.dbg_main[8 + 1024 + 3 * D.ng + 16 * p + 10 + (J - (r3 - 2))] = wall_clock64();  // trace: ready
+        }
     }
     return acquire_end(ok);
 }
@@ -1815,8 +1825,8 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
     bool ok = true;
     if (tid == 0) {
         // (between single blocks the chain's xslab items of this group read row block b0 + 2 of the column in place: not before they are done)
-        // and so do the early tiles (i, b0 + 1) and (b0 + 3, b0 + 2) of this update (sweep_tile_item, inplace)
-        const bool after_x = D.slab && i >= b0 + 2, after_y = D.slab && i == b0 + 3;
+        // and so do the early tiles (i, b0 + 1) and (i, b0 + 2) of this update (sweep_tile_item, inplace)
+        const bool after_x = D.slab && i >= b0 + 2, after_y = D.slab && i >= b0 + 3;
         const unsigned *gx = D.gen + (size_t)i * D.nblk + (after_x ? b0 + 1 : 0), *gy = D.gen + (size_t)i * D.nblk + (after_y ? b0 + 2 : 0);
         ok = spin_until(D, [&] {
             const unsigned f0 = flag_load(D.rb + (size_t)p * D.nblk + i), f1 = flag_load(gx), f2 = flag_load(gy);
@@ -1955,6 +1965,18 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
         const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
         const MainItem it = main_decode(D, p, item);
+        // trace (between single blocks): when the main list's items of row block b0 + 3 of update it.p were taken and done -- the
+        // inputs the chain waits for: [0..2] its panel halves (first taken, last done), [3..] tiles (b0+3, b0+1), (b0+3, b0+2), (b0+3, b0+3)
+        int xslot = -1;
+        if (D.dbg && D.slab && threadIdx.x == 0) {
+            const int r3 = g_start(D, it.p) + 3;
+            if (it.kind == 0 && it.a == r3) xslot = 0;
+            if (it.kind == 4 && it.a == r3) xslot = 3 + 2 * (it.b - (r3 - 2));
+            if (xslot >= 0) {
+                unsigned long long *xs = D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * it.p;
+                if (xslot == 0) atomicCAS(xs + 0, 0ull, wall_clock64()); else xs[xslot] = wall_clock64();
+            }
+        }
         if (it.kind == 1 || it.kind == 4) {
             if (D.rl < T && it.a == D.nblk - 1)
                 sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
@@ -1971,6 +1993,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
                 atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p, cyc);  // ... and per group: cycles, ticks, items
                 atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 1, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 2, 1ull);
+                if (xslot >= 3) D.dbg_main[8 + 1024 + 3 * D.ng + 16 * it.p + xslot + 1] = wall_clock64();
             }
             continue;
         }
@@ -1982,6 +2005,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 3, 1ull);
+                if (xslot == 0) atomicMax(D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * it.p + 1, wall_clock64());
             }
         } else if (it.kind == 2) {
             sweep_wb_item(D, it.p, it.a, Gs);
@@ -2018,11 +2042,12 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // pivot blocks per group: more blocks per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
     // are bound by the chain itself, which is shortest with single blocks (no scratch copy, no tile jobs).  Measured on
-    // MI355X with the round-3 tile loop (tools/sweep_groups.py, profiles/r03_sweep_groups*.log: inverse time over N x g x chain
-    // CUs): g = 1 is fastest up to 58 blocks, 2 to 64, 3 to 70, 4 from 71 on -- groups of four at n = 10 000 (79 blocks) need 12
-    // compute units for the chain (16.5 ms against 17.2 for groups of three; with 8 they lose: 17.9).
+    // MI355X with the round-3 tile loop and chain (tools/sweep_groups.py, profiles/r03_sweep_groups*.log: inverse time over
+    // N x g x chain CUs): g = 1 is fastest up to 54 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
+    // by the chain), 2 to 59, 3 to 70, 4 from 71 on -- groups of four at n = 10 000 (79 blocks) need 12 compute units for the chain
+    // (16.5 ms against 17.2 for groups of three; with 8 they lose: 17.9).
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 71 ? 4 : (nblk >= 65 ? 3 : (nblk >= 59 ? 2 : 1)));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 71 ? 4 : (nblk >= 60 ? 3 : (nblk >= 55 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
@@ -2085,7 +2110,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
         const int nrest = nblk - sz - nsz;
         // M(p), then the next group's panel rows and its diagonal tiles -- or, between single blocks, the fused slab items
         mpos += m_cnt(sz) + (slab ? (nsz ? SLAB_ITEMS : 0) + (n2 ? 2 * SLAB_ITEMS : 0) : nsz * 2 * sz + nsz * (nsz + 1) / 2);
-        pos += slab ? (gs[p] + 3 < nblk ? 2 : 0) : n2 * (n2 + 1) / 2;  // diag2 (between single blocks: two tiles of row block b0 + 3)
+        pos += slab ? (gs[p] + 3 < nblk ? 2 : 0) + std::max(0, nblk - gs[p] - 4) : n2 * (n2 + 1) / 2;  // diag2 (between single blocks: (b0+3, b0+3) and column b0 + 2)
         pos += (long long)nsz * nrest;                             // rest
         pos += (long long)(nblk - sz) * sz;                        // wb
         pos += nrest > 0 ? (long long)nrest * (nrest + 1) / 2 : 0; // rem (its diag2 tiles are empty items)
@@ -2152,9 +2177,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once -- the 2 (g-1)^2 half-tile jobs of a level of a four-block group are 18 -- and once the update hides the chain the
-    // workers go back to the tiles: 16 CUs for single-block groups of small matrices and for multi-block groups up to 74
-    // blocks, 12 up to 86, 8 up to 115, 4 beyond
-    const int mcu_rule = g == 1 ? (nblk < 28 ? 16 : 12) : (nblk <= 74 ? 16 : (nblk <= 86 ? 12 : (nblk <= 115 ? 8 : 4)));
+    // workers go back to the tiles: for multi-block groups 16 CUs up to 74 blocks, 12 up to 86, 8 up to 115, 4 beyond; between
+    // single blocks (a pivot and three times eight slab items per step) 12 CUs below 28 blocks, 8 above
+    const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 74 ? 16 : (nblk <= 86 ? 12 : (nblk <= 115 ? 8 : 4)));
     D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
     D.rl = rl;
@@ -2163,8 +2188,8 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
     unsigned long long *dbg = nullptr;
     if (trace_path) {
-        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024 + 3 * ng) * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024 + 3 * ng) * sizeof(unsigned long long), s0);
+        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) * sizeof(unsigned long long), s0);
     }
     D.dbg = dbg;
     D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
@@ -2178,7 +2203,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
     if (dbg) {
         (void)hipStreamSynchronize(s0);
-        std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024 + 3 * (size_t)ng);
+        std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024 + 19 * (size_t)ng);
         (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipMemcpy(hm.data(), dbg + 2 * (mpos + 1), hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipFree(dbg);
@@ -2211,6 +2236,19 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
             unsigned long long t0 = ~0ull;
             for (size_t x = 0; x < h.size(); x += 2)
                 if (h[x] && h[x] < t0) t0 = h[x];
+            if (slab) {
+                fprintf(fp, "# main-list items of row block b0 + 3, us since the first stamp: group: panel halves first taken .. last done | tile (b0+3, b0+1) taken .. done | "
+                            "(b0+3, b0+2) | (b0+3, b0+3)\n");
+                for (int p = 0; p + 3 < ng; ++p) {
+                    const unsigned long long *xs = &hm[8 + 1024 + 3 * (size_t)ng + 16 * (size_t)p];
+                    fprintf(fp, "# x %d:", p);
+                    for (int k = 0; k < 8; k += 2)
+                        fprintf(fp, " %8.1f (ready %8.1f) .. %8.1f |", xs[k == 0 ? 0 : k + 1] ? (double)(xs[k == 0 ? 0 : k + 1] - t0) / 100.0 : -1.0,
+                                xs[9 + k / 2] ? (double)(xs[9 + k / 2] - t0) / 100.0 : -1.0,
+                                xs[k == 0 ? 1 : k + 2] ? (double)(xs[k == 0 ? 1 : k + 2] - t0) / 100.0 : -1.0);
+                    fprintf(fp, "\n");
+                }
+            }
             int q = 0;
             for (long long x = 0; x < mpos; ++x) {
                 while (x >= mit[q + 1]) ++q;

@@ -436,10 +436,15 @@ print(json.dumps(out))
                                  {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}, {"GDCA_GROUP": "3", "GDCA_RAMP": "0"},
                                  {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"},
                                  {"GDCA_GROUP": "3", "GDCA_RAGGED": "0"}, {"GDCA_GROUP": "4", "GDCA_SWEEP_DEBUG": "1"},
-                                 {"GDCA_GROUP": "1", "GDCA_SWEEP_DEBUG": "1", "GDCA_MCUS": "16"}])
+                                 {"GDCA_GROUP": "1", "GDCA_SWEEP_DEBUG": "1", "GDCA_MCUS": "16"},
+                                 {"GDCA_GROUP": "1", "GDCA_SLAB": "0"}, {"GDCA_GROUP": "1", "GDCA_SLAB": "0", "GDCA_RING": "2"},
+                                 {"GDCA_GROUP": "1", "GDCA_RING": "2"}, {"GDCA_GROUP": "1", "GDCA_RING": "3", "GDCA_MCUS": "2"},
+                                 {"GDCA_GROUP": "1", "GDCA_MCUS": "1"}])
 def test_every_inverse_schedule_matches_lapack(env):
     """The SPD inverse is one persistent launch that sweeps pivot groups of 1-4 blocks (the group size is chosen by matrix
-    size) with its serial chain on 1-16 elected compute units.  Each combination, forced through its environment switches
+    size) with its serial chain on 1-16 elected compute units; between single blocks the chain's panel and tile work is cut
+    into row slabs (GDCA_SLAB=0: the panel / tile items of the multi-block schedules) and Pg and the panels live in a ring of
+    eight buffers (GDCA_RING).  Each combination, forced through its environment switches
     in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks (even and odd block counts, short last groups
     and matrices smaller than one group included) and the same `info` on a non-PD matrix."""
     import json

@@ -18,8 +18,11 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
 cd $R
 GDCA_SWEEP_TRACE=$out/sweep_trace_C.txt timeout 300 python tools/sweep_trace.py 10000 > $out/sweep_trace_C.log 2>&1
 GDCA_SWEEP_TRACE=$out/sweep_trace_D.txt timeout 300 python tools/sweep_trace.py 20000 > $out/sweep_trace_D.log 2>&1
-GDCA_SWEEP_TRACE=$out/sweep_trace_B.txt timeout 300 python tools/sweep_trace.py 2560 5,6 > $out/sweep_trace_B.log 2>&1
+GDCA_SWEEP_TRACE=$out/sweep_trace_B.txt timeout 300 python tools/sweep_trace.py 2560 5,6,7,8 > $out/sweep_trace_B.log 2>&1
 GDCA_SWEEP_TRACE=$out/clock_ramp_C.txt timeout 300 python tools/clock_ramp.py 10000 8 > $out/clock_ramp_C.log 2>&1
+# the pivot block alone (phase stamps) and the single-block chain options
+[ -x tools/_bin/test_pivot ] && timeout 120 tools/_bin/test_pivot > $out/pivot_chain_phases.log 2>&1
+timeout 900 bash tools/slab_ab.sh > $out/chain_slab_ab.log 2>&1
 head -4 $out/sweep_trace_C.log
 find $out -name "*agent_info*" -delete
 # host side: feed rate of the batch driver and thread scaling of the CPU port (no GPU work)
