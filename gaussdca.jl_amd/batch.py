@@ -11,11 +11,11 @@ from __future__ import annotations
 from typing import List, Sequence, Tuple
 
 # seconds, fitted to the round-3 MI355X stage times (profiles/r03_bench_*.json):
-#   SPD inverse   17.5 ms at n = 10 000 (config C), 123 ms at n = 20 000 (D)  ->  ALPHA n^3, but never less than the pivot
-#                 chain, CHAIN seconds per 128-block (config B: 20 blocks, 1.87 ms: small matrices are bound by that chain)
-#   reweighting   3.2 ms at M^2 N = 1.25e12 (C), 24.7 ms at 1e13 (D)           ->  BETA M^2 N
+#   SPD inverse   17.3 ms at n = 10 000 (config C), 125.7 ms at n = 20 000 (D)  ->  ALPHA n^3, but never less than the pivot
+#                 chain, CHAIN seconds per 128-block (config B: 20 blocks, 1.23 ms: small matrices are bound by that chain)
+#   reweighting   2.96 ms at M^2 N = 1.25e12 (C), 18.5 ms at 1e13 (D)          ->  BETA M^2 N
 #   tallies + covariance  3.3 ms at N^2 M = 1.25e10 (C), 21 ms at 1e11 (D)     ->  GAMMA N^2 M
-ALPHA, BETA, GAMMA, CHAIN = 17.0e-15, 2.5e-15, 2.4e-13, 94e-6
+ALPHA, BETA, GAMMA, CHAIN = 17.0e-15, 2.0e-15, 2.4e-13, 61e-6
 
 
 def family_cost(N: int, M: int, q: int = 21) -> float:

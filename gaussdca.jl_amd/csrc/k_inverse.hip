@@ -2243,9 +2243,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
                     const unsigned long long *xs = &hm[8 + 1024 + 3 * (size_t)ng + 16 * (size_t)p];
                     fprintf(fp, "# x %d:", p);
                     for (int k = 0; k < 8; k += 2)
-                        fprintf(fp, " %8.1f (ready %8.1f) .. %8.1f |", xs[k == 0 ? 0 : k + 1] ? (double)(xs[k == 0 ? 0 : k + 1] - t0) / 100.0 : -1.0,
-                                xs[9 + k / 2] ? (double)(xs[9 + k / 2] - t0) / 100.0 : -1.0,
-                                xs[k == 0 ? 1 : k + 2] ? (double)(xs[k == 0 ? 1 : k + 2] - t0) / 100.0 : -1.0);
+                        fprintf(fp, " %8.1f (ready %8.1f) .. %8.1f |", xs[k == 0 ? 0 : k + 1] ? (double)(long long)(xs[k == 0 ? 0 : k + 1] - t0) / 100.0 : -1.0,
+                                xs[9 + k / 2] ? (double)(long long)(xs[9 + k / 2] - t0) / 100.0 : -1.0,
+                                xs[k == 0 ? 1 : k + 2] ? (double)(long long)(xs[k == 0 ? 1 : k + 2] - t0) / 100.0 : -1.0);
                     fprintf(fp, "\n");
                 }
             }
