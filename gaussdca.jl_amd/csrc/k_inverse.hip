@@ -65,6 +65,8 @@ __device__ __forceinline__ int opaque_tid()
 #define MB 16                      // micro-block edge
 #define NMB (T / MB)               // micro-blocks per side
 #define PV_ROW 160                 // doubles per kk-row of an operand image
+#define SLAB_ITEMS 8               // 16-row slabs of a 128-row block (the chain's row-slab items)
+#define SLAB_PD 4                  // their load pipeline: rounds of 16 k in flight (a round's MFMAs take 0.4 us, a load from L2 / HBM one to two)
 
 __device__ __forceinline__ int pv_off(int kk)
 {
@@ -1033,12 +1035,12 @@ __device__ __forceinline__ bool acquire_end(bool ok)
     return *abort_lds() == 0;
 }
 
-// M(q): sz (sz+1) / 2 gather items (one lower tile each), per block w a pivot + 2 (sz-1) + 2 (sz-1)^2 tile jobs, then
+// M(q): sz (sz+1) / 2 gather items (one lower tile each), per block w a pivot + 8 (sz-1) row-slab jobs, then
 // sz (sz+1) / 2 scatter items
 // (a group of ONE block needs no scratch copy: a single item, the pivot in place)
 __device__ __forceinline__ int m_items(int sz)
 {
-    return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1));
+    return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + SLAB_ITEMS * (sz - 1));
 }
 
 // ---- the main list: item number -> what to do --------------------------------------------------------------------------
@@ -1142,13 +1144,60 @@ __device__ __forceinline__ void sweep_pivot(const double *Ain, size_t ldin, doub
     }
 }
 
+// ---- row-slab products (the chain's items between single blocks and inside a multi-block group) --------------------------------
+
+// x0, x1 (two 16 x 16 blocks of one 16-row slab) += sum_k b(r, k) a(c, k): operand elements straight from memory in MFMA operand
+// layout -- b(l15, 4 k4 + lq) = bp[(4 k4) ldb], a(l15, 4 k4 + lq) = ap[(4 k4) lda] and ap[(4 k4) lda + 16] with the lane's (l15, lq)
+// part already in bp / ap -- SLAB_PD rounds of 16 k ahead of the MFMAs.  B_LDS: b comes from LDS and is read where it is used.
+template <bool B_LDS>
+struct SlabPipe {
+    double b[SLAB_PD][4], a0[SLAB_PD][4], a1[SLAB_PD][4];
+    const double *bp, *ap;
+    size_t ldb, lda;
+    __device__ __forceinline__ void load(int kb, int st)
+    {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const size_t k = (size_t)(16 * kb + 4 * t4);
+            if (!B_LDS) b[st][t4] = bp[k * ldb];
+            a0[st][t4] = ap[k * lda];
+            a1[st][t4] = ap[k * lda + 16];
+        }
+    }
+    __device__ __forceinline__ void prologue()
+    {
+#pragma unroll
+        for (int st = 0; st < SLAB_PD - 1; ++st) load(st, st);
+    }
+    // COPY: the b elements also go to cp[(4 k4) ldc] (write-through), the 16 k of round kb by wave kb & 3
+    template <bool COPY>
+    __device__ __forceinline__ void run(double4_t &x0, double4_t &x1, double *cp, size_t ldc, int wv)
+    {
+#pragma unroll
+        for (int kb = 0; kb < NMB; ++kb) {
+            if (kb + SLAB_PD - 1 < NMB) load(kb + SLAB_PD - 1, (kb + SLAB_PD - 1) % SLAB_PD);
+            const int st = kb % SLAB_PD;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const double bv = B_LDS ? bp[(size_t)(16 * kb + 4 * t4) * ldb] : b[st][t4];
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[st][t4], bv, x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[st][t4], bv, x1, 0, 0, 0);
+            }
+            if (COPY && (kb & 3) == wv) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) store_wt(&cp[(size_t)(16 * kb + 4 * t4) * ldc], b[st][t4]);
+            }
+        }
+    }
+};
+
 // ---- M(q): one item of the super-block inverse of group q -------------------------------------------------------------
 __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, double (*Gs)[KC][LDS_LD], double (*Hs)[KC][LDS_LD],
                                              unsigned long long *dbg_ready = nullptr)
 {
     const int tid = opaque_tid();
     const int b0 = g_start(D, q), sz = g_size(D, q), m = sz * T;
-    const int n1 = 2 * (sz - 1), n2 = 2 * (sz - 1) * (sz - 1), per_w = 1 + n1 + n2, nt = sz * (sz + 1) / 2;
+    const int per_w = 1 + SLAB_ITEMS * (sz - 1), nt = sz * (sz + 1) / 2;
     const int nm = 2 * nt + sz * per_w;
     double *Agg = D.A + (size_t)b0 * T + (size_t)b0 * T * D.ld;
     unsigned *mc = D.mc + q;
@@ -1297,53 +1346,73 @@ __device__ __forceinline__ void sweep_m_item(const SweepDesc &D, int q, int e, d
         }
         return;
     }
-    // tile jobs on the scratch matrix (128 x 64 each):  J1: S_iw <- S_iw Pw (and its mirror S_wi);  J2: S_ij <- S_ij - (S_iw Pw) S_jw^T
-    // (halves, not whole tiles: the jobs of a level run side by side on the chain's workgroups, two to a compute unit, and the
-    // chain waits for the slowest -- whole 128 x 128 jobs on the hand-scheduled chunk loop left half of those workgroups idle
-    // and made the level longer: 46-73 us instead of 30-45)
-    const bool second = r > n1;
-    const int k = second ? r - 1 - n1 : r - 1;
-    const int ch = k & 1;
-    int ii, jj = 0;
-    if (!second) {
-        ii = k >> 1;
-    } else {
-        ii = (k >> 1) / (sz - 1);
-        jj = (k >> 1) % (sz - 1);
-    }
+    // Jobs on the scratch matrix, one per OTHER row block i and 16-row slab (8 (sz-1) per block w, ONE level between two pivots):
+    //      N = S_iw Pw  ->  S_iw (and its mirror S_wi);    S_ij <- S_ij - N S_jw^T for every j != w
+    // Rows are independent in all of it, so a slab does the sz products of its 16 rows back to back, N changing hands through LDS
+    // (SlabPipe: operands straight from L2 in MFMA operand layout).  As half-tile jobs -- 2 (sz-1) for S_iw, then 2 (sz-1)^2 for the
+    // S_ij, two dependent levels of 128 x 64 x 128 products on one workgroup each -- a block took 30-45 us per level.
+    const int k = r - 1, s = k % SLAB_ITEMS;
+    int ii = k / SLAB_ITEMS;
     if (ii >= w) ++ii;
-    if (jj >= w) ++jj;
     bool ok = true;
-    if (tid == 0) ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)(base_w + 1 + (second ? n1 : 0)); });
+    if (tid == 0) ok = spin_until(D, [&] { return flag_load(mc) >= (unsigned)(base_w + 1); });
     if (!acquire_end(ok)) return;
-    const double *gsrc = (second ? (const double *)Sout : Sin) + (size_t)ii * T + (size_t)w * T * m;
-    const double *hsrc = second ? Sin + (size_t)jj * T + (size_t)w * T * m : D.Pw;
-    const size_t hld = second ? (size_t)m : (size_t)T;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
-    double4_t acc[2][4];
+    const int lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R0 = MB * s;
+    constexpr int NL = MB + 1;  // N in LDS: Nl[c][r], 17 doubles per column (the mirror is read along c)
+    double *Nl = &Gs[0][0][0];
+    const size_t ms = (size_t)m;
+    double4_t n0 = (double4_t){0.0, 0.0, 0.0, 0.0}, n1v = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+        SlabPipe<false> pipe;
+        pipe.bp = Sin + (size_t)(ii * T + R0 + l15) + (size_t)(w * T + lq) * ms;
+        pipe.ldb = ms;
+        pipe.ap = D.Pw + (size_t)(32 * wv + l15) + (size_t)lq * T;
+        pipe.lda = T;
+        pipe.prologue();
+        pipe.run<false>(n0, n1v, nullptr, 0, wv);
+    }
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c = 32 * wv + lq + 4 * reg;
+        Nl[c * NL + l15] = n0[reg];
+        Nl[(c + 16) * NL + l15] = n1v[reg];
+        store_wt(&Sout[(size_t)(ii * T + R0 + l15) + (size_t)(w * T + c) * ms], n0[reg]);
+        store_wt(&Sout[(size_t)(ii * T + R0 + l15) + (size_t)(w * T + c + 16) * ms], n1v[reg]);
+    }
+    __syncthreads();  // N(slab, :) of all four waves is in LDS
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    tile_product<false, 2>(acc, gsrc, (size_t)m, hsrc + (size_t)ch * 64, hld, Gs[0], Hs[0], nullptr, 0);
-    const double *cin = second ? Sin + (size_t)ii * T + (size_t)jj * T * m : nullptr;
-    double *out = Sout + (size_t)ii * T + (size_t)(second ? jj : w) * T * m;
-    double *outT = second ? nullptr : Sout + (size_t)w * T + (size_t)ii * T * m;
+    for (int u = 0; u < 8; ++u) {
+        const int idx = tid + 256 * u, c = idx & 127, rr = idx >> 7;  // the mirror: row segments of S_wi
+        store_wt(&Sout[(size_t)(w * T + c) + (size_t)(ii * T + R0 + rr) * ms], Nl[c * NL + rr]);
+    }
+#pragma unroll 1
+    for (int jx = 0; jx < sz - 1; ++jx) {
+        const int jj = jx >= w ? jx + 1 : jx;
+        SlabPipe<true> pipe;
+        pipe.bp = Nl + lq * NL + l15;
+        pipe.ldb = NL;
+        pipe.ap = Sin + (size_t)(jj * T + 32 * wv + l15) + (size_t)(w * T + lq) * ms;  // S_jw(c', k), c' = this wave's columns
+        pipe.lda = ms;
+        pipe.prologue();
+        const double *cin = Sin + (size_t)(ii * T + R0 + l15) + (size_t)(jj * T + 32 * wv) * ms;
+        double c0[4], c1[4];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+        for (int reg = 0; reg < 4; ++reg) {
+            c0[reg] = cin[(size_t)(lq + 4 * reg) * ms];
+            c1[reg] = cin[(size_t)(16 + lq + 4 * reg) * ms];
+        }
+        double4_t x0 = (double4_t){0.0, 0.0, 0.0, 0.0}, x1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+        pipe.run<false>(x0, x1, nullptr, 0, wv);
+        double *out = Sout + (size_t)(ii * T + R0 + l15) + (size_t)(jj * T + 32 * wv) * ms;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rr = wr * 64 + tn * 16 + l15;
-                const int cc = ch * 64 + wc * 32 + tm * 16 + lq + 4 * reg;
-                double v = acc[tm][tn][reg];
-                if (cin) v = cin[(size_t)rr + (size_t)cc * m] - v;
-                out[(size_t)rr + (size_t)cc * m] = v;
-                if (outT) outT[(size_t)cc + (size_t)rr * m] = v;
-            }
-    publish_begin();
+        for (int reg = 0; reg < 4; ++reg) {
+            store_wt(&out[(size_t)(lq + 4 * reg) * ms], c0[reg] - x0[reg]);
+            store_wt(&out[(size_t)(16 + lq + 4 * reg) * ms], c1[reg] - x1[reg]);
+        }
+    }
+    publish_wt_begin();
     if (tid == 0) __hip_atomic_fetch_add(mc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1436,54 +1505,6 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
 // side by side, with no hand-over between the two products but a barrier inside the workgroup.  Operands come straight from L2 in
 // MFMA operand layout (8 bytes per lane: lane (l15, lq) holds element (16 blk + l15, 4 k4 + lq)); H changes hands through LDS.
 // The last slab to finish sets the flags the panel items (rb += 2) and the tile item (gen, done) would have set.
-#define SLAB_ITEMS 8
-#define SLAB_PD 4  // rounds of 16 k in flight: a round's MFMAs take 0.4 us, a load from L2 / HBM one to two
-
-// x0, x1 (two 16 x 16 blocks of one 16-row slab) += sum_k b(r, k) a(c, k): operand elements straight from memory in MFMA operand
-// layout -- b(l15, 4 k4 + lq) = bp[(4 k4) ldb], a(l15, 4 k4 + lq) = ap[(4 k4) lda] and ap[(4 k4) lda + 16] with the lane's (l15, lq)
-// part already in bp / ap -- SLAB_PD rounds of 16 k ahead of the MFMAs.  B_LDS: b comes from LDS and is read where it is used.
-template <bool B_LDS>
-struct SlabPipe {
-    double b[SLAB_PD][4], a0[SLAB_PD][4], a1[SLAB_PD][4];
-    const double *bp, *ap;
-    size_t ldb, lda;
-    __device__ __forceinline__ void load(int kb, int st)
-    {
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            const size_t k = (size_t)(16 * kb + 4 * t4);
-            if (!B_LDS) b[st][t4] = bp[k * ldb];
-            a0[st][t4] = ap[k * lda];
-            a1[st][t4] = ap[k * lda + 16];
-        }
-    }
-    __device__ __forceinline__ void prologue()
-    {
-#pragma unroll
-        for (int st = 0; st < SLAB_PD - 1; ++st) load(st, st);
-    }
-    // COPY: the b elements also go to cp[(4 k4) ldc] (write-through), the 16 k of round kb by wave kb & 3
-    template <bool COPY>
-    __device__ __forceinline__ void run(double4_t &x0, double4_t &x1, double *cp, size_t ldc, int wv)
-    {
-#pragma unroll
-        for (int kb = 0; kb < NMB; ++kb) {
-            if (kb + SLAB_PD - 1 < NMB) load(kb + SLAB_PD - 1, (kb + SLAB_PD - 1) % SLAB_PD);
-            const int st = kb % SLAB_PD;
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const double bv = B_LDS ? bp[(size_t)(16 * kb + 4 * t4) * ldb] : b[st][t4];
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[st][t4], bv, x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[st][t4], bv, x1, 0, 0, 0);
-            }
-            if (COPY && (kb & 3) == wv) {
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) store_wt(&cp[(size_t)(16 * kb + 4 * t4) * ldc], b[st][t4]);
-            }
-        }
-    }
-};
-
 // rowoff 1: the next pivot's row block; 2: the one after it (so that what the chain needs from the main list is a step further away)
 __device__ __forceinline__ void sweep_slab_item(const SweepDesc &D, int p, int s, int rowoff, double *lds, unsigned long long *dbg_ready = nullptr)
 {
@@ -2043,11 +2064,12 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
     // are bound by the chain itself, which is shortest with single blocks (no scratch copy, no tile jobs).  Measured on
     // MI355X with the round-3 tile loop and chain (tools/sweep_groups.py, profiles/r03_sweep_groups*.log: inverse time over
-    // N x g x chain CUs): g = 1 is fastest up to 54 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
-    // by the chain), 2 to 59, 3 to 70, 4 from 71 on -- groups of four at n = 10 000 (79 blocks) need 12 compute units for the chain
-    // (16.5 ms against 17.2 for groups of three; with 8 they lose: 17.9).
+    // N x g x chain CUs): g = 1 is fastest up to 48 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
+    // by the chain), 2 to 54, 3 to 57, 4 from 58 on (with the super-block inverse as row-slab jobs; as half-tile jobs its chain hid only
+    // from 71 blocks) -- groups of four at n = 10 000 (79 blocks) need 12 compute units for the chain (16.5 ms against 17.2 for groups
+    // of three; with 8 they lose: 17.9).
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 71 ? 4 : (nblk >= 60 ? 3 : (nblk >= 55 ? 2 : 1)));
+    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
@@ -2072,7 +2094,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // item table on the host, then to the device (pinned staging buffer of the workspace)
     int *it = ws.item0_host;
     auto size = [&](int p) { return sizes[(size_t)p]; };
-    auto m_cnt = [&](int sz) { return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + 2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)); };
+    auto m_cnt = [&](int sz) { return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + SLAB_ITEMS * (sz - 1)); };
     int *mit = it + (ng + 1);
     int *gs = it + 2 * (ng + 1);
     gs[0] = 0;
@@ -2121,7 +2143,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
         const double nrag = (rl < T && !last) ? (double)pn : 0.0;  // tile items of the ragged block row: rl / 128 of the MFMAs
         chunks += ((double)(pn * (pn + 1) / 2) - nrag + nrag * rl / T) * kch;  // tile items
         chunks += (double)pn * sz * 8 * sz;                                    // panel items (K = 128 sz, 128 sz columns)
-        if (sz > 1) chunks += 0.5 * sz * (2 * (sz - 1) + 2 * (sz - 1) * (sz - 1)) * 8;  // 128 x 64 x 128 jobs of the super-block inverse
+        if (sz > 1) chunks += (double)sz * (sz - 1) * sz * 8;  // super-block inverse: per block and other row, sz products of 128 x 128 x 128
     }
     it[ng] = (int)pos;
     mit[ng] = (int)mpos;
@@ -2177,9 +2199,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once -- the 2 (g-1)^2 half-tile jobs of a level of a four-block group are 18 -- and once the update hides the chain the
-    // workers go back to the tiles: for multi-block groups 16 CUs up to 74 blocks, 12 up to 86, 8 up to 115, 4 beyond; between
+    // workers go back to the tiles: for multi-block groups 16 CUs up to 74 blocks, 12 up to 86, 8 up to 100, 4 beyond; between
     // single blocks (a pivot and three times eight slab items per step) 12 CUs below 28 blocks, 8 above
-    const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 74 ? 16 : (nblk <= 86 ? 12 : (nblk <= 115 ? 8 : 4)));
+    const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 74 ? 16 : (nblk <= 86 ? 12 : (nblk <= 100 ? 8 : 4)));
     D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
     D.rl = rl;
