@@ -208,9 +208,6 @@ __device__ __forceinline__ void pivot_chain_wave(const double *Ain, size_t ldin,
                 for (int t4 = 0; t4 < 4; ++t4) g = __builtin_amdgcn_mfma_f64_16x16x4f64(v[t4], bb[t4], g, 0, 0, 0);
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) dt = __builtin_amdgcn_mfma_f64_16x16x4f64(g[t4], bb[t4], dt, 0, 0, 0);
-                // g is also what the workers need as the rows of micro-block K + 1 of Ns: they leave that block out
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) L.ns(reg >> 1, lq + 4 * reg)[MB * (K + 1) + l15] = g[reg];
             }
             PV_STAMP(K, 2);
             __syncthreads();  // barrier 2
@@ -270,34 +267,25 @@ __device__ __forceinline__ void pivot_worker(const double *Ain, size_t ldin, dou
             __syncthreads();  // barrier 1: Pms(K), image K and Dt are in LDS
             PV_STAMP(K, 1);
             if (W == 0 && ph && lane == 0 && K == 0) ph[1] = wall_clock64();
-            // Ns = -(G Pm) for the row blocks other than K (set to +Pm below) and K + 1 (the chain wave's): the remaining six (seven
-            // in the last round) are dealt out W, W + 3 (, W + 6): independent MFMA chains, interleaved
+            // Ns = -(G Pm) for the row blocks W, W + 3, W + 6 (independent MFMA chains, interleaved); the one of block K itself is
+            // computed on whatever the image holds there and dropped
             {
-                const int nrem = K + 1 < NMB ? NMB - 2 : NMB - 1;
-                constexpr int NR = 3;
+                constexpr int NR = (NMB - W + 2) / 3;
                 double4_t g[NR];
-                int rbs[NR];
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    g[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
-                    const int t = W + 3 * i;
-                    rbs[i] = t < K ? t : t + (K + 1 < NMB ? 2 : 1);
-                    if (t >= nrem) rbs[i] = 0;  // nothing left for this slot: computed on block 0 and dropped
-                }
+                for (int i = 0; i < NR; ++i) g[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
                     const int kk = 4 * t4 + lq;
                     const double a = Pms[kk * MB + l15];
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        if (i < 2 || (W == 0 && K + 1 == NMB)) g[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, G[pv_off(kk) + MB * rbs[i] + l15], g[i], 0, 0, 0);
-                    }
+                    for (int i = 0; i < NR; ++i) g[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, G[pv_off(kk) + MB * (W + 3 * i) + l15], g[i], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < NR; ++i)
-                    if (W + 3 * i < nrem) {
+                    if (W + 3 * i != K) {
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) L.ns(reg >> 1, lq + 4 * reg)[MB * rbs[i] + l15] = g[i][reg];
+                        for (int reg = 0; reg < 4; ++reg) L.ns(reg >> 1, lq + 4 * reg)[MB * (W + 3 * i) + l15] = g[i][reg];
                     }
             }
             if (W == 2) {
