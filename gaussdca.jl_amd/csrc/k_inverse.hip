@@ -2066,8 +2066,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // MI355X with the round-3 tile loop and chain (tools/sweep_groups.py, profiles/r03_sweep_groups*.log: inverse time over
     // N x g x chain CUs): g = 1 is fastest up to 48 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
     // by the chain), 2 to 54, 3 to 57, 4 from 58 on (with the super-block inverse as row-slab jobs; as half-tile jobs its chain hid only
-    // from 71 blocks) -- groups of four at n = 10 000 (79 blocks) need 12 compute units for the chain (16.5 ms against 17.2 for groups
-    // of three; with 8 they lose: 17.9).
+    // from 71 blocks).
     static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
     int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1)));
     if (nblk < 2 * g) g = 1;
