@@ -132,48 +132,94 @@ __global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A,
                                                     double *__restrict__ Te)
 {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, l15 = lane & 15, lq = lane >> 4;
     const int ss = sdim * sdim;
-    double *B0 = dsm, *B1 = dsm + ss;
-    double *vv = dsm + 2 * ss;  // [32] reflector
-    double *ww = vv + 32;       // [32]
+    double *V = dsm;
+    double *vv = dsm + ss;  // [32] reflector
+    double *ww = vv + 32;   // [32]
     const long long pair = blockIdx.x;
     int i, j;
     pair_decode(pair, i, j);
-    const double *src = A + (size_t)j * sdim + (size_t)i * sdim * ld;
-    const double *Li = Ld + (size_t)i * ss, *Lj = Ld + (size_t)j * ss;
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        B0[e] = src[(size_t)r + (size_t)c * ld];  // X(r, c), column-major
+    const double *src = A + (size_t)j * sdim + (size_t)i * sdim * ld;   // X(r, c) = src[r + c ld]
+    const double *Li = Ld + (size_t)i * ss, *Lj = Ld + (size_t)j * ss;  // lower triangular, zeros above the diagonal
+    // The three products on the matrix pipe, padded to 32 x 32 (2 x 2 tiles of 16 x 16, k in steps of 4), chained through
+    // registers: the MFMA operand layout (element (l15, 4 k4 + lq) in the register of step k4) is the accumulator layout
+    // (element (l15, lq + 4 reg) in register reg), so a product computed TRANSPOSED is the next product's operand as it stands.
+    //   T1^T(c, r) = sum_m L_i(m, c) X(r, m)              operands from memory (X in place, L_i from the factor array)
+    //   MM(r, c)   = sum_m L_j(m, r) T1(m, c)             a = T1^T from registers
+    //   V(r, r')   = sum_m MM(r, m) MM(r', m)             both operands = MM from registers
+    // (as 400 / 64 dot products per lane out of LDS the three of them were most of this kernel)
+    const int K4 = (sdim + 3) >> 2;
+    const bool two = sdim > 16;
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    double4_t T1T[2][2], MMt[2][2], Vt[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) T1T[x][y] = MMt[x][y] = Vt[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        if (k4 < K4) {
+            const int m = 4 * k4 + lq;
+            double aX[2], bL[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int rc = 16 * blk + l15;
+                const bool ok = m < sdim && rc < sdim;
+                aX[blk] = ok ? src[(size_t)rc + (size_t)m * ld] : 0.0;
+                bL[blk] = ok ? Li[m + rc * sdim] : 0.0;
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    if (two || (cb == 0 && rb == 0)) T1T[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aX[rb], bL[cb], T1T[cb][rb], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    // T1 = X L_i :  T1(r,c) = sum_{m >= c} X(r,m) L_i(m,c)
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        double a = 0.0;
-        for (int m = c; m < sdim; ++m) a += B0[r + m * sdim] * Li[m + c * sdim];
-        B1[e] = a;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        if (k4 < K4) {
+            const int m = 4 * k4 + lq;
+            double bJ[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int r = 16 * blk + l15;
+                bJ[blk] = (m < sdim && r < sdim) ? Lj[m + r * sdim] : 0.0;
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    if (two || (cb == 0 && rb == 0))
+                        MMt[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(T1T[cb][k4 >> 2][k4 & 3], bJ[rb], MMt[rb][cb], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    // MM = L_j^T T1 :  MM(r,c) = sum_{m >= r} L_j(m,r) T1(m,c)
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        double a = 0.0;
-        for (int m = r; m < sdim; ++m) a += Lj[m + r * sdim] * B1[m + c * sdim];
-        B0[e] = a;
+    // V: the tiles on and below the diagonal; the others are their mirror images (V is bitwise symmetric by construction)
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        if (k4 < K4) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb <= rb; ++cb)
+                    if (two || rb == 0)
+                        Vt[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(MMt[cb][k4 >> 2][k4 & 3], MMt[rb][k4 >> 2][k4 & 3], Vt[rb][cb], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    // V = MM MM^T, computed from the ordered index pair so that it is bitwise symmetric
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-        double a = 0.0;
-        for (int m = 0; m < sdim; ++m) a += B0[rr + m * sdim] * B0[cc + m * sdim];
-        B1[e] = a;
-    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb <= rb; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 16 * rb + l15, c = 16 * cb + lq + 4 * reg;
+                if (r < sdim && c < sdim && r >= c) {
+                    V[r + c * sdim] = Vt[rb][cb][reg];
+                    V[c + r * sdim] = Vt[rb][cb][reg];
+                }
+            }
     __syncthreads();
 
-    double *V = B1;
     for (int k = 0; k + 2 < sdim; ++k) {
         const int m = sdim - k - 1;                  // order of the trailing block V22 = V[k+1.., k+1..]
         const double *x = V + (k + 1) + k * sdim;    // x[t] = V(k+1+t, k)
@@ -188,21 +234,26 @@ __global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A,
             const double beta = 2.0 / (tail + v0 * v0);
             if (lane < m) vv[lane] = (lane == 0) ? v0 : xt;
             __syncthreads();
-            // p = beta V22 v   (lane r < m owns row r)
+            // p = beta V22 v: lane (r = lane & 31, h = lane >> 5) sums the columns c = h, h + 2, .. of row r; the two halves meet
+            // through one cross-lane add (fixed lane <-> element map: no integer division in the loop)
+            const int r = lane & 31, h = lane >> 5;
             double pr = 0.0;
-            if (lane < m) {
-                const double *row = V + (k + 1 + lane) + (k + 1) * sdim;
-                for (int c = 0; c < m; ++c) pr += row[c * sdim] * vv[c];
-                pr *= beta;
+            if (r < m) {
+                const double *row = V + (k + 1 + r) + (k + 1) * sdim;
+                for (int c = h; c < m; c += 2) pr += row[c * sdim] * vv[c];
             }
-            const double pv = wave_sum((lane < m) ? pr * vv[lane] : 0.0);
+            pr += __shfl_xor(pr, 32);
+            pr *= beta;
+            const double vr = (r < m) ? vv[r] : 0.0;
+            const double pv = wave_sum((lane < m) ? pr * vr : 0.0);
             const double K = 0.5 * beta * pv;
-            if (lane < m) ww[lane] = pr - K * vv[lane];
+            const double wr = pr - K * vr;
+            if (lane < m) ww[lane] = wr;
             __syncthreads();
-            // V22 -= v w^T + w v^T
-            for (int e = lane; e < m * m; e += 64) {
-                const int r = e % m, c = e / m;
-                V[(k + 1 + r) + (k + 1 + c) * sdim] -= vv[r] * ww[c] + ww[r] * vv[c];
+            // V22 -= v w^T + w v^T, the same map
+            if (r < m) {
+                double *row = V + (k + 1 + r) + (k + 1) * sdim;
+                for (int c = h; c < m; c += 2) row[c * sdim] -= vr * ww[c] + wr * vv[c];
             }
             __syncthreads();
         }
@@ -325,7 +376,7 @@ void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld,
     if (npairs <= 0) return;
     const long long tstride = (npairs + 63) / 64 * 64;
     double *Td = Tws, *Te = Tws + (size_t)sdim * tstride;
-    const size_t lds1 = (size_t)(2 * sdim * sdim + 64) * sizeof(double);
+    const size_t lds1 = (size_t)(sdim * sdim + 64) * sizeof(double);
     hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)npairs), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
     const size_t lds2 = (size_t)2 * sdim * 64 * sizeof(double);
     hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S, sc);
