@@ -120,35 +120,29 @@ void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, doub
 
 // ---- DI ---------------------------------------------------------------------------------------------
 // gamma = eigenvalues of V = MM MM^T, MM = L_j^T X L_i (s x s).  Two kernels:
-//   k_di_tridiag: one wave per site pair -- the three small products, then a Householder reduction of
-//                 V to tridiagonal form (4/3 s^3 flops; lanes <-> matrix elements, reflector vectors
-//                 broadcast through LDS).  Writes the diagonal / sub-diagonal to HBM, index-major.
+//   k_di_tridiag: one wave per TWO site pairs -- the three small products of each (MFMA, chained through registers), then a
+//                 Householder reduction of both V to tridiagonal form side by side (4/3 s^3 flops; lane r of a half-wave owns
+//                 row r, reflector vectors broadcast through LDS).  Writes the diagonal / sub-diagonal to HBM, index-major.
 //   k_di_ql:      one LANE per site pair -- implicit QL (EISPACK tql1) on its tridiagonal, eigenvalues
 //                 only, then DI = z + 1/2 sum log(1 + sqrt(1 + 4 gamma)).
 // ~10x fewer flops than a Jacobi sweep on the full matrix, and the serial part (QL) runs 64 pairs wide.
-__global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A, size_t ld,
-                                                    const double *__restrict__ Ld, int sdim, long long npairs,
-                                                    long long tstride, double *__restrict__ Td,
-                                                    double *__restrict__ Te)
+// V = MM MM^T of one site pair into LDS (see k_di_tridiag): the three products on the matrix pipe, padded to 32 x 32 (2 x 2 tiles
+// of 16 x 16, k in steps of 4), chained through registers: the MFMA operand layout (element (l15, 4 k4 + lq) in the register of
+// step k4) is the accumulator layout (element (l15, lq + 4 reg) in register reg), so a product computed TRANSPOSED is the next
+// product's operand as it stands.
+//   T1^T(c, r) = sum_m L_i(m, c) X(r, m)              operands from memory (X in place, L_i from the factor array)
+//   MM(r, c)   = sum_m L_j(m, r) T1(m, c)             a = T1^T from registers
+//   V(r, r')   = sum_m MM(r, m) MM(r', m)             both operands = MM from registers
+// (as 400 / 64 dot products per lane out of LDS the three of them were most of this kernel)
+__device__ __forceinline__ void di_pair_products(const double *__restrict__ A, size_t ld, const double *__restrict__ Ld, int sdim,
+                                                 long long pair, double *V, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) double dsm[];
-    const int lane = threadIdx.x, l15 = lane & 15, lq = lane >> 4;
+    const int l15 = lane & 15, lq = lane >> 4;
     const int ss = sdim * sdim;
-    double *V = dsm;
-    double *vv = dsm + ss;  // [32] reflector
-    double *ww = vv + 32;   // [32]
-    const long long pair = blockIdx.x;
     int i, j;
     pair_decode(pair, i, j);
     const double *src = A + (size_t)j * sdim + (size_t)i * sdim * ld;   // X(r, c) = src[r + c ld]
     const double *Li = Ld + (size_t)i * ss, *Lj = Ld + (size_t)j * ss;  // lower triangular, zeros above the diagonal
-    // The three products on the matrix pipe, padded to 32 x 32 (2 x 2 tiles of 16 x 16, k in steps of 4), chained through
-    // registers: the MFMA operand layout (element (l15, 4 k4 + lq) in the register of step k4) is the accumulator layout
-    // (element (l15, lq + 4 reg) in register reg), so a product computed TRANSPOSED is the next product's operand as it stands.
-    //   T1^T(c, r) = sum_m L_i(m, c) X(r, m)              operands from memory (X in place, L_i from the factor array)
-    //   MM(r, c)   = sum_m L_j(m, r) T1(m, c)             a = T1^T from registers
-    //   V(r, r')   = sum_m MM(r, m) MM(r', m)             both operands = MM from registers
-    // (as 400 / 64 dot products per lane out of LDS the three of them were most of this kernel)
     const int K4 = (sdim + 3) >> 2;
     const bool two = sdim > 16;
     typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -218,51 +212,75 @@ __global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A,
                     V[c + r * sdim] = Vt[rb][cb][reg];
                 }
             }
-    __syncthreads();
+}
 
+// sum over the 32 lanes of the caller's half of the wave
+__device__ __forceinline__ double half_sum(double v)
+{
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per TWO site pairs: the products of each pair with the whole wave (the MFMA tiles are 64 lanes wide), then the
+// Householder reduction of both V side by side, 32 lanes each (lane r of a half owns row r: the reduction keeps at most 31 lanes
+// busy, so two pairs per wave halve its instruction count per pair).  Branch-free in the pair: a column that is already reduced
+// gets the zero reflector.
+__global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A, size_t ld,
+                                                    const double *__restrict__ Ld, int sdim, long long npairs,
+                                                    long long tstride, double *__restrict__ Td,
+                                                    double *__restrict__ Te)
+{
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int ss = sdim * sdim;
+    const long long pair0 = 2 * (long long)blockIdx.x;
+    di_pair_products(A, ld, Ld, sdim, pair0, dsm, lane);
+    if (pair0 + 1 < npairs) di_pair_products(A, ld, Ld, sdim, pair0 + 1, dsm + ss + 64, lane);
+    __syncthreads();
+    const long long pair = pair0 + h;
+    const bool live = pair < npairs;
+    double *V = dsm + h * (ss + 64);
+    double *vv = V + ss;   // [32] reflector
+    double *ww = vv + 32;  // [32]
     for (int k = 0; k + 2 < sdim; ++k) {
         const int m = sdim - k - 1;                  // order of the trailing block V22 = V[k+1.., k+1..]
         const double *x = V + (k + 1) + k * sdim;    // x[t] = V(k+1+t, k)
-        const double xt = (lane < m) ? x[lane] : 0.0;
-        const double sigma = wave_sum(xt * xt);
-        const double x0 = x[0];
+        const double xt = (live && r < m) ? x[r] : 0.0;
+        const double sigma = half_sum(xt * xt);
+        const double x0 = live ? x[0] : 0.0;
         const double tail = sigma - x0 * x0;
-        double alpha = x0;  // sub-diagonal entry if the column is already reduced
-        if (tail > 0.0 && sigma > 0.0) {
-            alpha = (x0 >= 0.0) ? -sqrt(sigma) : sqrt(sigma);
-            const double v0 = x0 - alpha;
-            const double beta = 2.0 / (tail + v0 * v0);
-            if (lane < m) vv[lane] = (lane == 0) ? v0 : xt;
-            __syncthreads();
-            // p = beta V22 v: lane (r = lane & 31, h = lane >> 5) sums the columns c = h, h + 2, .. of row r; the two halves meet
-            // through one cross-lane add (fixed lane <-> element map: no integer division in the loop)
-            const int r = lane & 31, h = lane >> 5;
-            double pr = 0.0;
-            if (r < m) {
-                const double *row = V + (k + 1 + r) + (k + 1) * sdim;
-                for (int c = h; c < m; c += 2) pr += row[c * sdim] * vv[c];
-            }
-            pr += __shfl_xor(pr, 32);
-            pr *= beta;
-            const double vr = (r < m) ? vv[r] : 0.0;
-            const double pv = wave_sum((lane < m) ? pr * vr : 0.0);
-            const double K = 0.5 * beta * pv;
-            const double wr = pr - K * vr;
-            if (lane < m) ww[lane] = wr;
-            __syncthreads();
-            // V22 -= v w^T + w v^T, the same map
-            if (r < m) {
-                double *row = V + (k + 1 + r) + (k + 1) * sdim;
-                for (int c = h; c < m; c += 2) row[c * sdim] -= vr * ww[c] + wr * vv[c];
-            }
-            __syncthreads();
+        const bool act = tail > 0.0 && sigma > 0.0;
+        const double alpha = act ? ((x0 >= 0.0) ? -sqrt(sigma) : sqrt(sigma)) : x0;  // x0: the column is already reduced
+        const double v0 = x0 - alpha;
+        const double beta = act ? 2.0 / (tail + v0 * v0) : 0.0;
+        const double vr = (act && r < m) ? ((r == 0) ? v0 : xt) : 0.0;
+        if (r < m) vv[r] = vr;
+        __syncthreads();
+        // p = beta V22 v: lane r sums row r
+        double pr = 0.0;
+        if (live && r < m) {
+            const double *row = V + (k + 1 + r) + (k + 1) * sdim;
+            for (int c = 0; c < m; ++c) pr += row[c * sdim] * vv[c];
         }
-        if (lane == 0) {
+        pr *= beta;
+        const double pv = half_sum(pr * vr);
+        const double K = 0.5 * beta * pv;
+        const double wr = pr - K * vr;
+        if (r < m) ww[r] = wr;
+        __syncthreads();
+        // V22 -= v w^T + w v^T
+        if (live && r < m) {
+            double *row = V + (k + 1 + r) + (k + 1) * sdim;
+            for (int c = 0; c < m; ++c) row[c * sdim] -= vr * ww[c] + wr * vv[c];
+        }
+        __syncthreads();
+        if (live && r == 0) {
             Td[(size_t)k * tstride + pair] = V[k + k * sdim];
             Te[(size_t)k * tstride + pair] = alpha;
         }
     }
-    if (lane == 0) {
+    if (live && r == 0) {
         if (sdim >= 2) {
             const int k = sdim - 2;
             Td[(size_t)k * tstride + pair] = V[k + k * sdim];
@@ -376,8 +394,8 @@ void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld,
     if (npairs <= 0) return;
     const long long tstride = (npairs + 63) / 64 * 64;
     double *Td = Tws, *Te = Tws + (size_t)sdim * tstride;
-    const size_t lds1 = (size_t)(sdim * sdim + 64) * sizeof(double);
-    hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)npairs), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
+    const size_t lds1 = (size_t)2 * (sdim * sdim + 64) * sizeof(double);
+    hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)((npairs + 1) / 2)), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
     const size_t lds2 = (size_t)2 * sdim * 64 * sizeof(double);
     hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S, sc);
 }
