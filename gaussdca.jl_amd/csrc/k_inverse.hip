@@ -871,9 +871,11 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
 //     rem(p)       every other tile of update p
 //   M list (the serial chain), for group q = 0, 1, ...
 //     M(q)         Pg(q): gather the diagonal super-block into a dense scratch matrix, sweep it block by block (128 x 128
-//                  pivot, then tile products for the other blocks of the scratch matrix), scatter -Pg back
+//                  pivot, then one level of row-slab jobs for the other blocks of the scratch matrix), scatter -Pg back
 //     mpanel(q)    the panel items of the NEXT group's row blocks
 //     diag(q+1)    the tiles of update q inside the next group's diagonal super-block  -> M(q+1) can start
+//     (a schedule of single blocks has, instead of the last two: slab(q), xslab(q), slab2(q) -- the next pivot row's panel and
+//      diagonal tile, the tile below it and the row after that as fused 16-row slabs, see sweep_slab_item)
 //   The chain never waits for the bulk of an update, only for the early diag2 / rest items of the previous group.
 // ONE launch of 2 workgroups per compute unit runs the list: a workgroup takes the next item off a device-wide counter,
 // waits (one lane polling, s_sleep) until the few flags the item depends on are set, does it, publishes its result
