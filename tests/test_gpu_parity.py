@@ -461,6 +461,48 @@ def test_every_inverse_schedule_matches_lapack(env):
         assert rel <= 1e-10 and sym, (env, n, rel, sym)    # cond ~ 1e2: far inside the 1e-6 bar for scores
 
 
+_TRACE_SCRIPT = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import gaussdca.jl_amd as g
+ctx = g.Context(0)
+rng = np.random.default_rng(11)
+n = 1536
+B = rng.standard_normal((n, 40))
+A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
+X = g.inv_cholesky(A, ctx=ctx)
+Xr = np.linalg.inv(A)
+print(json.dumps({"rel": float(np.max(np.abs(X - Xr)) / np.max(np.abs(Xr)))}))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group,items", [("1", 12 + 11 * 8 + 10 * 16), ("4", None)])
+def test_sweep_trace_lists_every_chain_item(tmp_path, group, items):
+    """GDCA_SWEEP_TRACE (the kernel's own time stamps, tools/sweep_trace.py): the inverse stays correct with the trace on, and the
+    file lists every item of the serial chain with end >= start -- for single blocks (n = 1536: 12 pivots, 11 x 8 slab items of
+    the next row block, 10 x (8 + 8) for the tile below it and the row after) and for a multi-block schedule."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trace = tmp_path / "trace.txt"
+    e = dict(os.environ, GDCA_GROUP=group, GDCA_SWEEP_TRACE=str(trace))
+    r = subprocess.run([sys.executable, "-c", _TRACE_SCRIPT, root], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["rel"] <= 1e-10
+    lines = trace.read_text().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    rows = [l.split() for l in lines if not l.startswith("#")]
+    assert head[0].startswith("# nblk 12 g %s" % group)
+    assert any(l.startswith("# pivot items: 12;") for l in head)
+    if items is not None:
+        assert len(rows) == items
+    assert len(rows) > 12 and all(float(b) >= float(a) > -1e-9 for _, _, a, b in rows)
+
+
 @pytest.mark.parametrize("N,M,score,pc", [(430, 4000, "frob", 0.8), (260, 5000, "DI", 0.2)])
 def test_mid_size_families_match_oracle(g, ctx, o, N, M, score, pc):
     """Whole hot path against the oracle at sizes where the production schedules are active: N = 430 (n = 8600,
