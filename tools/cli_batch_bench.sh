@@ -16,7 +16,7 @@ for f, (N, M) in enumerate(batch.batch_sizes(256)[:F]):
 print("generated", F, "families")
 PY
 du -sh $D/in | cut -f1
-for k in 1 2; do
+for k in ${INFLIGHT:-1 2}; do
   gaussdca.jl_amd/gdca_cli --batch $D/in --out $D/out --gpus 1 --inflight $k 2>&1 | tail -2
 done
 ls $D/out | wc -l
