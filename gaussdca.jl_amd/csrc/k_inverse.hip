@@ -2201,9 +2201,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once -- the row-slab jobs of a level of a four-block group are 24 -- and once the update hides the chain the workers go
     // back to the tiles: for multi-block groups 16 CUs up to 63 blocks, 12 up to 68, 10 up to 74, 6 up to 90 (n = 10 000: 16.5 ms
-    // with 6, 16.85 with 12, 20.8 with 4), 4 beyond; between single blocks (a pivot and three times eight slab items per step) 12
+    // with 6, 16.85 with 12, 20.8 with 4), 4 up to 120, 2 beyond (n = 20 000: 123.1 ms with 2, 123.75 with 4); between single blocks (a pivot and three times eight slab items per step) 12
     // CUs below 28 blocks, 8 above
-    const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 63 ? 16 : (nblk <= 68 ? 12 : (nblk <= 74 ? 10 : (nblk <= 90 ? 6 : 4))));
+    const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 63 ? 16 : (nblk <= 68 ? 12 : (nblk <= 74 ? 10 : (nblk <= 90 ? 6 : (nblk <= 120 ? 4 : 2)))));
     D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
     D.n_real = n_real;
     D.rl = rl;
