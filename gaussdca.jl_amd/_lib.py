@@ -49,7 +49,7 @@ class Stats(C.Structure):
         ("theta", C.c_double), ("Meff", C.c_double), ("pair_identity_sum", C.c_uint64),
         ("thresh", C.c_int32), ("info", C.c_int32),
         ("N", C.c_int32), ("M", C.c_int32), ("q", C.c_int32), ("n", C.c_int32), ("n_pad", C.c_int32),
-        ("update_launches", C.c_int32),
+        ("update_launches", C.c_int32), ("inverse_batch", C.c_int32),
         ("ms_total", C.c_double), ("ms_theta", C.c_double), ("ms_weights", C.c_double),
         ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
         ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
@@ -73,6 +73,7 @@ SYMBOLS = {
     "gdca_ctx_synchronize": (C.c_int, [_ctx]),
     "gdca_last_error": (C.c_char_p, [_ctx]),
     "gdca_ctx_set_timing": (C.c_int, [_ctx, C.c_int32]),
+    "gdca_ctx_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_char_p]),
     "gdca_run": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
                            C.POINTER(Stats)]),
     "gdca_run_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p,
@@ -98,6 +99,7 @@ SYMBOLS = {
                                            C.c_void_p]),
     "gdca_covariance_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "gdca_spd_inverse_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _i32p]),
+    "gdca_spd_inverse_batch_dev": (C.c_int, [C.POINTER(_ctx), C.c_int32, C.POINTER(C.c_void_p), _i32p, _i32p]),
     "gdca_fn_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_di_dev": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_apc_dev": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
@@ -209,6 +211,15 @@ class Context:
     def set_timing(self, on: bool):
         self.check(self.lib.gdca_ctx_set_timing(self.h, 1 if on else 0))
 
+    def set_option(self, key: str, value) -> None:
+        """Tuning switch of this context (gdca_ctx_set_option): key = a GDCA_* variable's name, with or without the prefix."""
+        self.check(self.lib.gdca_ctx_set_option(self.h, str(key).encode(), str(value).encode()))
+
+    def set_options(self, **kv) -> "Context":
+        for k, v in kv.items():
+            self.set_option(k, v)
+        return self
+
     # ---- fused path ----
     def run(self, Zf: np.ndarray, q: int, pseudocount: float, theta: float, score: int, apc: bool = True):
         """Zf: int8, shape (N, M), Fortran-contiguous.  Returns (S[N,N], stats dict)."""
@@ -255,7 +266,22 @@ def run_dev_phased(ctxs, Z_ptrs, Ns, Ms, qs, pseudocount: float, theta: float, s
     zp = (C.c_void_p * K)(*[C.c_void_p(int(z)) for z in Z_ptrs])
     sp = (C.c_void_p * K)(*[C.c_void_p(int(x)) for x in S_ptrs])
     i32 = lambda v: (C.c_int32 * K)(*[int(x) for x in v])  # noqa: E731
+    # (the library copies a failing member's message to the leader: ctxs[0]'s last_error names the member)
     ctxs[0].check(ctxs[0].lib.gdca_run_dev_phased(hs, K, zp, i32(Ns), i32(Ms), i32(qs), C.byref(prm), sp))
+
+
+def spd_inverse_batch_dev(ctxs, A_ptrs, ns):
+    """K independent SPD inverses in place on device matrices (gdca_spd_inverse_batch_dev): the small ones share merged launches
+    of the sweep kernel.  Returns the list of info values; raises PosDefException(info of the first failing member)."""
+    K = len(ctxs)
+    assert K >= 1 and len(A_ptrs) == len(ns) == K
+    hs = (_ctx * K)(*[c.h for c in ctxs])
+    ap = (C.c_void_p * K)(*[C.c_void_p(int(a)) for a in A_ptrs])
+    nn = (C.c_int32 * K)(*[int(x) for x in ns])
+    info = (C.c_int32 * K)()
+    rc = ctxs[0].lib.gdca_spd_inverse_batch_dev(hs, K, ap, nn, info)
+    ctxs[0].check(rc, next((int(i) for i in info if i), 0))
+    return [int(i) for i in info]
 
 
 class DeviceBuffer:

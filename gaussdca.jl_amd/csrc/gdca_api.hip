@@ -1,10 +1,13 @@
 // C-ABI of libgdca.so (see include/gdca.h): context, workspace, the fused device pipeline and
 // the operator-level entry points.  Host-side orchestration only; all arithmetic is in the
 // k_*.hip kernels.  No CPU fallback exists: every entry point needs a HIP device.
+#include <algorithm>
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 
 #include "gdca_internal.h"
 
@@ -30,6 +33,7 @@ struct gdca_ctx {
     hipStream_t stream;
     bool own_stream;
     bool timing;
+    gdca_tuning tune;          // this context's switches (gdca_ctx_set_option; GDCA_* environment at creation)
     char err[512];
     // named device buffers (grow-only)
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
@@ -47,8 +51,89 @@ struct gdca_ctx {
     bool pending;
     bool pend_timed;
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
+    int pend_batch;            // families that shared this run's SPD-inverse launch (1: a launch of its own)
+    hipEvent_t pend_upd_ev[2]; // the two events around that launch (a merged launch's are its first member's)
     double pend_upd_flops;
 };
+
+// ---- tuning switches: environment at context creation, gdca_ctx_set_option afterwards -----------------------------------------
+static bool parse_long(const char *v, long *out)
+{
+    if (!v || !*v) return false;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v || *end) return false;
+    *out = x;
+    return true;
+}
+
+bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
+{
+    if (!t || !key || !value) return false;
+    char k[64];
+    size_t n = 0;
+    if (!strncasecmp(key, "GDCA_", 5)) key += 5;
+    for (; key[n] && n + 1 < sizeof(k); ++n) k[n] = (char)toupper((unsigned char)key[n]);
+    k[n] = 0;
+    if (!strcmp(k, "SWEEP_TRACE")) {
+        if (strlen(value) >= sizeof(t->sweep_trace)) return false;
+        strcpy(t->sweep_trace, value);
+        return true;
+    }
+    if (!strcmp(k, "HAMMING_MODE")) {
+        const char c = (char)tolower((unsigned char)value[0]);
+        t->hamming_mode = c == 'f' ? 0 : (c == 'b' ? 1 : -1);
+        return c == 'f' || c == 'b' || c == 'a' || c == 0;  // full | bound | auto
+    }
+    if (!strcmp(k, "FORCE_FALLBACK")) {  // any value but "" and "0" switches it on (as DCAUTILS_FORCE_FALLBACK in the reference's tests)
+        t->force_fallback = (*value && strcmp(value, "0") != 0) ? 1 : 0;
+        return true;
+    }
+    long x = 0;
+    if (!parse_long(value, &x)) return false;
+    struct { const char *name; int *field; long lo, hi; } ints[] = {
+        {"GROUP", &t->group, -1, 4},        {"RAMP", &t->ramp, 0, 1},          {"RAGGED", &t->ragged, 0, 1},
+        {"REM_TAIL", &t->rem_tail, -1, 1 << 20}, {"PANEL_HALVES", &t->panel_halves, -1, 1}, {"SLAB", &t->slab, 0, 1},
+        {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
+        {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
+        {"MERGE_MCUS", &t->merge_mcus, -1, 16},
+    };
+    for (auto &e : ints)
+        if (!strcmp(k, e.name)) {
+            if (x < e.lo || x > e.hi) return false;
+            *e.field = (int)x;
+            return true;
+        }
+    if (!strcmp(k, "SWEEP_TIMEOUT_MS")) {
+        if (x < 0) return false;
+        t->sweep_timeout_ms = x;
+        return true;
+    }
+    return false;
+}
+
+void gdca_tuning_from_env(gdca_tuning *t)
+{
+    memset(t, 0, sizeof(*t));
+    t->group = -1;
+    t->ramp = 1;
+    t->ragged = 1;
+    t->rem_tail = -1;
+    t->panel_halves = -1;
+    t->slab = 1;
+    t->ring = 8;
+    t->mcus = -1;
+    t->hamming_mode = -1;
+    t->merge = 4;
+    t->merge_blocks = 48;
+    t->merge_mcus = -1;
+    static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
+                                        "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
+                                        "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
+                                        "GDCA_MERGE_MCUS", "GDCA_SWEEP_TRACE"};
+    for (const char *nm : names)
+        if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
+}
 
 static gdca_status fail(gdca_ctx *ctx, gdca_status st, const char *fmt, const char *a, const char *b)
 {
@@ -120,6 +205,7 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     if (!ctx) return GDCA_ENOMEM;
     ctx->device = device_id;
     ctx->timing = true;
+    gdca_tuning_from_env(&ctx->tune);
     if (hipSetDevice(device_id) != hipSuccess) {
         free(ctx);
         return GDCA_EHIP;
@@ -240,6 +326,14 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled)
     return GDCA_OK;
 }
 
+gdca_status gdca_ctx_set_option(gdca_ctx *ctx, const char *key, const char *value)
+{
+    if (!ctx) return GDCA_EINVAL;
+    if (!key || !value) return fail(ctx, GDCA_EINVAL, "null option key or value%s%s", "", "");
+    if (!gdca_tuning_set(&ctx->tune, key, value)) return fail(ctx, GDCA_EINVAL, "unknown option or unusable value: %s=%s", key, value);
+    return GDCA_OK;
+}
+
 }  // extern "C"
 
 static gdca_status need_events(gdca_ctx *ctx, int n)
@@ -290,13 +384,12 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t), s));
     gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M, q, sc);  // (also the symbol-range check)
-    // GDCA_FORCE_FALLBACK (any value but "0"; read per call so that a test can switch it): the independent byte-compare kernel
-    // instead of the bit-sliced one -- the analogue of DCAUTILS_FORCE_FALLBACK in the reference's tests (test/runtests.jl:78-86)
-    const char *fb = getenv("GDCA_FORCE_FALLBACK");
-    if (fb && *fb && strcmp(fb, "0") != 0)
+    // option GDCA_FORCE_FALLBACK: the independent byte-compare kernel instead of the bit-sliced one -- the analogue of
+    // DCAUTILS_FORCE_FALLBACK in the reference's tests (test/runtests.jl:78-86)
+    if (ctx->tune.force_fallback)
         gdca_launch_hamming_fallback(s, Zd, (int32_t *)ctx->hcnt.p, N, M, sc);
     else
-        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc);
+        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
     // Meff is one long dependent chain on a single CU: run it on the side stream, next to the kernels that
@@ -316,7 +409,7 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim;
     const int shift = gdca_fix_shift(M);
-    const int TJ = gdca_tally_tj(q);
+    const int TJ = gdca_tally_tj(q, ctx->tune.tally_tj);
     CHK(ensure(ctx, ctx->Zt, (size_t)N * M));
     CHK(ensure(ctx, ctx->Zp, (size_t)round_up(N, 64) * M + 64));
     CHK(ensure(ctx, ctx->Pifix, (size_t)N * 32 * sizeof(unsigned long long)));
@@ -334,17 +427,16 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
                             (double *)ctx->Pipc.p);
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
                            (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
-                           (const double *)ctx->Pipc.p, mode, out, ld);
+                           (const double *)ctx->Pipc.p, mode, out, ld, TJ);
     return check_launch(ctx, "tally");
 }
 
-static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, int *n_upd, double *upd_flops)
+// the workspace of one inverse: 2 x 4 panels G and H (pivot groups of up to four blocks, double-buffered by group parity), one
+// 128 x 128 pivot inverse, four 512 x 512 scratch matrices for a group's diagonal super-block, the sweep's flags and item table
+static gdca_status inverse_job(gdca_ctx *ctx, int n, int n_pad, gdca_inverse_job *job)
 {
-    hipStream_t s = ctx->stream;
     const size_t pbytes = (size_t)n_pad * GDCA_TILE * sizeof(double);
     const int nblk = n_pad / GDCA_TILE;
-    // 2 x 4 panels G and H (pivot groups of up to four blocks, double-buffered by group parity), one 128 x 128 pivot
-    // inverse, four 512 x 512 scratch matrices for a group's diagonal super-block, the sweep's flags and item table
     const size_t sg = (size_t)4 * GDCA_TILE * 4 * GDCA_TILE * sizeof(double);
     const size_t fbytes = gdca_inverse_flag_bytes(n_pad);
     CHK(ensure(ctx, ctx->G, (size_t)8 * pbytes));
@@ -358,7 +450,7 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
         HIPCHK(hipHostMalloc((void **)&ctx->item0_host, (size_t)3 * (nblk + 2) * sizeof(int), hipHostMallocDefault));
         ctx->item0_cap = 3 * (nblk + 2);
     }
-    gdca_inverse_ws ws;
+    gdca_inverse_ws &ws = job->ws;
     for (int w = 0; w < 8; ++w) {
         ws.G[w] = (double *)((char *)ctx->G.p + (size_t)w * pbytes);
         ws.H[w] = (double *)((char *)ctx->H.p + (size_t)w * pbytes);
@@ -373,6 +465,27 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     ws.item0_dev = (int *)((char *)ctx->Sg.p + 4 * sg + fbytes);
     ws.item0_host = ctx->item0_host;
     ws.update_cus = ctx->ncu;
+    job->A = (double *)ctx->A.p;
+    job->n_pad = n_pad;
+    job->n_real = n;
+    job->sc = (gdca_dev_scalars *)ctx->sc.p;
+    job->tune = &ctx->tune;
+    return GDCA_OK;
+}
+
+static gdca_status poison_inverse_ws(gdca_ctx *ctx, hipStream_t s)
+{
+    HIPCHK(hipMemsetAsync(ctx->G.p, 0xFF, ctx->G.cap, s));
+    HIPCHK(hipMemsetAsync(ctx->H.p, 0xFF, ctx->H.cap, s));
+    HIPCHK(hipMemsetAsync(ctx->P.p, 0xFF, ctx->P.cap, s));
+    HIPCHK(hipMemsetAsync(ctx->Sg.p, 0xFF, (size_t)4 * 4 * GDCA_TILE * 4 * GDCA_TILE * sizeof(double), s));
+    return GDCA_OK;
+}
+
+static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, int *n_upd, double *upd_flops)
+{
+    gdca_inverse_job job;
+    CHK(inverse_job(ctx, n, n_pad, &job));
     hipEvent_t *uev = nullptr;
     int max_ev = 0;
     if (timed) {
@@ -380,7 +493,18 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
         uev = ctx->ev + 16;
         max_ev = 2;
     }
-    gdca_launch_spd_inverse(s, (double *)ctx->A.p, n_pad, ws, (gdca_dev_scalars *)ctx->sc.p, n, uev, max_ev, n_upd, upd_flops);
+    // tests (option SWEEP_DEBUG): bit 4 = the panel / scratch buffers are poisoned with NaNs first (an item that reads a buffer
+    // before its producer wrote it can then not pass on the leftovers of an earlier, identical run); bit 3 = the merged kernel
+    // carries this single inverse
+    if (ctx->tune.sweep_debug & 16) CHK(poison_inverse_ws(ctx, ctx->stream));
+    if (ctx->tune.sweep_debug & 8) {
+        double fl = 0.0;
+        gdca_launch_spd_inverse_merged(ctx->stream, &job, 1, uev, max_ev, &fl);
+        if (n_upd) *n_upd = 1;
+        if (upd_flops) *upd_flops = fl;
+        return check_launch(ctx, "spd_inverse_merged");
+    }
+    gdca_launch_spd_inverse(ctx->stream, job, uev, max_ev, n_upd, upd_flops);
     return check_launch(ctx, "spd_inverse");
 }
 
@@ -463,6 +587,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->n = ctx->pend_n;
         st->n_pad = ctx->pend_npad;
         st->update_launches = ctx->pend_nupd;
+        st->inverse_batch = ctx->pend_batch;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
@@ -476,16 +601,15 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
             st->ms_weights = ms;
             HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3]));
             st->ms_covariance = ms;
+            // (a family whose inverse shared a merged launch with others reports its share of that launch: the launch's time
+            // divided by the families it carried -- the sum over the members is the launch)
+            const double share = 1.0 / (double)(ctx->pend_batch > 0 ? ctx->pend_batch : 1);
             HIPCHK(hipEventElapsedTime(&ms, ev[6], ev[4]));  // from the start of its turn (after any pipeline gate)
-            st->ms_inverse = ms;
+            st->ms_inverse = ms * share;
             HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
             st->ms_score = ms;
-            double upd = 0.0;
-            for (int k = 0; k < ctx->pend_nupd && 16 + 2 * k + 1 < ctx->n_ev; ++k) {
-                HIPCHK(hipEventElapsedTime(&ms, ev[16 + 2 * k], ev[16 + 2 * k + 1]));
-                upd += ms;
-            }
-            st->ms_inverse_update = upd;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
+            st->ms_inverse_update = ms * share;
         }
     }
     if (h.bad_symbol) return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
@@ -570,6 +694,61 @@ static gdca_status run_inverse(gdca_ctx *ctx)
     }
     ctx->pend_nupd = n_upd;
     ctx->pend_upd_flops = upd_flops;
+    ctx->pend_batch = 1;
+    if (timed) {
+        ctx->pend_upd_ev[0] = ev[16];
+        ctx->pend_upd_ev[1] = ev[17];
+    }
+    return GDCA_OK;
+}
+
+// The inverses of K members of a phase batch as ONE merged launch on the batch's stream (k_sweep_merged: small matrices, which
+// leave most of the chip idle when they run alone).  Every member keeps its own workspace, flags and scalars; the events around
+// the launch are the first member's.
+static gdca_status run_inverse_merged(gdca_ctx *const *mem, int K)
+{
+    gdca_ctx *ctx = mem[0];
+    hipStream_t s = ctx->stream;
+    gdca_inverse_job jobs[8];
+    double flops[8];
+    if (K > gdca_inverse_max_merge() || K > 8) return fail(ctx, GDCA_EINVAL, "too many members in a merged inverse%s%s", "", "");
+    bool timed = true;
+    for (int k = 0; k < K; ++k) {
+        timed = timed && mem[k]->pend_timed;
+        if (mem[k]->gate && mem[k]->gate->armed) HIPCHK(hipStreamWaitEvent(s, mem[k]->gate->ev[mem[k]->gate->last], 0));
+    }
+    for (int k = 0; k < K; ++k) {
+        if (mem[k]->pend_timed) HIPCHK(hipEventRecord(mem[k]->ev[6], s));
+        CHK(inverse_job(mem[k], mem[k]->pend_n, mem[k]->pend_npad, &jobs[k]));
+        if (ctx->tune.sweep_debug & 16) CHK(poison_inverse_ws(mem[k], s));
+    }
+    hipEvent_t *uev = nullptr;
+    if (timed) {
+        CHK(need_events(ctx, 18));
+        uev = ctx->ev + 16;
+    }
+    gdca_launch_spd_inverse_merged(s, jobs, K, uev, timed ? 2 : 0, flops);
+    CHK(check_launch(ctx, "spd_inverse_merged"));
+    for (int k = 0; k < K; ++k) {
+        gdca_ctx *m = mem[k];
+        if (m->pend_timed) HIPCHK(hipEventRecord(m->ev[4], s));
+        if (m->gate) {
+            gdca_gate *g = m->gate;
+            HIPCHK(hipEventRecord(g->ev[g->next], s));
+            g->last = g->next;
+            g->next = (g->next + 1) & 3;
+            g->armed = 1;
+        }
+        m->pend_nupd = k == 0 ? 1 : 0;
+        m->pend_upd_flops = flops[k];
+        m->pend_batch = K;
+        // (a member without timing of its own still gets valid events to read: the launch's, or none -- collect reads them only if timed)
+        m->pend_timed = m->pend_timed && timed;
+        if (timed) {
+            m->pend_upd_ev[0] = uev[0];
+            m->pend_upd_ev[1] = uev[1];
+        }
+    }
     return GDCA_OK;
 }
 
@@ -579,6 +758,33 @@ static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;
     return GDCA_OK;
+}
+
+// The inverses of the members of a batch, all enqueued on the batch's stream (every member's `stream` points there, pend_n /
+// pend_npad are set): those of the small members (up to `merge_blocks` 128-blocks: chain-bound single-block schedules that leave
+// most of the chip idle) are carried `merge` at a time by ONE launch (options GDCA_MERGE, GDCA_MERGE_BLOCKS of the leader; bit for
+// bit the results of launches of their own), the others run back to back
+static gdca_status run_inverses(gdca_ctx *lead, gdca_ctx *const *ctxs, int K)
+{
+    gdca_ctx *small[64];
+    int n_small = 0;
+    gdca_status st = GDCA_OK;
+    const int merge = std::min(lead->tune.merge, gdca_inverse_max_merge());
+    for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        if (merge > 1 && ctxs[k]->pend_npad / GDCA_TILE <= lead->tune.merge_blocks)
+            small[n_small++] = ctxs[k];
+        else
+            st = run_inverse(ctxs[k]);
+    }
+    // (groups of equal size rather than full ones and a remainder: 5 members at merge = 4 go 3 + 2)
+    const int n_grp = n_small ? (n_small + merge - 1) / merge : 0;
+    for (int gi = 0, at = 0; gi < n_grp && st == GDCA_OK; ++gi) {
+        const int cnt = n_small / n_grp + (gi < n_small % n_grp ? 1 : 0);
+        // (option SWEEP_DEBUG bit 3, tests: the merged kernel for a single member too)
+        st = (cnt == 1 && !(lead->tune.sweep_debug & 8)) ? run_inverse(small[at]) : run_inverse_merged(small + at, cnt);
+        at += cnt;
+    }
+    return st;
 }
 
 extern "C" {
@@ -603,8 +809,16 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
         for (int j = 0; j < k; ++j)
             if (ctxs[j] == ctxs[k]) return fail(lead, GDCA_EINVAL, "the same context twice in one batch%s%s", "", "");
         if (ctxs[k]->device != lead->device) return fail(lead, GDCA_EINVAL, "contexts of one batch must share a device%s%s", "", "");
-        CHK(not_pending(ctxs[k]));
-        CHK(run_check_args(ctxs[k], Z_dev[k], N[k], M[k], q[k], p, S_dev[k]));
+        gdca_status vs = not_pending(ctxs[k]);
+        if (vs == GDCA_OK) vs = run_check_args(ctxs[k], Z_dev[k], N[k], M[k], q[k], p, S_dev[k]);
+        if (vs != GDCA_OK) {
+            if (k > 0) {  // the caller reads the leader's last_error
+                char msg[sizeof(lead->err)];
+                snprintf(msg, sizeof(msg), "member %d: %.400s", k, ctxs[k]->err);
+                memcpy(lead->err, msg, sizeof(msg));
+            }
+            return vs;
+        }
     }
     // everything goes to the leader's stream, phase by phase: K front ends, K inverses back to back, K score stages.  The
     // members keep their own workspaces, scalars and timing events; their streams are restored before returning.
@@ -621,14 +835,22 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
         st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
         if (st == GDCA_OK) ++done_front;
     }
-    for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_inverse(ctxs[k]);
+    if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
     for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
     if (st != GDCA_OK) {
-        // a member failed to enqueue (allocation, launch): drain what was enqueued and leave nobody half-pending
+        // a member failed to enqueue (allocation, launch): drain what was enqueued -- the batch's stream AND every member's side
+        // stream, where its k_meff may still be writing the member's scalars -- and leave nobody half-pending.  The failing
+        // member's message goes to the leader, whose last_error the caller reads.
         (void)hipStreamSynchronize(lead->stream);
         for (int k = 0; k < K; ++k) {
+            if (ctxs[k]->side) (void)hipStreamSynchronize(ctxs[k]->side);
             ctxs[k]->pending = false;
             ctxs[k]->meff_pending = false;
+            if (k > 0 && ctxs[k]->err[0] && k == done_front) {
+                char msg[sizeof(lead->err)];
+                snprintf(msg, sizeof(msg), "member %d: %.400s", k, ctxs[k]->err);
+                memcpy(lead->err, msg, sizeof(msg));
+            }
         }
     }
     for (int k = 0; k < K; ++k) ctxs[k]->stream = own[k];
@@ -636,8 +858,11 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
     if (st == GDCA_OK)
         for (int k = 1; k < K; ++k) {
             if (hipEventRecord(ctxs[k]->ev_batch, lead->stream) != hipSuccess ||
-                hipStreamWaitEvent(own[k], ctxs[k]->ev_batch, 0) != hipSuccess)
+                hipStreamWaitEvent(own[k], ctxs[k]->ev_batch, 0) != hipSuccess) {
+                // the chain could not be built: the members' collects would not wait for the batch -- wait for it here instead
+                (void)hipStreamSynchronize(lead->stream);
                 return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
+            }
         }
     return st;
 }
@@ -853,6 +1078,63 @@ gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_
     if (ctx->sc_host->info != 0)
         return fail(ctx, GDCA_ENOTPD, "matrix is not positive definite; Cholesky factorization failed%s%s", "", "");
     return GDCA_OK;
+}
+
+gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double *const *A_dev, const int32_t *n, int32_t *info)
+{
+    if (!ctxs || K < 1 || K > 64 || !A_dev || !n) return GDCA_EINVAL;
+    gdca_ctx *lead = ctxs[0];
+    if (!lead) return GDCA_EINVAL;
+    gdca_ctx *ctx = lead;
+    for (int k = 0; k < K; ++k) {
+        if (!ctxs[k] || !A_dev[k] || n[k] < 1 || n[k] > GDCA_MAX_N) return fail(lead, GDCA_EINVAL, "invalid member of the batch%s%s", "", "");
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(lead, GDCA_EINVAL, "the same context twice in one batch%s%s", "", "");
+        if (ctxs[k]->device != lead->device) return fail(lead, GDCA_EINVAL, "contexts of one batch must share a device%s%s", "", "");
+        CHK(not_pending(ctxs[k]));
+        if (info) info[k] = 0;
+    }
+    HIPCHK(hipSetDevice(lead->device));
+    hipStream_t own[64];
+    for (int k = 0; k < K; ++k) {
+        own[k] = ctxs[k]->stream;
+        if (k > 0) (void)hipStreamSynchronize(own[k]);
+        ctxs[k]->stream = lead->stream;
+    }
+    gdca_status st = GDCA_OK;
+    for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        gdca_ctx *m = ctxs[k];
+        const int n_pad = round_up(n[k], GDCA_TILE);
+        st = begin(m);
+        if (st == GDCA_OK) st = ensure(m, m->A, (size_t)n_pad * n_pad * sizeof(double));
+        if (st != GDCA_OK) break;
+        gdca_launch_copy_in(lead->stream, A_dev[k], n[k], (double *)m->A.p, n_pad);
+        m->pend_n = n[k];
+        m->pend_npad = n_pad;
+        m->pend_timed = false;
+    }
+    if (st == GDCA_OK) st = run_inverses(lead, ctxs, K);
+    for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        gdca_launch_copy_out_neg_sym(lead->stream, (const double *)ctxs[k]->A.p, ctxs[k]->pend_npad, A_dev[k], n[k]);
+        st = check_launch(lead, "copy_out");
+    }
+    (void)hipStreamSynchronize(lead->stream);
+    for (int k = 0; k < K; ++k) ctxs[k]->stream = own[k];
+    if (st != GDCA_OK) return st;
+    gdca_status worst = GDCA_OK;
+    for (int k = 0; k < K; ++k) {
+        gdca_ctx *m = ctxs[k];
+        st = fetch_scalars(m);
+        if (st != GDCA_OK) return st;
+        const int inf = m->sc_host->info;
+        if (inf == INT32_MIN)
+            worst = fail(lead, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
+        else if (inf != 0) {
+            if (info) info[k] = inf;
+            if (worst == GDCA_OK) worst = fail(lead, GDCA_ENOTPD, "matrix is not positive definite; Cholesky factorization failed%s%s", "", "");
+        }
+    }
+    return worst;
 }
 
 // mJ (device, n x n full, ld n) -> ctx->A as "-mJ" with ld = n_pad (the score kernels read its lower triangle)

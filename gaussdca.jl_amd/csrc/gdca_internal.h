@@ -24,6 +24,32 @@ struct gdca_dev_scalars {
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
 };
 
+// Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
+// created, never read from the environment afterwards -- two contexts of one process may differ, and a switch changed through
+// gdca_ctx_set_option takes effect at the next call on that context.  -1 = "the measured rule" where a rule exists.
+struct gdca_tuning {
+    int group;              // GDCA_GROUP: pivot blocks per group of the sweep, 1..4
+    int ramp;               // GDCA_RAMP: 0 = uniform groups, the remainder last
+    int ragged;             // GDCA_RAGGED: 0 = sweep the matrix padded to 128 instead of 16
+    int rem_tail;           // GDCA_REM_TAIL: remainder tiles of update p listed after panel(p+1)
+    int panel_halves;       // GDCA_PANEL_HALVES: 1 = two 128 x 64 panel items per pivot block and row, 0 = one 128 x 128
+    int slab;               // GDCA_SLAB: 0 = panel and tile items between single blocks instead of the fused row slabs
+    int ring;               // GDCA_RING: panel / Pg slots between single blocks (2..8)
+    int mcus;               // GDCA_MCUS: compute units elected for the pivot chain (1..16)
+    int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected
+    long sweep_timeout_ms;  // GDCA_SWEEP_TIMEOUT_MS: bound of one dependency wait; 0 = scaled with the problem (>= 4 s)
+    int tally_tj;           // GDCA_TALLY_TJ: 32 = the wide pair-tally form
+    int hamming_mode;       // GDCA_HAMMING_MODE: -1 = probe, 0 = full (exact five-plane distances), 1 = bound (three planes + refinement)
+    int force_fallback;     // GDCA_FORCE_FALLBACK: 1 = the independent byte-compare Hamming kernel
+    int merge;              // GDCA_MERGE: families one merged sweep launch may carry in gdca_run_dev_phased (1 = never merge)
+    int merge_blocks;       // GDCA_MERGE_BLOCKS: largest member of a merged launch, in 128-blocks
+    int merge_mcus;         // GDCA_MERGE_MCUS: chain compute units per member of a merged launch
+    char sweep_trace[256];  // GDCA_SWEEP_TRACE: file the in-kernel trace of the next inverse is written to ("" = off)
+};
+void gdca_tuning_from_env(gdca_tuning *t);
+// key: the variable's name with or without the GDCA_ prefix, any case.  false: unknown key or unusable value.
+bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value);
+
 // ---- k_theta.hip -------------------------------------------------------------------------
 void gdca_launch_transpose_i8(hipStream_t s, const int8_t *Z, int8_t *Zt, int N, int M);
 // cnt: uint32 [N][32], zeroed by the caller
@@ -41,7 +67,8 @@ size_t gdca_bitplane_bytes(int N, int M);
 void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M, int q,
                                gdca_dev_scalars *sc);
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc);
+// force: -1 = decide per family from a sample of tiles, 0 = the exact form, 1 = the lower bound with refinement
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force);
 // the same counts by an independent plain byte-compare kernel straight from Z (GDCA_FORCE_FALLBACK; overwrites cnt[0..M-1])
 void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc);
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)
@@ -64,11 +91,11 @@ void gdca_launch_pi_finalize(hipStream_t s, const unsigned long long *Pifix, int
 // Pair tallies.  mode 0: out = Pij_true (full symmetric, ld);  mode 1: out = C =
 // add_pseudocount + compute_C fused (full symmetric, ld).  Pi_pc used by mode 1 only.
 // Zc: the alignment regrouped as [ceil(N/TJ)][M][TJ] (gdca_launch_colblock), TJ = gdca_tally_tj(q).
-int gdca_tally_tj(int q);
+int gdca_tally_tj(int q, int tj_wanted);
 void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ);
 void gdca_launch_pair_tally(hipStream_t s, const int8_t *Zc, const int8_t *Zt, const unsigned long long *Wfix,
                             int N, int M, int q, int fix_shift, const double *Meff_dev, double pc,
-                            const double *Pi_pc, int mode, double *out, size_t ld);
+                            const double *Pi_pc, int mode, double *out, size_t ld, int TJ);
 
 // ---- k_elementwise.hip ---------------------------------------------------------------------
 void gdca_launch_add_pseudocount(hipStream_t s, const double *Pi_true, const double *Pij_true, int N, int q,
@@ -98,12 +125,25 @@ struct gdca_inverse_ws {
     int *item0_dev;
     int update_cus;    // compute units of the device
 };
-// In place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles authoritative): A <- -inverse(A) by
-// the block symmetric sweep, ONE persistent launch on stream s.  sc->info gets the 1-based index of the first
-// non-positive pivot, if any.  upd_ev (optional, 2 events) are recorded around the launch.
+// One inverse: in place on A (n_pad x n_pad, ld = n_pad, lower triangle + full diagonal tiles authoritative): A <- -inverse(A) by
+// the block symmetric sweep.  sc->info gets the 1-based index of the first non-positive pivot, if any (INT_MIN: the kernel's
+// watchdog abandoned a dependency wait).
+struct gdca_inverse_job {
+    double *A;
+    int n_pad, n_real;
+    gdca_inverse_ws ws;
+    gdca_dev_scalars *sc;
+    const gdca_tuning *tune;
+};
 size_t gdca_inverse_flag_bytes(int n_pad);
-void gdca_launch_spd_inverse(hipStream_t s, double *A, int n_pad, const gdca_inverse_ws &ws, gdca_dev_scalars *sc, int n_real,
-                             hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch, double *upd_flops);
+// ONE persistent launch on stream s; upd_ev (optional, 2 events) are recorded around the launch.
+void gdca_launch_spd_inverse(hipStream_t s, const gdca_inverse_job &job, hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch,
+                             double *upd_flops);
+// K <= gdca_inverse_max_merge() independent inverses (single-block schedules: small matrices) carried by ONE persistent launch;
+// every member's arithmetic is that of a launch of its own.  upd_flops: K entries.
+int gdca_inverse_max_merge(void);
+void gdca_launch_spd_inverse_merged(hipStream_t s, const gdca_inverse_job *jobs, int K, hipEvent_t *upd_ev, int max_upd_ev,
+                                    double *upd_flops);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
 
 // ---- k_score.hip ---------------------------------------------------------------------------

@@ -318,13 +318,12 @@ __global__ void k_hamming_decide(gdca_dev_scalars *sc, long long sampled_pairs, 
         sc->ham_mode = force >= 0 ? force : ((double)sc->ham_cand < 1e-3 * (double)sampled_pairs ? 1 : 0);
 }
 
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc)
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
     const long long ntile = (long long)Mt * (Mt + 1) / 2;
-    // GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a sample of tiles
-    const char *env = getenv("GDCA_HAMMING_MODE");
-    const int force = !env ? -1 : (env[0] == 'f' ? 0 : (env[0] == 'b' ? 1 : -1));
+    // the context option GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a
+    // sample of tiles
     const int nprobe = (int)std::min<long long>(ntile, 192);
     if (force < 0 && ntile >= 64) {
         hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
@@ -332,8 +331,14 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N,
     } else {
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, 1ll, force < 0 ? 0 : force);  // tiny families: the exact form
     }
-    hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
-    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+    // both forms are launched only where the device decides between them (the one not chosen exits on sc->ham_mode: Mt (Mt + 1) / 2
+    // empty workgroups); a forced form, and a family too small to sample, launch the one they run
+    const bool decided = !(force < 0 && ntile >= 64);
+    const int form = decided ? (force < 0 ? 0 : force) : -1;
+    if (form != 0)
+        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+    if (form != 1)
+        hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
 }
 
 // ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------

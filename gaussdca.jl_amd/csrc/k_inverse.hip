@@ -1674,24 +1674,37 @@ __device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I,
     return acquire_end(ok);
 }
 
+// The workgroup's NEXT take (thread 0's values; nullptr s_next: none, an M-list caller): item number `nxt`, in flight as an atomic
+// since the start of this item, and where it goes.  A merged launch (k_sweep_merged) takes the next item from another family: Dn =
+// that family's descriptor, pn = the group its last item there belonged to, fn = its index (-> *s_fam).
+struct NextTake {
+    int nxt;
+    int *s_next, *s_ready;
+    const SweepDesc *Dn;
+    int pn, fn;
+    int *s_fam;
+};
+
 // after the tile's (write-through) stores have been issued: look the next item up while they drain, then publish
-__device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int I, int J, int nxt, int *s_next, int *s_ready)
+__device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int I, int J, const NextTake &nt)
 {
     const int tid = opaque_tid();
-    if (s_next && tid == 0) {
-        *s_next = nxt;
+    if (nt.s_next && tid == 0) {
+        *nt.s_next = nt.nxt;
+        if (nt.s_fam) *nt.s_fam = nt.fn;
+        const SweepDesc &Dn = nt.Dn ? *nt.Dn : D;
         int r = 0;
-        if (nxt < D.total) {
-            int ph = p;
-            const MainItem ni = main_decode(D, ph, nxt);
+        if (nt.nxt < Dn.total) {
+            int ph = nt.Dn ? nt.pn : p;
+            const MainItem ni = main_decode(Dn, ph, nt.nxt);
             if (ni.kind == 1 || ni.kind == 4) {
-                const int nsz2 = g_size(D, ni.p);
-                const unsigned f1 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.a), f2 = flag_load(D.rb + (size_t)ni.p * D.nblk + ni.b),
-                               f3 = flag_load(D.gen + (size_t)ni.a * D.nblk + ni.b);
+                const int nsz2 = g_size(Dn, ni.p);
+                const unsigned f1 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + ni.a), f2 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + ni.b),
+                               f3 = flag_load(Dn.gen + (size_t)ni.a * Dn.nblk + ni.b);
                 r = (f1 >= 2u * (unsigned)nsz2) & (f2 >= 2u * (unsigned)nsz2) & (f3 >= (unsigned)ni.p);
             }
         }
-        *s_ready = r;
+        *nt.s_ready = r;
     }
     publish_wt_begin();
     if (tid == 0) {
@@ -1702,8 +1715,7 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
 
 template <bool MULTI>
 __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
-                                                double (*Hs)[KC][LDS_LD], int ready = 0, int nxt = 0, int *s_next = nullptr,
-                                                int *s_ready = nullptr, bool inplace = false)
+                                                double (*Hs)[KC][LDS_LD], int ready = 0, const NextTake &nt = NextTake{}, bool inplace = false)
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
@@ -1774,7 +1786,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
                 const int c = wc * 64 + tm * 16 + lq + 4 * reg;
                 store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
             }
-    tile_item_finish(D, p, I, J, nxt, s_next, s_ready);
+    tile_item_finish(D, p, I, J, nt);
 }
 
 // ---- a tile of the LAST block row when the matrix ends inside that block (n = 10 000: 78 blocks of 128 and 16 rows) ------------
@@ -1783,7 +1795,7 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
 // plain loop (one LDS buffer, two barriers per chunk): these items are 1 / nblk of the tile items and bound by their operand
 // traffic, not by the matrix pipe.
 __device__ __forceinline__ void sweep_tile_item_ragged(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
-                                                       double (*Hs)[KC][LDS_LD], int ready, int nxt, int *s_next, int *s_ready)
+                                                       double (*Hs)[KC][LDS_LD], int ready, const NextTake &nt)
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
@@ -1833,7 +1845,7 @@ __device__ __forceinline__ void sweep_tile_item_ragged(const SweepDesc &D, int p
                     store_wt(q, *q + acc[tm][tn][reg]);
                 }
         }
-    tile_item_finish(D, p, I, J, nxt, s_next, s_ready);
+    tile_item_finish(D, p, I, J, nt);
 }
 
 // ---- wb(p): one tile of the group's new columns ----------------------------------------------------------------------------
@@ -1867,21 +1879,13 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
+__device__ __forceinline__ void sweep_one_family(const SweepDesc &D)
 {
     // ONE array: the pivot's images (pivot_chain) span both staging buffers off one base
     __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
     double(*const Gs)[KC][LDS_LD] = GHs;
     double(*const Hs)[KC][LDS_LD] = GHs + 2;
     __shared__ int s_item;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the descriptor is read where it lies, in the kernel-argument segment
-    typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
-    const SweepDesc &D = *(const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)Darg;
-#else
-    const SweepDesc &D = Darg;
-#endif
     // ---- the M list runs on compute units of its own ----
     // The serial chain of a group (128 dependent steps per pivot block, each a handful of VALU / DPP / MFMA instructions) is
     // several times slower when its waves share their SIMDs with the MFMA stream of a tile item, and then IT sets the pace
@@ -2001,12 +2005,13 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             }
         }
         if (it.kind == 1 || it.kind == 4) {
+            const NextTake nt{nxt, &s_next, &s_ready, nullptr, 0, 0, nullptr};
             if (D.rl < T && it.a == D.nblk - 1)
-                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
             else if (MULTI && g_size(D, it.p) > 1)
-                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready);
+                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
             else
-                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nxt, &s_next, &s_ready,
+                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt,
                                        D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
             if (D.dbg && threadIdx.x == 0) {
                 atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
@@ -2049,6 +2054,215 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work
 }
 
+template <bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the descriptor is read where it lies, in the kernel-argument segment
+    typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
+    const SweepDesc &D = *(const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Darg;
+#else
+    const SweepDesc &D = Darg;
+#endif
+    sweep_one_family<MULTI>(D);
+}
+
+// =====================================================================================================================
+// K independent inverses in ONE persistent launch (gdca_run_dev_phased: families batched by phase)
+// =====================================================================================================================
+// A matrix of a few dozen blocks cannot fill the chip: between single blocks a step of the sweep is a serial chain of ~45-60 us
+// (pivot, the next row's slabs, flag hops) with at most nblk^2 / 2 tile items of ~30 us beside it -- 200 at 20 blocks for 512
+// workgroup slots -- and a second k_sweep launch cannot move in beside the first, which holds two 74-KB workgroups on every
+// compute unit.  So the launch itself carries K families: one descriptor, item table and flag block per family (exactly what a
+// launch of its own would get, so the arithmetic of a family -- every tile's update order is fixed by ITS flags -- is bit for bit
+// that of a single run), and
+//   * every family's chain gets compute units of its own: a workgroup on XCC x offers itself to family (x + t) % K, t = 0, 1, ..:
+//     the first workgroup to reach a family decides its XCD, so with K <= 8 the chains sit on different XCDs (each hands its
+//     data on through one L2) whenever the workgroups of a launch are spread over them;
+//   * everybody else takes main-list items of the families in turn (its j-th take goes to the next family that still has
+//     items): the families advance side by side, and a workgroup parked on an item of family A that waits for A's chain keeps
+//     nothing of family B from running.
+// Items of one family are still handed out in that family's list order, so the no-deadlock argument of k_sweep holds family by
+// family.  Members are single-block schedules (MULTI = false): the chain-bound sizes, which are the ones that leave the chip idle.
+#define SWEEP_MAX_MERGE 8
+struct SweepBatch {
+    SweepDesc fam[SWEEP_MAX_MERGE];
+    int K;
+};
+
+__global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
+    double(*const Gs)[KC][LDS_LD] = GHs;
+    double(*const Hs)[KC][LDS_LD] = GHs + 2;
+    __shared__ int s_item, s_fam, s_next, s_ready, s_live;
+    __shared__ int s_p[SWEEP_MAX_MERGE];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const SweepBatch __attribute__((address_space(4))) *kernarg_batch_t;
+    const SweepBatch &B = *(const SweepBatch *)(kernarg_batch_t)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)Barg;
+#else
+    const SweepBatch &B = Barg;
+#endif
+    const int K = B.K;
+    if (threadIdx.x == 0) {
+        *abort_lds() = 0;
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        xcc &= 15u;
+        int worker = 0, wf = 0;
+        const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
+        for (int t = 0; t < K && !worker; ++t) {
+            const int f = (int)((xcc + (unsigned)t) % (unsigned)K);
+            const SweepDesc &Df = B.fam[f];
+            const bool candidate = !(Df.debug & 2) && !((Df.debug & 1) && xcc == 0u) && !((Df.debug & 4) && xcc != 0u);
+            if (!candidate) continue;
+            const unsigned old = atomicCAS(Df.mxcc, 0u, xcc + 1u);
+            if (old == 0u || old == xcc + 1u) {
+                for (int k = 0; k < Df.n_mcu && !worker; ++k) {
+                    const unsigned o2 = atomicCAS(Df.mcu + k, 0u, key);
+                    if (o2 == 0u || o2 == key) worker = 1;
+                }
+                if (worker) wf = f;
+            }
+        }
+        s_item = worker;
+        s_fam = wf;
+        for (int f = 0; f < SWEEP_MAX_MERGE; ++f) s_p[f] = 0;
+    }
+    __syncthreads();
+    const bool m_worker = s_item != 0;
+    const int wfam = __builtin_amdgcn_readfirstlane(s_fam);
+    const bool clock_probe = threadIdx.x == 0;
+    const unsigned long long probe_c0 = clock_probe ? (unsigned long long)clock64() : 0ull;
+    const unsigned long long probe_w0 = clock_probe ? wall_clock64() : 0ull;
+    __syncthreads();
+    if (m_worker) {
+        const SweepDesc &D = B.fam[wfam];
+        int q = 0;
+        for (;;) {
+            if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(D.next_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int item = s_item;
+            __syncthreads();
+            if (item >= D.total_m || *abort_lds()) break;
+            while (item >= D.mitem0[q + 1]) ++q;
+            int e = item - D.mitem0[q];
+            const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
+            const int nm = m_items(sz);
+            if (e < nm) {
+                sweep_m_item(D, q, e, Gs, Hs);
+                continue;
+            }
+            e -= nm;
+            if (D.slab) {
+                if (e < SLAB_ITEMS)
+                    sweep_slab_item(D, q, e, 1, &Gs[0][0][0]);
+                else if (e < 2 * SLAB_ITEMS)
+                    sweep_xslab_item(D, q, e - SLAB_ITEMS);
+                else
+                    sweep_slab_item(D, q, e - 2 * SLAB_ITEMS, 2, &Gs[0][0][0]);
+                continue;
+            }
+            int rr = 0;
+            while (e >= 2 * sz + rr + 1) {
+                e -= 2 * sz + rr + 1;
+                ++rr;
+            }
+            if (e < 2 * sz) {
+                sweep_panel_item<2>(D, q, c0 + rr, e, Gs, Hs);
+                continue;
+            }
+            e -= 2 * sz;
+            sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
+        }
+    }
+    // ---- the main lists, the families in turn ----
+    // Which family the next take goes to is thread 0's business (s_live: the families whose list this workgroup has not yet seen
+    // exhausted); the workgroup learns the family of the current item from s_fam, next to its number in s_next.  As in k_sweep the
+    // next item is requested while the current one is worked on, its number reaches LDS inside the item (tile_item_finish: with
+    // the look-ahead at that item's flags), and per family the items of a workgroup ascend (s_p: the group its last item there
+    // belonged to).
+    if (threadIdx.x == 0) {
+        s_live = (int)((1u << K) - 1u);
+        const int f0 = (int)(blockIdx.x % (unsigned)K);
+        s_fam = f0;
+        s_next = (int)__hip_atomic_fetch_add(B.fam[f0].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ready = 0;
+    }
+    for (;;) {
+        __syncthreads();
+        const int item = s_next, rdy = s_ready;
+        const int f = __builtin_amdgcn_readfirstlane(s_fam);
+        __syncthreads();  // everybody has read them
+        if (f < 0 || *abort_lds()) break;
+        const SweepDesc &D = B.fam[f];
+        if (item >= D.total) {
+            // this family's list is exhausted: strike it and take from the next one that is not (none left: f = -1 ends the loop)
+            if (threadIdx.x == 0) {
+                const unsigned live = (unsigned)s_live & ~(1u << f);
+                s_live = (int)live;
+                int fn = -1;
+                if (live) {
+                    fn = f;
+                    do fn = fn + 1 == K ? 0 : fn + 1; while (!((live >> fn) & 1u));
+                    s_next = (int)__hip_atomic_fetch_add(B.fam[fn].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_fam = fn;
+                s_ready = 0;
+            }
+            continue;
+        }
+        int nxt = 0, fn = 0, pn = 0;
+        if (threadIdx.x == 0) {
+            const unsigned live = (unsigned)s_live;
+            fn = f;
+            do fn = fn + 1 == K ? 0 : fn + 1; while (!((live >> fn) & 1u));
+            nxt = (int)__hip_atomic_fetch_add(B.fam[fn].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pn = s_p[fn];
+        }
+        int p = s_p[f];
+        const MainItem it = main_decode(D, p, item);
+        if (threadIdx.x == 0) {
+            s_p[f] = p;  // (the others read it again only after the barriers at the top of the loop, or see this very value)
+            if (fn == f) pn = p;
+        }
+        if (it.kind == 1 || it.kind == 4) {
+            const NextTake nt{nxt, &s_next, &s_ready, &B.fam[fn], pn, fn, &s_fam};
+            if (D.rl < T && it.a == D.nblk - 1)
+                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
+            else
+                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt,
+                                       D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
+            continue;
+        }
+        if (it.kind == 0)
+            sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
+        else if (it.kind == 2)
+            sweep_wb_item(D, it.p, it.a, Gs);
+        if (threadIdx.x == 0) {
+            s_next = nxt;
+            s_fam = fn;
+            s_ready = 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long cyc = (unsigned long long)clock64() - probe_c0, tk = wall_clock64() - probe_w0;
+        const bool aborted = *abort_lds() != 0;
+        for (int k = 0; k < K; ++k) {
+            atomicAdd(&B.fam[k].sc->sweep_cycles, cyc);
+            atomicAdd(&B.fam[k].sc->sweep_ticks, tk);
+            // a wait of ANY member ran out of time: this workgroup has dropped its items, so no member's result can be trusted
+            if (aborted) {
+                __hip_atomic_store(B.fam[k].abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&B.fam[k].sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 size_t gdca_inverse_flag_bytes(int n_pad)
 {
     const size_t nblk = (size_t)(n_pad / T);
@@ -2057,10 +2271,28 @@ size_t gdca_inverse_flag_bytes(int n_pad)
     return (nblk * nblk + nblk * nblk + 5 * nblk + 96) * sizeof(unsigned);
 }
 
-// Host side: the item table, the flags, one launch.
-void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_inverse_ws &ws, gdca_dev_scalars *sc, int n_real,
-                             hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch, double *upd_flops)
+int gdca_inverse_max_merge(void)
 {
+    return SWEEP_MAX_MERGE;
+}
+
+// Host side: the schedule of one inverse -- group sizes, the item table (written to the job's pinned staging buffer and sent to
+// the device on s0), the flags (zeroed on s0), the descriptor.  `merged`: the inverse is a member of a merged launch of
+// `members` families (single-block groups, chain CUs from the merge rule, no trace).
+struct SweepPlan {
+    SweepDesc D;
+    int g;
+    long long mpos;
+    double chunks;     // 128 x 128 x 16 MFMA chunk products issued (tile, panel and super-block items)
+    bool slab;
+    std::vector<int> mit;
+};
+
+static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool merged, int members)
+{
+    const gdca_tuning &tu = *job.tune;
+    const gdca_inverse_ws &ws = job.ws;
+    const int n_pad = job.n_pad, n_real = job.n_real;
     const int nblk = n_pad / T;
     // pivot blocks per group: more blocks per pass raise the update's arithmetic intensity (K = 128 g) and amortise the per-item
     // costs; the serial chain of a group grows with g (and has the group's whole update to hide behind).  Small matrices
@@ -2069,8 +2301,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // N x g x chain CUs): g = 1 is fastest up to 48 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
     // by the chain), 2 to 54, 3 to 57, 4 from 58 on (with the super-block inverse as row-slab jobs; as half-tile jobs its chain hid only
     // from 71 blocks).
-    static const int group_env = getenv("GDCA_GROUP") ? atoi(getenv("GDCA_GROUP")) : -1;
-    int g = group_env >= 1 ? std::min(group_env, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1)));
+    int g = merged ? 1 : (tu.group >= 1 ? std::min(tu.group, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1))));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
@@ -2078,11 +2309,10 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     // update before it), and the remainder of nblk / g joins the ramp instead of ending the sweep as a lone short group
     // (measured at n = 10 000: 17.9-18.1 ms against 18.2-18.3 with the remainder last and 18.2 without the ramp).
     // GDCA_RAMP=0: uniform groups, the remainder last.
-    static const int ramp_env = getenv("GDCA_RAMP") ? atoi(getenv("GDCA_RAMP")) : 1;
     std::vector<int> sizes;
     {
         const int ramp_sum = g * (g - 1) / 2;
-        if (ramp_env && g > 1 && nblk >= ramp_sum + 2 * g) {
+        if (tu.ramp && g > 1 && nblk >= ramp_sum + 2 * g) {
             for (int k = 1; k < g; ++k) sizes.push_back(k);
             const int rest = nblk - ramp_sum, rem = rest % g;
             if (rem) sizes.insert(std::upper_bound(sizes.begin(), sizes.end(), rem), rem);
@@ -2103,28 +2333,23 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     long long pos = 0, mpos = 0;
     // real rows of the last block, in 16-row MFMA blocks: the sweep treats the matrix as n rounded up to 16, not to 128 -- the
     // tile items of the last block row and the k loop over the last pivot block skip the rest of the padding (GDCA_RAGGED=0: off)
-    static const int ragged_env = getenv("GDCA_RAGGED") ? atoi(getenv("GDCA_RAGGED")) : 1;
-    const int rl = ragged_env ? std::min(T, ((n_real - (nblk - 1) * T + 15) / 16) * 16) : T;
-    double chunks = 0.0;  // 128 x 128 x 16 MFMA chunk products issued (tile, panel and super-block items)
+    const int rl = tu.ragged ? std::min(T, ((n_real - (nblk - 1) * T + 15) / 16) * 16) : T;
+    double chunks = 0.0;
     // remainder tiles of update p listed after panel(p+1): about one round of the workgroups, so that the panels are complete
     // when the first tile items of update p+1 are handed out and the chain has had most of update p to produce Pg(p+1).
     // Only where the update hides the chain (groups of three and four): on a chain-bound matrix Pg(p+1) is late anyway and
     // workgroups parked on panel items are missing from update p (measured: config E 59.5 instead of 63.4 families/s).
-    static const int tail_env = getenv("GDCA_REM_TAIL") ? atoi(getenv("GDCA_REM_TAIL")) : -1;
-    const int rem_tail = tail_env >= 0 ? tail_env : (g >= 3 ? 2 * ws.update_cus : 0);
+    const int rem_tail = tu.rem_tail >= 0 ? tu.rem_tail : (g >= 3 ? 2 * ws.update_cus : 0);
     // main-list panel items: one 128 x 128 item per pivot block and row where the panels are throughput (multi-block groups of
     // three and four), two 128 x 64 halves where their latency counts
-    static const int ppb_env = getenv("GDCA_PANEL_HALVES") ? atoi(getenv("GDCA_PANEL_HALVES")) : -1;
-    const int ppb = ppb_env >= 0 ? (ppb_env ? 2 : 1) : (g >= 3 ? 1 : 2);
+    const int ppb = merged ? 2 : (tu.panel_halves >= 0 ? (tu.panel_halves ? 2 : 1) : (g >= 3 ? 1 : 2));
     // single-block groups: the chain between two pivots as fused row-slab items (sweep_slab_item; GDCA_SLAB=0: panel and tile items)
-    static const int slab_env = getenv("GDCA_SLAB") ? atoi(getenv("GDCA_SLAB")) : 1;
-    bool slab = slab_env != 0;
+    bool slab = tu.slab != 0;
     bool single = true;
     for (int p = 0; p < ng; ++p) single = single && size(p) == 1;
     slab = slab && single;
     // buffers per kind (ring_panel): eight one-panel slots between single blocks (GDCA_RING=2: two, as for multi-block groups)
-    static const int ring_env = getenv("GDCA_RING") ? atoi(getenv("GDCA_RING")) : 8;
-    const int ring = single && ring_env >= 3 ? std::min(ring_env, 8) : 2;
+    const int ring = single && tu.ring >= 3 ? std::min(tu.ring, 8) : 2;
     const int pro = ng > 0 ? (nblk - size(0) - (ng > 1 ? size(1) : 0)) * ppb * size(0) : 0;  // panel(0)
     for (int p = 0; p < ng; ++p) {
         it[p] = (int)pos;
@@ -2151,8 +2376,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)3 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
     (void)hipMemsetAsync(ws.flags, 0, ws.flags_bytes, s0);
 
-    SweepDesc D{};
-    D.A = A;
+    SweepPlan P{};
+    SweepDesc &D = P.D;
+    D.A = job.A;
     D.ld = (size_t)n_pad;
     D.nblk = nblk;
     D.g = g;
@@ -2181,12 +2407,14 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.mcu = f + 2;
     D.mxcc = f + 18;
     D.abort = f + 64;
-    // bound of one dependency wait (GDCA_SWEEP_TIMEOUT_MS, default 4 s; a healthy wait is microseconds, a whole inverse at
-    // n = 48 000 takes 1.8 s)
-    static const long timeout_env = getenv("GDCA_SWEEP_TIMEOUT_MS") ? atol(getenv("GDCA_SWEEP_TIMEOUT_MS")) : 4000;
-    D.timeout_ticks = (unsigned long long)std::max(1L, timeout_env) * 100000ull;
-    static const int debug_env = getenv("GDCA_SWEEP_DEBUG") ? atoi(getenv("GDCA_SWEEP_DEBUG")) : 0;
-    D.debug = debug_env;
+    // bound of one dependency wait (GDCA_SWEEP_TIMEOUT_MS; a healthy wait is microseconds).  By default it grows with the work the
+    // launch holds: the early workgroups of a launch that starts behind another one (two contexts in flight on one GPU, another
+    // tenant) wait for most of that launch's run time, and a slow but correct run must not be turned into GDCA_EHIP -- 4 s or
+    // eight times the modelled duration of everything this launch carries (n = 48 000: 1.8 s measured), whichever is longer
+    const double model_ms = 8.0 * members * ((double)n_pad * n_pad * n_pad / 50e12 * 1e3);
+    const long timeout_ms = tu.sweep_timeout_ms > 0 ? tu.sweep_timeout_ms : std::max(4000L, (long)model_ms);
+    D.timeout_ticks = (unsigned long long)std::max(1L, timeout_ms) * 100000ull;
+    D.debug = tu.sweep_debug;
     D.item0 = ws.item0_dev;
     D.mitem0 = ws.item0_dev + (ng + 1);
     D.gs = ws.item0_dev + 2 * (ng + 1);
@@ -2197,19 +2425,39 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     D.ppb = ppb;
     D.slab = slab ? SLAB_ITEMS : 0;
     D.ring = ring;
-    static const int mcu_env = getenv("GDCA_MCUS") ? atoi(getenv("GDCA_MCUS")) : -1;
     // compute units for the M list (same measurement): a chain-bound inverse wants every parallel item of the chain served at
     // once -- the row-slab jobs of a level of a four-block group are 24 -- and once the update hides the chain the workers go
     // back to the tiles: for multi-block groups 16 CUs up to 63 blocks, 12 up to 68, 10 up to 74, 6 up to 90 (n = 10 000: 16.5 ms
     // with 6, 16.85 with 12, 20.8 with 4), 4 up to 120, 2 beyond (n = 20 000: 123.1 ms with 2, 123.75 with 4); between single blocks (a pivot and three times eight slab items per step) 12
     // CUs below 28 blocks, 8 above
     const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 63 ? 16 : (nblk <= 68 ? 12 : (nblk <= 74 ? 10 : (nblk <= 90 ? 6 : (nblk <= 120 ? 4 : 2)))));
-    D.n_mcu = mcu_env >= 1 ? std::min(mcu_env, 16) : mcu_rule;
+    // a member of a merged launch: its own rule unless that would hand more than a quarter of the chip to the chains
+    const int mcu_merged = tu.merge_mcus >= 1 ? tu.merge_mcus : std::min(mcu_rule, std::max(2, ws.update_cus / (4 * std::max(1, members))));
+    D.n_mcu = merged ? std::min(mcu_merged, 16) : (tu.mcus >= 1 ? std::min(tu.mcus, 16) : mcu_rule);
     D.n_real = n_real;
     D.rl = rl;
-    D.sc = sc;
+    D.sc = job.sc;
+    D.dbg = nullptr;
+    D.dbg_main = nullptr;
+    P.g = g;
+    P.mpos = mpos;
+    P.chunks = chunks;
+    P.slab = slab;
+    P.mit.assign(mit, mit + ng + 1);
+    return P;
+}
+
+static void write_sweep_trace(const char *trace_path, const SweepPlan &P, unsigned grid, unsigned long long *dbg);
+
+void gdca_launch_spd_inverse(hipStream_t s0, const gdca_inverse_job &job, hipEvent_t *upd_ev, int max_upd_ev, int *n_upd_launch,
+                             double *upd_flops)
+{
+    SweepPlan P = plan_sweep(s0, job, false, 1);
+    SweepDesc &D = P.D;
+    const int ng = D.ng;
+    const long long mpos = P.mpos;
     // GDCA_SWEEP_TRACE=file: stamps of the M-list items of this inverse are written to `file` (debug aid; synchronises)
-    static const char *trace_path = getenv("GDCA_SWEEP_TRACE");
+    const char *trace_path = job.tune->sweep_trace[0] ? job.tune->sweep_trace : nullptr;
     unsigned long long *dbg = nullptr;
     if (trace_path) {
         (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) * sizeof(unsigned long long));
@@ -2217,20 +2465,53 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
     }
     D.dbg = dbg;
     D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
-    const unsigned grid = (unsigned)(2 * ws.update_cus);  // two 256-VGPR workgroups per CU: every register file full
+    const unsigned grid = (unsigned)(2 * job.ws.update_cus);  // two 256-VGPR workgroups per CU: every register file full
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
-    if (g > 1)
+    if (P.g > 1)
         hipLaunchKernelGGL((k_sweep<true>), dim3(grid), dim3(256), 0, s0, D);
     else
         hipLaunchKernelGGL((k_sweep<false>), dim3(grid), dim3(256), 0, s0, D);
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
     if (dbg) {
         (void)hipStreamSynchronize(s0);
+        write_sweep_trace(trace_path, P, grid, dbg);
+        (void)hipFree(dbg);
+    }
+    if (n_upd_launch) *n_upd_launch = 1;
+    if (upd_flops) *upd_flops = 2.0 * T * T * KC * P.chunks;
+}
+
+// K <= SWEEP_MAX_MERGE inverses as one launch of k_sweep_merged; upd_flops[k] receives member k's issued MFMA flops
+void gdca_launch_spd_inverse_merged(hipStream_t s0, const gdca_inverse_job *jobs, int K, hipEvent_t *upd_ev, int max_upd_ev,
+                                    double *upd_flops)
+{
+    SweepBatch B{};
+    B.K = K;
+    int cus = 0;
+    for (int k = 0; k < K; ++k) {
+        SweepPlan P = plan_sweep(s0, jobs[k], true, K);
+        B.fam[k] = P.D;
+        if (upd_flops) upd_flops[k] = 2.0 * T * T * KC * P.chunks;
+        cus = std::max(cus, jobs[k].ws.update_cus);
+    }
+    const unsigned grid = (unsigned)(2 * cus);
+    const bool tm = upd_ev && max_upd_ev >= 2;
+    if (tm) (void)hipEventRecord(upd_ev[0], s0);
+    hipLaunchKernelGGL(k_sweep_merged, dim3(grid), dim3(256), 0, s0, B);
+    if (tm) (void)hipEventRecord(upd_ev[1], s0);
+}
+
+static void write_sweep_trace(const char *trace_path, const SweepPlan &P, unsigned grid, unsigned long long *dbg)
+{
+    const int nblk = P.D.nblk, g = P.g, ng = P.D.ng;
+    const long long mpos = P.mpos;
+    const bool slab = P.slab;
+    const int *mit = P.mit.data();
+    {
         std::vector<unsigned long long> h((size_t)2 * mpos), hm(8 + 1024 + 19 * (size_t)ng);
         (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipMemcpy(hm.data(), dbg + 2 * (mpos + 1), hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        (void)hipFree(dbg);
         if (FILE *fp = fopen(trace_path, "w")) {
             fprintf(fp, "# nblk %d g %d ng %d; per M-list item: group local_index start_us end_us (since the first stamp)\n", nblk, g, ng);
             unsigned long long tend = 0, tmin = ~0ull;
@@ -2281,8 +2562,6 @@ void gdca_launch_spd_inverse(hipStream_t s0, double *A, int n_pad, const gdca_in
             fclose(fp);
         }
     }
-    if (n_upd_launch) *n_upd_launch = 1;
-    if (upd_flops) *upd_flops = 2.0 * T * T * KC * chunks;
 }
 
 // -------------------------------------------------------------------------------------------------

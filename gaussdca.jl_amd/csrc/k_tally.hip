@@ -288,22 +288,21 @@ static size_t tally_lds_bytes(int s, int TJ)
     return (size_t)s * (s + 2) * TJ * 8 + (size_t)TALLY_CHUNK * 8 + (size_t)TALLY_CHUNK * TJ;
 }
 
-int gdca_tally_tj(int q)
+int gdca_tally_tj(int q, int tj_wanted)
 {
     // 16 columns per workgroup: 80 KB of histograms at s = 20, so TWO 1024-thread workgroups share a CU and one's staging
     // barriers and epilogue hide behind the other's atomics (measured at config C: 3.26 ms against 4.03 ms with 32 columns
-    // and one workgroup per CU; GDCA_TALLY_TJ=32 brings the wide form back for comparison)
-    static const int tj_env = getenv("GDCA_TALLY_TJ") ? atoi(getenv("GDCA_TALLY_TJ")) : 0;
-    if (tj_env == 32 && tally_lds_bytes(q - 1, 32) <= 160 * 1024) return 32;
+    // and one workgroup per CU; the context option GDCA_TALLY_TJ=32 brings the wide form back for comparison)
+    if (tj_wanted == 32 && tally_lds_bytes(q - 1, 32) <= 160 * 1024) return 32;
     return 16;
 }
 
 void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,
                             int fix_shift, const double *Meff_dev, double pc, const double *Pi_pc, int mode,
-                            double *out, size_t ld)
+                            double *out, size_t ld, int TJ)
 {
     const int s = q - 1;
-    if (gdca_tally_tj(q) == 32) {
+    if (TJ == 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, Zc,

@@ -43,7 +43,7 @@ extern "C" {
 #define GDCA_MAX_N 60000
 
 #define GDCA_VERSION_MAJOR 0
-#define GDCA_VERSION_MINOR 3
+#define GDCA_VERSION_MINOR 4
 
 typedef enum gdca_status {
     GDCA_OK = 0,
@@ -77,7 +77,9 @@ typedef struct gdca_stats {
     int32_t info;               /* 0; k>0: leading minor k of C not positive definite;
                                    k<0: -k site pairs whose DI eigenvalue iteration failed  */
     int32_t N, M, q, n, n_pad;  /* n = N(q-1); n_pad = n rounded up to the tile size        */
-    int32_t update_launches;    /* launches of the dominant kernel (trailing sweep update)  */
+    int32_t update_launches;    /* launches of the dominant kernel this run accounts for (a merged launch: its first member) */
+    int32_t inverse_batch;      /* families that shared this run's SPD-inverse launch (gdca_run_dev_phased merges the small ones;
+                                   1 = a launch of its own).  ms_inverse and ms_inverse_update are the launch's time divided by it */
     /* device time (HIP events on the ctx stream), milliseconds */
     double ms_total;            /* Z in HBM -> S in HBM                                     */
     double ms_theta;            /* column histograms + theta                                */
@@ -109,6 +111,15 @@ gdca_status gdca_ctx_synchronize(gdca_ctx *ctx);
 const char *gdca_last_error(gdca_ctx *ctx); /* valid until the next call on ctx */
 /* per-stage device timing (HIP events + one stream sync per run); default on */
 gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
+/* Tuning switch of THIS context (no process-global state: a context reads the GDCA_* environment variables once, when it is
+ * created; afterwards only this call changes them, and two contexts of one process may differ).  key = the variable's name with
+ * or without the GDCA_ prefix, any case; value = what the variable would hold.  Schedule of the SPD inverse: GROUP (1..4, -1 = the
+ * measured rule), RAMP, RAGGED, REM_TAIL, PANEL_HALVES, SLAB, RING, MCUS; SWEEP_TIMEOUT_MS (bound of one dependency wait inside
+ * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
+ * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
+ * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
+ * 128-blocks), MERGE_MCUS.  Results never depend on them.  GDCA_EINVAL: unknown key or unusable value. */
+gdca_status gdca_ctx_set_option(gdca_ctx *ctx, const char *key, const char *value);
 
 /* ---- fused hot path: replaces src/GaussDCA.jl:28-42 in one call ------------------------ */
 /* Z_host: N x M int8 (host).  S_host: N x N f64 column-major (host), caller-owned.
@@ -173,6 +184,12 @@ gdca_status gdca_add_pseudocount_dev(gdca_ctx *ctx, const double *Pi_true_dev, c
                                      int32_t q, double pc, double *Pi_dev, double *Pij_dev);
 gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const double *Pij_dev, int32_t n, double *C_dev);
 gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info);
+/* K independent inv(cholesky(.)) on one GPU (:34, for K families at once): A_dev[k] (n[k] x n[k], full symmetric, device) is
+ * replaced by its inverse; info[k] as gdca_spd_inverse (info may be NULL).  The small members -- up to MERGE_BLOCKS 128-blocks,
+ * which leave most of the chip idle when they run alone -- share launches of the sweep kernel, MERGE of them at a time
+ * (gdca_ctx_set_option on ctxs[0]); every result is bit for bit that of gdca_spd_inverse_dev.  K <= 64 distinct contexts of
+ * one device (a member's workspace is its context's).  Synchronous.  GDCA_ENOTPD if any member is not positive definite. */
+gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double *const *A_dev, const int32_t *n, int32_t *info);
 gdca_status gdca_fn_dev(gdca_ctx *ctx, const double *mJ_dev, int32_t N, int32_t q, double *S_dev);
 gdca_status gdca_di_dev(gdca_ctx *ctx, const double *mJ_dev, const double *C_dev, int32_t N, int32_t q, double *S_dev);
 gdca_status gdca_apc_dev(gdca_ctx *ctx, double *S_dev, int32_t N);

@@ -27,6 +27,7 @@ int main(void)
     F(gdca_stats, n);
     F(gdca_stats, n_pad);
     F(gdca_stats, update_launches);
+    F(gdca_stats, inverse_batch);
     F(gdca_stats, ms_total);
     F(gdca_stats, ms_theta);
     F(gdca_stats, ms_weights);

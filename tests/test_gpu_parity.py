@@ -63,12 +63,13 @@ def test_reference_goldens_through_cabi(g, ctx, golden, refdata):
         assert st["pair_identity_sum"] == want["pair_identity_sum"]
 
 
-def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refdata, monkeypatch):
+def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refdata):
     """test3 of the reference (test/runtests.jl:78-86) runs a golden again with ENV["DCAUTILS_FORCE_FALLBACK"], i.e. through
     DCAUtils' second, independent Hamming implementation.  The analogue here: GDCA_FORCE_FALLBACK switches the reweighting to a
-    plain byte-compare kernel that shares nothing with the bit-sliced one.  Both must reproduce the golden (the reference's
-    case and the large one) and give identical neighbour counts, bit for bit, on random alignments with awkward sizes."""
-    monkeypatch.setenv("GDCA_FORCE_FALLBACK", "true")
+    plain byte-compare kernel that shares nothing with the bit-sliced one (an option of the context: gdca_ctx_set_option, or the
+    environment variable when the context is created).  Both must reproduce the golden (the reference's case and the large one)
+    and give identical neighbour counts, bit for bit, on random alignments with awkward sizes."""
+    ctx.set_option("GDCA_FORCE_FALLBACK", "true")
     for golden in ("small.DIRout.txt", "large.DIRout.txt"):
         c = CASES[golden]
         R = g.gDCA(os.path.join(refdata, c["fasta"]), ctx=ctx, **c["kw"])
@@ -79,14 +80,14 @@ def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refda
     for (M, N, q, thr) in ((301, 37, 21, 12), (1000, 130, 21, 45), (129, 33, 5, 20), (64, 7, 3, 4)):
         Zo = random_msa(rng, M, N, q)
         Z = np.asfortranarray(Zo.T)
-        monkeypatch.setenv("GDCA_FORCE_FALLBACK", "true")
+        ctx.set_option("GDCA_FORCE_FALLBACK", "true")
         n_fb = g.neighbour_counts(Z, thr, ctx=ctx)
-        monkeypatch.setenv("GDCA_FORCE_FALLBACK", "0")
+        ctx.set_option("GDCA_FORCE_FALLBACK", "0")
         n_bs = g.neighbour_counts(Z, thr, ctx=ctx)
         assert np.array_equal(n_fb, n_bs) and np.array_equal(n_fb, o.neighbour_counts(Zo, thr)), (M, N, q)
 
 
-def test_hamming_lower_bound_form_counts_exactly(g, ctx, o, monkeypatch):
+def test_hamming_lower_bound_form_counts_exactly(g, ctx, o):
     """The reweighting kernel has two forms (csrc/k_hamming.hip): exact distances on all five bit planes, and a two-plane
     lower bound followed by exact refinement of the few pairs the bound does not rule out; a sample of tiles decides per family
     (dense families keep the exact form).  All three settings -- forced exact, forced bound, automatic -- must give the same
@@ -107,9 +108,9 @@ def test_hamming_lower_bound_form_counts_exactly(g, ctx, o, monkeypatch):
         Z = np.asfortranarray(Zo.T)
         want = o.neighbour_counts(Zo, thr)
         for mode in ("full", "bound", "auto"):
-            monkeypatch.setenv("GDCA_HAMMING_MODE", mode)
+            ctx.set_option("HAMMING_MODE", mode)
             assert np.array_equal(g.neighbour_counts(Z, thr, ctx=ctx), want), (name, mode)
-    monkeypatch.delenv("GDCA_HAMMING_MODE")
+    ctx.set_option("HAMMING_MODE", "auto")
 
 
 def test_gdca_matches_oracle_ranking_order(g, ctx, o, refdata):
@@ -336,6 +337,8 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
                 assert torch.equal(outs[k].cpu(), ref[k]), (score, rep, k)
                 assert sts[k]["Meff"] == ref_st[k]["Meff"] and sts[k]["thresh"] == ref_st[k]["thresh"] and sts[k]["info"] == 0
                 assert sts[k]["ms_inverse"] > 0 and sts[k]["sweep_ghz"] > 1.0
+            # the four small members shared ONE merged sweep launch (its first member accounts for it), N = 430 had its own
+            assert [st_["inverse_batch"] for st_ in sts] == [4, 4, 4, 1, 4] and sum(st_["update_launches"] for st_ in sts) == 2
         with pytest.raises(g.ArgumentError):
             g.run_dev_phased([cs[0], cs[0]], [Zd[0].data_ptr()] * 2, [40] * 2, [500] * 2, [21] * 2, pc, -1.0, score,
                              [outs[0].data_ptr()] * 2)               # the same context twice
@@ -404,61 +407,176 @@ def test_large_spd_inverse_residual(g, ctx, n):
     assert np.array_equal(X, X.T)
 
 
-_SCHEDULE_SCRIPT = r"""
-import os, sys, json
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-import gaussdca.jl_amd as g
-ctx = g.Context(0)
-rng = np.random.default_rng(7)
-out = {}
-for n in (128, 300, 640, 768, 896, 1100, 1536, 1700):      # 1 .. 14 pivot blocks, even and odd counts
-    B = rng.standard_normal((n, 40))
-    A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
-    X = g.inv_cholesky(A, ctx=ctx)
-    Xr = np.linalg.inv(A)
-    out[str(n)] = [float(np.max(np.abs(X - Xr)) / np.max(np.abs(Xr))), bool(np.array_equal(X, X.T))]
-A[5, 5] = -1.0                                            # not positive definite: leading minor 6
-try:
-    g.inv_cholesky(A, ctx=ctx)
-    out["info"] = 0
-except g.PosDefException as e:
-    out["info"] = e.info
-print(json.dumps(out))
-"""
+_SCHEDULES = [{"GDCA_GROUP": "1"}, {"GDCA_GROUP": "2"}, {"GDCA_GROUP": "3"}, {"GDCA_GROUP": "4"},
+              {"GDCA_GROUP": "3", "GDCA_MCUS": "1"}, {"GDCA_GROUP": "2", "GDCA_MCUS": "16"},
+              {"GDCA_GROUP": "4", "GDCA_MCUS": "3"}, {"GDCA_GROUP": "3", "GDCA_REM_TAIL": "0"},
+              {"GDCA_GROUP": "2", "GDCA_REM_TAIL": "7"}, {"GDCA_GROUP": "4", "GDCA_REM_TAIL": "100000"},
+              {"GDCA_GROUP": "3", "GDCA_PANEL_HALVES": "1"}, {"GDCA_GROUP": "2", "GDCA_PANEL_HALVES": "0"},
+              {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}, {"GDCA_GROUP": "3", "GDCA_RAMP": "0"},
+              {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"},
+              {"GDCA_GROUP": "3", "GDCA_RAGGED": "0"}, {"GDCA_GROUP": "4", "GDCA_SWEEP_DEBUG": "1"},
+              {"GDCA_GROUP": "1", "GDCA_SWEEP_DEBUG": "1", "GDCA_MCUS": "16"},
+              {"GDCA_GROUP": "1", "GDCA_SLAB": "0"}, {"GDCA_GROUP": "1", "GDCA_SLAB": "0", "GDCA_RING": "2"},
+              {"GDCA_GROUP": "1", "GDCA_RING": "2"}, {"GDCA_GROUP": "1", "GDCA_RING": "3", "GDCA_MCUS": "2"},
+              {"GDCA_GROUP": "1", "GDCA_MCUS": "1"},
+              # the merged kernel (k_sweep_merged) carrying this one inverse (SWEEP_DEBUG bit 3), workspaces poisoned (bit 4)
+              {"GDCA_SWEEP_DEBUG": "24"}, {"GDCA_SWEEP_DEBUG": "24", "GDCA_SLAB": "0"}, {"GDCA_SWEEP_DEBUG": "25", "GDCA_RING": "2"},
+              {"GDCA_SWEEP_DEBUG": "24", "GDCA_MERGE_MCUS": "1"}, {"GDCA_SWEEP_DEBUG": "24", "GDCA_RAGGED": "0", "GDCA_MERGE_MCUS": "16"}]
 
 
-@pytest.mark.parametrize("env", [{"GDCA_GROUP": "1"}, {"GDCA_GROUP": "2"}, {"GDCA_GROUP": "3"}, {"GDCA_GROUP": "4"},
-                                 {"GDCA_GROUP": "3", "GDCA_MCUS": "1"}, {"GDCA_GROUP": "2", "GDCA_MCUS": "16"},
-                                 {"GDCA_GROUP": "4", "GDCA_MCUS": "3"}, {"GDCA_GROUP": "3", "GDCA_REM_TAIL": "0"},
-                                 {"GDCA_GROUP": "2", "GDCA_REM_TAIL": "7"}, {"GDCA_GROUP": "4", "GDCA_REM_TAIL": "100000"},
-                                 {"GDCA_GROUP": "3", "GDCA_PANEL_HALVES": "1"}, {"GDCA_GROUP": "2", "GDCA_PANEL_HALVES": "0"},
-                                 {"GDCA_GROUP": "1", "GDCA_PANEL_HALVES": "0"}, {"GDCA_GROUP": "3", "GDCA_RAMP": "0"},
-                                 {"GDCA_GROUP": "4", "GDCA_RAMP": "0"}, {"GDCA_GROUP": "2", "GDCA_RAMP": "0", "GDCA_MCUS": "2"},
-                                 {"GDCA_GROUP": "3", "GDCA_RAGGED": "0"}, {"GDCA_GROUP": "4", "GDCA_SWEEP_DEBUG": "1"},
-                                 {"GDCA_GROUP": "1", "GDCA_SWEEP_DEBUG": "1", "GDCA_MCUS": "16"},
-                                 {"GDCA_GROUP": "1", "GDCA_SLAB": "0"}, {"GDCA_GROUP": "1", "GDCA_SLAB": "0", "GDCA_RING": "2"},
-                                 {"GDCA_GROUP": "1", "GDCA_RING": "2"}, {"GDCA_GROUP": "1", "GDCA_RING": "3", "GDCA_MCUS": "2"},
-                                 {"GDCA_GROUP": "1", "GDCA_MCUS": "1"}])
-def test_every_inverse_schedule_matches_lapack(env):
+@pytest.mark.parametrize("opts", _SCHEDULES, ids=lambda o: ",".join("%s=%s" % (k[5:], v) for k, v in o.items()))
+def test_every_inverse_schedule_matches_lapack(g, opts):
     """The SPD inverse is one persistent launch that sweeps pivot groups of 1-4 blocks (the group size is chosen by matrix
     size) with its serial chain on 1-16 elected compute units; between single blocks the chain's panel and tile work is cut
-    into row slabs (GDCA_SLAB=0: the panel / tile items of the multi-block schedules) and Pg and the panels live in a ring of
-    eight buffers (GDCA_RING).  Each combination, forced through its environment switches
-    in a fresh process, must give the LAPACK inverse on 1..14 pivot blocks (even and odd block counts, short last groups
-    and matrices smaller than one group included) and the same `info` on a non-PD matrix."""
-    import json
-    import subprocess
-    import sys
+    into row slabs (SLAB=0: the panel / tile items of the multi-block schedules) and Pg and the panels live in a ring of
+    eight buffers (RING).  Each combination, forced through the options of a context of its own (gdca_ctx_set_option: no
+    process-global switches, so all of them run in this process, beside each other), must give the LAPACK inverse on 1..14
+    pivot blocks (even and odd block counts, short last groups and matrices smaller than one group included) and the same
+    `info` on a non-PD matrix."""
+    c = g.Context(0)
+    c.set_options(**opts)
+    rng = np.random.default_rng(7)
+    try:
+        for n in (128, 300, 640, 768, 896, 1100, 1536, 1700):      # 1 .. 14 pivot blocks, even and odd counts
+            B = rng.standard_normal((n, 40))
+            A = (B @ B.T) / 40 + np.diag(0.3 + rng.random(n))
+            X = g.inv_cholesky(A, ctx=c)
+            Xr = np.linalg.inv(A)
+            rel = float(np.max(np.abs(X - Xr)) / np.max(np.abs(Xr)))
+            assert rel <= 1e-10 and np.array_equal(X, X.T), (opts, n, rel)   # cond ~ 1e2: far inside the 1e-6 bar for scores
+        A[5, 5] = -1.0                                            # not positive definite: leading minor 6
+        with pytest.raises(g.PosDefException) as ei:
+            g.inv_cholesky(A, ctx=c)
+        assert ei.value.info == 6
+    finally:
+        c.close()
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-c", _SCHEDULE_SCRIPT, root], capture_output=True, text=True, env=e, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out.pop("info") == 6
-    for n, (rel, sym) in out.items():
-        assert rel <= 1e-10 and sym, (env, n, rel, sym)    # cond ~ 1e2: far inside the 1e-6 bar for scores
+
+def test_context_options_are_per_context(g, ctx):
+    """gdca_ctx_set_option: unknown keys and unusable values are GDCA_EINVAL and leave the context as it was; two contexts of
+    one process hold different schedules and give the same bits."""
+    c1, c2 = g.Context(0), g.Context(0)
+    try:
+        for key, val in (("NO_SUCH_SWITCH", "1"), ("GROUP", "9"), ("GROUP", "x"), ("RING", "1"), ("SWEEP_TIMEOUT_MS", "-5")):
+            with pytest.raises(g.ArgumentError):
+                c1.set_option(key, val)
+        c1.set_options(GROUP=1, gdca_mcus=3, Hamming_Mode="full")
+        c2.set_options(GROUP=4, MCUS=16, HAMMING_MODE="bound")
+        rng = np.random.default_rng(3)
+        n = 1300
+        B = rng.standard_normal((n, 30))
+        A = (B @ B.T) / 30 + np.diag(0.4 + rng.random(n))
+        X1, X2, X0 = g.inv_cholesky(A, ctx=c1), g.inv_cholesky(A, ctx=c2), g.inv_cholesky(A, ctx=ctx)
+        assert np.max(np.abs(X1 - X2)) <= 1e-11 * np.max(np.abs(X0)) and np.max(np.abs(X1 - X0)) <= 1e-11 * np.max(np.abs(X0))
+        Z = np.asfortranarray(rng.integers(1, 22, size=(60, 900)).astype(np.int8))
+        n1 = g.neighbour_counts(Z, 25, ctx=c1)
+        n2 = g.neighbour_counts(Z, 25, ctx=c2)
+        assert np.array_equal(n1, n2)
+    finally:
+        c1.close()
+        c2.close()
+
+
+def test_merged_inverses_equal_single_launches(g, ctx):
+    """gdca_spd_inverse_batch_dev: K small matrices carried by ONE launch of k_sweep_merged (each family its own descriptor,
+    flags and chain compute units; the workgroups take main-list items of the families in turn) must give, bit for bit, what K
+    launches of their own give -- every K, mixed and equal sizes, ragged ends, one to 48 blocks, with the members' workspaces
+    poisoned with NaNs before each run (an item that reads a panel before its producer wrote it cannot pass on the leftovers of
+    an earlier identical run).  A member that is not positive definite reports its own `info`; the others are unaffected."""
+    import torch
+
+    rng = np.random.default_rng(21)
+
+    def mat(n):
+        B = rng.standard_normal((n, 24))
+        return (B @ B.T) / 24 + np.diag(0.5 + rng.random(n))
+
+    cs = [g.Context(0) for _ in range(8)]
+    try:
+        for rnd, ns in enumerate(([2560] * 4, [2560] * 8, [100, 1290, 3000, 777, 6016, 128, 129, 2000], [4000, 4096], [640],
+                                  [1900, 1900, 1900], [5000, 300, 5000, 300, 5000])):
+            As = [mat(n) for n in ns]
+            ref = []
+            for A in As:
+                d = torch.from_numpy(A).cuda()
+                info = g._lib.C.c_int32()
+                ctx.check(ctx.lib.gdca_spd_inverse_dev(ctx.h, g._lib.C.c_void_p(d.data_ptr()), A.shape[0], g._lib.C.byref(info)))
+                ref.append(d.cpu().numpy())
+                V = rng.standard_normal((A.shape[0], 2))
+                assert np.max(np.abs(A @ (ref[-1] @ V) - V)) < 1e-9
+            for merge, extra in ((8, {}), (4, {"MERGE_MCUS": 2}), (2, {"SLAB": rnd % 2}), (3, {"RING": 2 + rnd % 5})):
+                K = len(ns)
+                if extra.get("SLAB", 1) == 0:   # another schedule, another summation order: its own single launches are the reference
+                    ctx.set_option("SLAB", 0)
+                    ref_here = []
+                    for A in As:
+                        d = torch.from_numpy(A).cuda()
+                        info = g._lib.C.c_int32()
+                        ctx.check(ctx.lib.gdca_spd_inverse_dev(ctx.h, g._lib.C.c_void_p(d.data_ptr()), A.shape[0], g._lib.C.byref(info)))
+                        ref_here.append(d.cpu().numpy())
+                    ctx.set_option("SLAB", 1)
+                else:
+                    ref_here = ref
+                cs[0].set_options(MERGE=merge, MERGE_BLOCKS=48, SWEEP_DEBUG=24, MERGE_MCUS=-1, SLAB=1, RING=8)
+                cs[0].set_options(**extra)
+                for c in cs[1:K]:   # (a member's schedule switches are its own context's)
+                    c.set_options(SLAB=extra.get("SLAB", 1), RING=extra.get("RING", 8))
+                ds = [torch.from_numpy(A).cuda() for A in As]
+                infos = g.spd_inverse_batch_dev(cs[:K], [d.data_ptr() for d in ds], ns)
+                assert infos == [0] * K
+                for k in range(K):
+                    assert np.array_equal(ds[k].cpu().numpy(), ref_here[k]), (ns, merge, extra, k)
+        # one member not positive definite
+        ns = [900, 1400, 700]
+        As = [mat(n) for n in ns]
+        As[1][300, 300] = -2.0
+        ds = [torch.from_numpy(A).cuda() for A in As]
+        cs[0].set_options(MERGE=4, SWEEP_DEBUG=0)
+        with pytest.raises(g.PosDefException) as ei:
+            g.spd_inverse_batch_dev(cs[:3], [d.data_ptr() for d in ds], ns)
+        assert ei.value.info == 301
+        for k in (0, 2):
+            assert np.max(np.abs(ds[k].cpu().numpy() - np.linalg.inv(As[k]))) < 1e-9
+        with pytest.raises(g.ArgumentError):
+            g.spd_inverse_batch_dev([cs[0], cs[0]], [ds[0].data_ptr()] * 2, [900] * 2)
+    finally:
+        for c in cs:
+            c.close()
+
+
+def test_merged_sweep_watchdog(g):
+    """The merged launch keeps the promise of the single one: when a member's chain never runs (SWEEP_DEBUG bit 1: nobody is
+    elected) the bounded waits end the launch, EVERY member of it is reported as aborted (no member's result can be trusted
+    once a workgroup has dropped its items), and the contexts stay usable."""
+    import time
+
+    import torch
+
+    rng = np.random.default_rng(2)
+    cs = [g.Context(0) for _ in range(3)]
+    try:
+        ns = [1500, 2000, 1000]
+        As = []
+        for n in ns:
+            B = rng.standard_normal((n, 24))
+            As.append((B @ B.T) / 24 + np.diag(0.5 + rng.random(n)))
+        for c in cs:
+            c.set_options(SWEEP_DEBUG=0, SWEEP_TIMEOUT_MS=300)
+        cs[1].set_options(SWEEP_DEBUG=2)               # this member's chain gets no compute unit
+        cs[0].set_options(MERGE=4)
+        ds = [torch.from_numpy(A).cuda() for A in As]
+        t = time.time()
+        with pytest.raises(g.GdcaError) as ei:
+            g.spd_inverse_batch_dev(cs, [d.data_ptr() for d in ds], ns)
+        assert "timed out" in str(ei.value) and time.time() - t < 20.0
+        cs[1].set_options(SWEEP_DEBUG=0)
+        ds = [torch.from_numpy(A).cuda() for A in As]
+        assert g.spd_inverse_batch_dev(cs, [d.data_ptr() for d in ds], ns) == [0, 0, 0]
+        for k in range(3):
+            assert np.max(np.abs(ds[k].cpu().numpy() - np.linalg.inv(As[k]))) < 1e-9
+    finally:
+        for c in cs:
+            c.close()
 
 
 _TRACE_SCRIPT = r"""
