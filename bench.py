@@ -168,27 +168,31 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         probe_omp[c] = best
     cores = min(probe_omp, key=probe_omp.get)
     o.set_threads(cores)
+    # OpenBLAS: the thread count is chosen on the TIMED size, not on a small probe (an n/4 probe, 64x fewer flops,
+    # picked 16 threads and the n = 10 000 inverse then ran at 0.65 TFLOP/s).  A first estimate on n/2 (8x fewer flops) ranks the
+    # candidates; where the family is measured in full, potrf + potri then runs at full size on the best candidates and the stage
+    # time is the minimum over them (`blas_inv_sec_at_n` in thread_choice says which counts were timed).
     probe_blas = {}
     blas_threads = avail
+    threadpool_limits = None
     try:
         from threadpoolctl import threadpool_limits
 
         rng0 = np.random.default_rng(1)
-        B0 = rng0.standard_normal((max(512, n // 4), 64))
+        B0 = rng0.standard_normal((max(512, n // 2), 64))
         C0 = B0 @ B0.T / 64 + np.eye(B0.shape[0])
         for c in cands:
             with threadpool_limits(limits=c, user_api="blas"):
                 o.spd_inverse(np.eye(64))
-                best = 1e9
-                for _ in range(2):
-                    t = time.time()
-                    o.spd_inverse(C0)
-                    best = min(best, time.time() - t)
-                probe_blas[c] = best
+                t = time.time()
+                o.spd_inverse(C0)
+                probe_blas[c] = time.time() - t
+        del B0, C0
         blas_threads = min(probe_blas, key=probe_blas.get)
         blas_limit = threadpool_limits(limits=blas_threads, user_api="blas")
     except Exception:  # noqa: BLE001
         blas_limit = None
+    blas_full = {}
     th = o.compute_theta(Z) if theta < 0 else float(theta)
     thr = o.hamming_threshold(th, N)
 
@@ -200,13 +204,16 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
     ham_rate = (Mp * (Mp - 1.0) / 2) / max(1e-6, time.time() - t)  # pairs per second, all threads
     est_ham = (M * (M - 1.0) / 2) / ham_rate
     rng = np.random.default_rng(0)
-    npb = max(256, n // 4)
-    Bp = rng.standard_normal((npb, 64))
-    Cp = Bp @ Bp.T / 64 + np.eye(npb)
-    o.spd_inverse(np.eye(64))                      # LAPACK import / thread start-up outside the probe
-    t = time.time()
-    o.spd_inverse(Cp)
-    est_inv = (time.time() - t) * (n / npb) ** 3
+    npb = max(256, n // 2)
+    if probe_blas:
+        est_inv = probe_blas[blas_threads] * (n / max(512, n // 2)) ** 3
+    else:
+        Bp = rng.standard_normal((npb, 64))
+        Cp = Bp @ Bp.T / 64 + np.eye(npb)
+        o.spd_inverse(np.eye(64))                      # LAPACK import / thread start-up outside the probe
+        t = time.time()
+        o.spd_inverse(Cp)
+        est_inv = (time.time() - t) * (n / npb) ** 3
     Mf = min(M, 6000)
     t = time.time()
     o.compute_frequencies(Z[:Mf], q, np.ones(Mf), float(Mf))
@@ -249,9 +256,23 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         C = o.compute_C(Pi2, Pij2)
         stage["cov"] = time.time() - t
         del Pi, Pij, Pij2
-        t = time.time()
-        mJ = o.spd_inverse(C)
-        stage["inv"] = time.time() - t
+        # potrf + potri on the family's own covariance with every candidate thread count whose n/2 estimate is within 1.6x of
+        # the best (at most three): the stage time is the fastest of them
+        if threadpool_limits is not None and probe_blas:
+            ranked = sorted(probe_blas, key=probe_blas.get)
+            tryc = [c for c in ranked if probe_blas[c] <= 1.6 * probe_blas[ranked[0]]][:3]
+            mJ = None
+            for c in tryc:
+                with threadpool_limits(limits=c, user_api="blas"):
+                    t = time.time()
+                    mJ = o.spd_inverse(C)
+                    blas_full[c] = time.time() - t
+            blas_threads = min(blas_full, key=blas_full.get)
+            stage["inv"] = blas_full[blas_threads]
+        else:
+            t = time.time()
+            mJ = o.spd_inverse(C)
+            stage["inv"] = time.time() - t
         t = time.time()
         S = o.compute_DI_gauss(mJ, C, q) if score_name == "DI" else o.compute_FN(mJ, q)
         o.correct_APC(S)
@@ -287,11 +308,15 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
     sec = sum(stage.values())
     if blas_limit is not None:
         blas_limit.restore_original_limits()
-    return dict(value=1.0 / sec, unit="families/s", cores=cores, blas_threads=blas_threads, host_threads_available=avail,
+    inv_flops = (n ** 3 / 3.0 + n * n / 2.0 + n / 6.0) + (2.0 * n ** 3 / 3.0 + n * n / 2.0 + 5.0 * n / 6.0)
+    return dict(value=1.0 / sec, unit="families/s", cores=max(cores, blas_threads),
+                threads={"omp": cores, "blas": blas_threads}, host_threads_available=avail,
                 thread_choice={"openmp_probe_sec": {str(k): round(v, 4) for k, v in probe_omp.items()},
-                               "blas_probe_sec": {str(k): round(v, 4) for k, v in probe_blas.items()}},
+                               "blas_probe_sec_at_half_n": {str(k): round(v, 4) for k, v in probe_blas.items()},
+                               "blas_inv_sec_at_n": {str(k): round(v, 4) for k, v in blas_full.items()}},
                 kind="port", measured_in_full=bool(full),
                 sec_per_family=sec, stage_sec={k: round(v, 4) for k, v in stage.items()},
+                inv_tflops=inv_flops / max(stage["inv"], 1e-9) / 1e12,
                 thread_scaling={"hamming_pairs_per_s_1_thread": ham_rate_1, "hamming_pairs_per_s_all": ham_rate,
                                 "hamming_speedup": ham_rate / ham_rate_1,
                                 "tally_s_per_seq_1_thread": freq_1, "tally_s_per_seq_all": freq_all,
@@ -331,6 +356,8 @@ def main():
     ap.add_argument("--q", type=int, default=21)
     ap.add_argument("--families", type=int, default=256, help="--config E: families in the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (config C, :frob): skip the lines of :DI, B, D and the E prefix (`other_configs`)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: every rank derives its shard, the ranks meet at the (gloo) barrier and rank 0 prints "
                          "the JSON line with the shards instead of timings (used by the CPU tests of the N > 1 path)")
@@ -356,12 +383,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     q = args.q
-    score = 1 if args.score == "DI" else 0
-    pc = 0.2 if score == 1 else 0.8
-    cfg = CONFIGS[args.config]
     fams = workload(args.config, args, rank, world)
 
-    import numpy as np
     import torch
 
     dist = None
@@ -415,15 +438,91 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    meas = measure(args, args.config, args.score, args.steps, args.warmup, rank, world, local, dev, dist)
+    out = summarize(args, meas, world, dist, comm_fallback)  # (every rank: it holds the reductions)
+    if rank != 0:
+        release(meas)
+    else:
+        cfg = CONFIGS[args.config]
+        N0, M0 = meas["fams"][0][1], meas["fams"][0][2]
+        if world == 1 and args.config != "E":
+            out["end_to_end_gdca_sec"] = end_to_end(meas["Zh"][0], q, args.score, meas["pc"], meas["ctxs"][0])
+        release(meas)
+        # every other single-GPU configuration of BASELINE.json in the same run: :DI at the headline size, B
+        # (alone and four at a time through the merged sweep), D and a 32-family prefix of the batch E
+        if world == 1 and args.config == "C" and args.score == "frob" and not args.no_other_configs and not (args.N or args.M):
+            others = {}
+            plan = (("C_DI", "C", "DI", 20, 3, 1, False, 256), ("B", "B", "frob", 40, 5, 1, False, 256),
+                    ("B_merged4", "B", "frob", 40, 5, 4, True, 256), ("D", "D", "frob", 5, 1, 1, False, 256),
+                    ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_phased4", "E", "frob", 2, 1, 4, True, 32))
+            for key, cname, sc, st_, wu, P_, ph_, nf in plan:
+                try:
+                    a2 = argparse.Namespace(**vars(args))
+                    a2.pipeline, a2.phased, a2.gate, a2.families, a2.N, a2.M = P_, ph_, False, nf, 0, 0
+                    m2 = measure(a2, cname, sc, st_, wu, 0, 1, local, dev, None)
+                    o2 = summarize(a2, m2, 1, None, None)
+                    if cname not in ("E",):
+                        o2["end_to_end_gdca_sec"] = end_to_end(m2["Zh"][0], q, sc, m2["pc"], m2["ctxs"][0]) if key in ("C_DI", "D") else None
+                    release(m2)
+                    others[key] = {k: o2[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "sec_per_family", "stage_ms",
+                                                      "spd_inverse_tflops", "end_to_end_gdca_sec") if k in o2}
+                    others[key]["workload"] = o2["config"]["workload"]
+                    others[key]["schedule"] = o2["config"]["schedule"]
+                    others[key]["roofline"] = {k: o2["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                                             "launches_per_step", "measured_shader_ghz",
+                                                                             "frac_of_attainable_at_measured_clock")}
+                except Exception as e:  # noqa: BLE001
+                    others[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["other_configs"] = others
+        if world == 1 and not args.no_cpu_baseline and args.config != "E":
+            out["reference_julia"] = probe_reference_julia()
+            try:
+                out["cpu_baseline"] = cpu_baseline(N0, M0, q, meas["pc"], cfg["theta"], args.score, meas["fams"][0][3])
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def release(meas):
+    """Free a measurement's contexts and device buffers before the next configuration is set up."""
+    for c in meas["ctxs"] + meas["ctxs2"]:
+        c.close()
+    meas["ctxs"], meas["ctxs2"] = [], []
+    meas["Zd"] = meas["Sd"] = meas["Sd2"] = None
+    import torch
+
+    torch.cuda.empty_cache()
+
+
+def measure(args, config, score_name, steps, warmup, rank, world, local, dev, dist):
+    """W untimed and exactly K timed steps of `config` on this rank's GPU, bracketed by barrier + synchronize on both sides."""
+    import numpy as np  # noqa: F401
+    import torch
+
+    import gaussdca.jl_amd as g
+
+    q = args.q
+    score = 1 if score_name == "DI" else 0
+    pc = 0.2 if score == 1 else 0.8
+    cfg = CONFIGS[config]
+    fams = workload(config, args, rank, world)
+    P = max(1, args.pipeline)
+    phased = bool(args.phased and P > 1)
+    if config == "E" and phased:
+        # batches of P neighbours in this order: families of similar covariance size side by side, so that the small ones of
+        # a batch share merged sweep launches (any processing order is as good as another: the families are independent)
+        fams = sorted(fams, key=lambda f: (-f[1], f[0]))
     # synthetic families, resident in HBM before the timed region ((M, N) int8 == Julia's N x M column-major bytes)
     from concurrent.futures import ThreadPoolExecutor
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         Zh = list(ex.map(lambda f: synth_family(f[1], f[2], q, f[3]), fams))
     Zd = [torch.from_numpy(z).to(dev) for z in Zh]
-    if args.config == "E":
+    if config == "E":
         Zh = Zh[:1]
-    P = max(1, args.pipeline)
     nmax = max(f[1] for f in fams)
     Sd = [torch.empty((nmax, nmax), dtype=torch.float64, device=dev) for _ in range(P)]  # stay in HBM
     ctxs = [g.Context(local)]
@@ -431,7 +530,7 @@ def main():
         ctxs.append(ctxs[0].peer() if args.gate else g.Context(local))
     busy = [False] * P
     ctxs2, Sd2 = [], []
-    if args.phased and P > 1:
+    if phased:
         ctxs2 = [g.Context(local) for _ in range(P)]
         Sd2 = [torch.empty((nmax, nmax), dtype=torch.float64, device=dev) for _ in range(P)]
 
@@ -457,7 +556,7 @@ def main():
     def run_steps(count, sink):
         """`count` steps; inside a step the rank's families go round-robin over the P contexts; a context's previous
         pass is collected (stream sync + stats) right before it is given the next one."""
-        if args.phased and P > 1:
+        if phased:
             return run_steps_phased(count, sink)
         t = 0
         for _ in range(count):
@@ -481,19 +580,33 @@ def main():
             c.synchronize()
 
     # every context is warmed (workspace allocation: hipMalloc synchronises the device) before the clock starts
-    warm = max(args.warmup, 1, -(-(2 * P if (args.phased and P > 1) else P) // max(1, len(fams))))
+    warm = max(warmup, 1, -(-(2 * P if phased else P) // max(1, len(fams))))
     run_steps(warm, [])
     barrier()
     t0 = time.perf_counter()
     stats = []
-    run_steps(args.steps, stats)
+    run_steps(steps, stats)
     barrier()
     dt = time.perf_counter() - t0
-    nfam_local = len(fams) * args.steps
+    return dict(config=config, score_name=score_name, pc=pc, fams=fams, Zh=Zh, Zd=Zd, Sd=Sd, Sd2=Sd2, ctxs=ctxs, ctxs2=ctxs2,
+                stats=stats, dt=dt, steps=steps, warm=warm, P=P, phased=phased)
+
+
+def summarize(args, meas, world, dist, comm_fallback):
+    """Rank 0's JSON object of one measurement (all ranks take part in the reductions)."""
+    import numpy as np
+    import torch
+
+    q = args.q
+    cfg = CONFIGS[meas["config"]]
+    config, score_name, pc = meas["config"], meas["score_name"], meas["pc"]
+    fams, stats, dt, P = meas["fams"], meas["stats"], meas["dt"], meas["P"]
+    nfam_local = len(fams) * meas["steps"]
     nfam = nfam_local
     flops_local = float(sum(s["inverse_flops"] for s in stats))
     flops = flops_local
     if dist is not None:
+        dev = torch.device("cuda", torch.cuda.current_device())
         on = dev if dist.get_backend() == "nccl" else "cpu"
         tt = torch.tensor([dt], dtype=torch.float64, device=on)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -501,89 +614,82 @@ def main():
         cnt = torch.tensor([float(nfam_local), flops_local], dtype=torch.float64, device=on)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         nfam, flops = int(round(float(cnt[0].item()))), float(cnt[1].item())
-
-    if rank == 0:
-        K = args.steps
-        ms_step = dt / K * 1e3
-        upd_ms = float(np.sum([s["ms_inverse_update"] for s in stats]))
-        upd_launch = int(np.sum([s["update_launches"] for s in stats]))
-        upd_flops = float(np.sum([s["update_flops"] for s in stats]))
-        inv_ms = float(np.sum([s["ms_inverse"] for s in stats]))
-        alg_flops = float(np.sum([s["inverse_flops"] for s in stats]))  # F = n^3 + n^2 + n per family
-        achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-        N0, M0 = fams[0][1], fams[0][2]
-        ghz = float(np.mean([s["sweep_ghz"] for s in stats]))
-        traffic, traffic_src = pmc_traffic(N0, M0, args.score) if args.config != "E" else (None, None)
-        if args.config == "E":
-            wl = ("batch of %d synthetic Pfam-like families, N in [100,600], M in [5k,80k], q=%d, score=:%s, "
-                  "theta=:auto, pseudocount=%.1f, LPT-sharded over %d rank(s) (%s)"
-                  % (args.families, q, args.score, pc, world, cfg["ref"]))
-        else:
-            wl = ("synthetic Pfam-like MSA N=%d M=%d q=%d, score=:%s, theta=%s, pseudocount=%.1f (%s)"
-                  % (N0, M0, q, args.score, ":auto" if cfg["theta"] < 0 else repr(cfg["theta"]), pc, cfg["ref"]))
-        out = {
-            "metric": METRIC,
-            "value": nfam / dt,
-            "unit": "families/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": warm,
-            "ms_per_step": ms_step,
-            "higher_is_better": True,
-            "scaling": "strong" if args.config == "E" else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": wl, "name": args.config, "q": q,
-                       "families_per_step": nfam // K, "families_per_step_rank0": len(fams),
-                       "families_in_flight_per_gpu": P,
-                       "schedule": ("phase-batched: %d front ends, %d inverses back to back, %d score stages" % (P, P, P))
-                       if (args.phased and P > 1) else ("one family after the other" if P == 1 else "independent streams")},
-            "sec_per_family": dt / (nfam / world) if args.config != "E" else dt / nfam,
-            "aggregate_inverse_tflops": flops / dt / 1e12,
-            "latency_ms_per_family": float(np.mean([s["ms_total"] for s in stats])),
-            "spd_inverse_tflops": float(np.sum([s["inverse_flops"] for s in stats])) / (inv_ms * 1e-3) / 1e12,
-            "stage_ms": {k: float(np.mean([s[k] for s in stats])) for k in
-                         ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
-                          "ms_score")},
-            "roofline": {
-                "kernel": "k_sweep (the whole SPD inverse as ONE persistent launch: block symmetric sweep, f64 MFMA 128x128 "
-                          "tiles, pivot chain on elected CUs; duration from HIP events on its stream)",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_F64_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F64_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,  # a committed rocprofv3 counter pass of this command, not this run
-                "launches_per_step": upd_launch / K,
-                "flops_per_launch": alg_flops / max(1, upd_launch),
-                "mfma_flops_issued_per_launch": upd_flops / max(1, upd_launch),  # incl. the padding to 128-blocks
-                "avg_launch_ms": upd_ms / max(1, upd_launch),
-                # shader clock of the timed launches, measured by the kernel (s_memtime / 100 MHz wall clock of one
-                # workgroup, gdca_stats.sweep_ghz), and what the matrix pipes could deliver at that clock
-                "measured_shader_ghz": ghz,
-                "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ,
-                "frac_of_attainable_at_measured_clock": (achieved / (PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ)) if ghz > 0 else None,
-            },
-            "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
-                     "data_path_collectives": 0, "fallback_reason": comm_fallback},
-        }
-        if args.config != "E":
-            out["config"].update({"N": N0, "M": M0, "n": N0 * (q - 1)})
-            out.update({"theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"]})
-        if world == 1 and args.config != "E":
-            out["end_to_end_gdca_sec"] = end_to_end(Zh[0], q, args.score, pc, ctxs[0])
-        if world == 1 and not args.no_cpu_baseline and args.config != "E":
-            out["reference_julia"] = probe_reference_julia()
-            try:
-                out["cpu_baseline"] = cpu_baseline(N0, M0, q, pc, cfg["theta"], args.score, fams[0][3])
-                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    K = meas["steps"]
+    ms_step = dt / K * 1e3
+    upd_ms = float(np.sum([s["ms_inverse_update"] for s in stats]))
+    upd_launch = int(np.sum([s["update_launches"] for s in stats]))
+    upd_flops = float(np.sum([s["update_flops"] for s in stats]))
+    inv_ms = float(np.sum([s["ms_inverse"] for s in stats]))
+    alg_flops = float(np.sum([s["inverse_flops"] for s in stats]))  # F = n^3 + n^2 + n per family
+    achieved = alg_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    N0, M0 = fams[0][1], fams[0][2]
+    ghz = float(np.mean([s["sweep_ghz"] for s in stats]))
+    traffic, traffic_src = pmc_traffic(N0, M0, score_name) if config != "E" else (None, None)
+    merged = sorted({int(s["inverse_batch"]) for s in stats})
+    if config == "E":
+        wl = ("batch of %d synthetic Pfam-like families, N in [100,600], M in [5k,80k], q=%d, score=:%s, "
+              "theta=:auto, pseudocount=%.1f, LPT-sharded over %d rank(s) (%s)"
+              % (args.families, q, score_name, pc, world, cfg["ref"]))
+    else:
+        wl = ("synthetic Pfam-like MSA N=%d M=%d q=%d, score=:%s, theta=%s, pseudocount=%.1f (%s)"
+              % (N0, M0, q, score_name, ":auto" if cfg["theta"] < 0 else repr(cfg["theta"]), pc, cfg["ref"]))
+    kernel = ("k_sweep (the whole SPD inverse as ONE persistent launch: block symmetric sweep, f64 MFMA 128x128 "
+              "tiles, pivot chain on elected CUs; duration from HIP events on its stream)")
+    if merged != [1]:
+        kernel = ("k_sweep / k_sweep_merged (one persistent launch per SPD inverse, or per group of up to %d small inverses sharing a "
+                  "launch: block symmetric sweep, f64 MFMA 128x128 tiles; duration from HIP events on its stream)" % max(merged))
+    out = {
+        "metric": METRIC,
+        "value": nfam / dt,
+        "unit": "families/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": meas["warm"],
+        "ms_per_step": ms_step,
+        "higher_is_better": True,
+        "scaling": "strong" if config == "E" else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": wl, "name": config, "q": q,
+                   "families_per_step": nfam // K, "families_per_step_rank0": len(fams),
+                   "families_in_flight_per_gpu": P,
+                   "inverses_per_sweep_launch": merged,
+                   "schedule": ("phase-batched: %d front ends, the %d inverses (the small ones merged into shared launches), %d score stages"
+                                % (P, P, P)) if meas["phased"] else ("one family after the other" if P == 1 else "independent streams")},
+        "sec_per_family": dt / (nfam / world) if config != "E" else dt / nfam,
+        "aggregate_inverse_tflops": flops / dt / 1e12,
+        "latency_ms_per_family": float(np.mean([s["ms_total"] for s in stats])),
+        "spd_inverse_tflops": float(np.sum([s["inverse_flops"] for s in stats])) / (inv_ms * 1e-3) / 1e12,
+        "stage_ms": {k: float(np.mean([s[k] for s in stats])) for k in
+                     ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
+                      "ms_score")},
+        "roofline": {
+            "kernel": kernel,
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": PEAK_F64_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F64_MFMA_TFLOPS,
+            "traffic": traffic,
+            "traffic_source": traffic_src,  # a committed rocprofv3 counter pass of this command, not this run
+            "launches_per_step": upd_launch / K,
+            "flops_per_launch": alg_flops / max(1, upd_launch),
+            "mfma_flops_issued_per_launch": upd_flops / max(1, upd_launch),  # incl. the padding to 128-blocks
+            "avg_launch_ms": upd_ms / max(1, upd_launch),
+            # shader clock of the timed launches, measured by the kernel (s_memtime / 100 MHz wall clock of one
+            # workgroup, gdca_stats.sweep_ghz), and what the matrix pipes could deliver at that clock
+            "measured_shader_ghz": ghz,
+            "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ,
+            "frac_of_attainable_at_measured_clock": (achieved / (PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ)) if ghz > 0 else None,
+        },
+        "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
+                 "data_path_collectives": 0, "fallback_reason": comm_fallback},
+    }
+    if config != "E":
+        out["config"].update({"N": N0, "M": M0, "n": N0 * (q - 1)})
+        out.update({"theta": stats[-1]["theta"], "Meff": stats[-1]["Meff"], "thresh": stats[-1]["thresh"]})
+    return out
 
 
 if __name__ == "__main__":

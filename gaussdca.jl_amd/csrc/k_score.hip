@@ -31,60 +31,98 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ---- FN ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t ld, int N, int sdim, long long npairs,
-                                             double *__restrict__ S)
+// HBM-bound: 8 s^2 bytes per site pair, one pass over the lower block triangle (399 MB at N = 500).  One wave per pair reading its
+// own s column segments of 8 s bytes (160 B at a stride of ld) got 2.5 TB/s out of that.  Now a workgroup takes FN_PG
+// consecutive row sites j of ONE column site i: in each of the s columns their blocks are one contiguous run of FN_PG 8 s
+// bytes (1280 B), fetched with 16-byte loads, all s runs in flight at once, into an LDS image [column][run] (row stride
+// padded so that a column walk hits different banks); then every wave scores its pairs from LDS.  The arithmetic of a pair --
+// row means, column means, their order of summation, the per-lane partial sums of the norm and the butterfly that adds them -- is
+// unchanged: scores are bit for bit those of the old kernel.
+#define FN_PG 8
+
+// workgroup b <-> (row chunk J, column site i), i < min(N - 1, FN_PG (J + 1) - 1): chunk J has FN_PG J + FN_PG - 1 column sites
+// (every site left of its last row), but for the last chunk, which is clipped at N - 1
+__device__ __forceinline__ void fn_decode(long long b, int &J, int &i)
+{
+    // b = FN_PG J (J - 1) / 2 + (FN_PG - 1) J + i
+    int jj = (int)((sqrt((double)(FN_PG - 2) * (FN_PG - 2) / 4.0 + 2.0 * FN_PG * (double)b) - (FN_PG - 2) / 2.0) / FN_PG);
+    auto first = [](long long x) { return (long long)FN_PG * x * (x - 1) / 2 + (long long)(FN_PG - 1) * x; };
+    while (jj > 0 && first(jj) > b) --jj;
+    while (first(jj + 1) <= b) ++jj;
+    J = jj;
+    i = (int)(b - first(jj));
+}
+
+__global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t ld, int N, int sdim, double *__restrict__ S)
 {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ss = sdim * sdim;
-    double *blk = fsm + (size_t)wv * (ss + 64);
-    double *rm = blk + ss, *cm = rm + 32;
-    long long p = (long long)blockIdx.x * 4 + wv;
-    const bool live = p < npairs;
-    if (!live) p = npairs - 1;
-    int i, j;
-    pair_decode(p, i, j);
-    const double *src = A + (size_t)j * sdim + (size_t)i * sdim * ld;
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        blk[e] = src[(size_t)r + (size_t)c * ld];
+    int J, i;
+    fn_decode((long long)blockIdx.x, J, i);
+    const int j_lo = max(J * FN_PG, i + 1), j_hi = min(N, J * FN_PG + FN_PG);
+    const int L = (j_hi - j_lo) * sdim;          // rows of the run
+    const int Lp = FN_PG * sdim + 2;             // row stride of the LDS image (even: 16-byte stores stay aligned)
+    double *img = fsm;                           // img[c * Lp + (row of the run)]
+    double *rm = fsm + (size_t)sdim * Lp + (size_t)wv * 64, *cm = rm + 32;
+    const double *src = A + (size_t)j_lo * sdim + (size_t)i * sdim * ld;
+    if (((j_lo * sdim) & 1) == 0 && (L & 1) == 0) {
+        const int L2 = L >> 1;
+        for (int e = tid; e < sdim * L2; e += 256) {
+            const int c = e / L2, r2 = e - c * L2;
+            const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)c * ld + 2 * r2);
+            *reinterpret_cast<double2 *>(img + c * Lp + 2 * r2) = v;
+        }
+    } else {
+        for (int e = tid; e < sdim * L; e += 256) {
+            const int c = e / L, r = e - c * L;
+            img[c * Lp + r] = src[(size_t)c * ld + r];
+        }
     }
     __syncthreads();
-    if (lane < sdim) {
-        double a = 0.0;
-        for (int c = 0; c < sdim; ++c) a += blk[lane + c * sdim];
-        rm[lane] = a / (double)sdim;
-    } else if (lane >= 32 && lane - 32 < sdim) {
-        const int c = lane - 32;
-        double a = 0.0;
-        for (int r = 0; r < sdim; ++r) a += blk[r + c * sdim];
-        cm[c] = a / (double)sdim;
-    }
-    __syncthreads();
-    double tot = 0.0;
-    for (int r = 0; r < sdim; ++r) tot += rm[r];
-    tot /= (double)sdim;  // = sum(block) / s^2
-    double f = 0.0;
-    for (int e = lane; e < ss; e += 64) {
-        const int r = e % sdim, c = e / sdim;
-        const double kx = blk[e] - rm[r] - cm[c] + tot;
-        f += kx * kx;
-    }
-    f = wave_sum(f);
-    if (live && lane == 0) {
-        const double v = sqrt(f);
-        S[(size_t)i + (size_t)j * N] = v;
-        S[(size_t)j + (size_t)i * N] = v;
+    for (int t = wv; t < j_hi - j_lo; t += 4) {   // (wave-uniform trip count: the barriers below are per wave, not per workgroup)
+        const double *blk = img + t * sdim;       // element (r, c) of the pair's block: blk[r + c * Lp]
+        if (lane < sdim) {
+            double a = 0.0;
+            for (int c = 0; c < sdim; ++c) a += blk[lane + c * Lp];
+            rm[lane] = a / (double)sdim;
+        } else if (lane >= 32 && lane - 32 < sdim) {
+            const int c = lane - 32;
+            double a = 0.0;
+            for (int r = 0; r < sdim; ++r) a += blk[r + c * Lp];
+            cm[c] = a / (double)sdim;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double tot = 0.0;
+        for (int r = 0; r < sdim; ++r) tot += rm[r];
+        tot /= (double)sdim;  // = sum(block) / s^2
+        double f = 0.0;
+        for (int e = lane; e < ss; e += 64) {
+            const int r = e % sdim, c = e / sdim;
+            const double kx = blk[r + c * Lp] - rm[r] - cm[c] + tot;
+            f += kx * kx;
+        }
+        f = wave_sum(f);
+        if (lane == 0) {
+            const int j = j_lo + t;
+            const double v = sqrt(f);
+            S[(size_t)i + (size_t)j * N] = v;
+            S[(size_t)j + (size_t)i * N] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // rm / cm are rewritten by the wave's next pair
     }
 }
 
 void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S)
 {
     (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
-    const long long npairs = (long long)N * (N - 1) / 2;
-    if (npairs <= 0) return;
-    const size_t lds = (size_t)4 * (sdim * sdim + 64) * sizeof(double);
-    hipLaunchKernelGGL(k_fn, dim3((unsigned)((npairs + 3) / 4)), dim3(256), lds, s, A, ld, N, sdim, npairs, S);
+    if (N < 2) return;
+    const long long nJ = (N + FN_PG - 1) / FN_PG;   // row chunks; the last one is clipped to the N - 1 column sites that exist
+    const long long nwg = (long long)FN_PG * (nJ - 1) * (nJ - 2) / 2 + (long long)(FN_PG - 1) * (nJ - 1) + (N - 1);
+    const size_t lds = ((size_t)sdim * (FN_PG * sdim + 2) + 4 * 64) * sizeof(double);
+    hipLaunchKernelGGL(k_fn, dim3((unsigned)nwg), dim3(256), lds, s, A, ld, N, sdim, S);
 }
 
 // ---- Cholesky factors of the diagonal blocks of C ------------------------------------------------------
