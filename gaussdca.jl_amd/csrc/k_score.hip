@@ -38,41 +38,45 @@ __device__ __forceinline__ double wave_sum(double v)
 // padded so that a column walk hits different banks); then every wave scores its pairs from LDS.  The arithmetic of a pair --
 // row means, column means, their order of summation, the per-lane partial sums of the norm and the butterfly that adds them -- is
 // unchanged: scores are bit for bit those of the old kernel.
-#define FN_PG 8
+#define FN_PG 4
 
-// workgroup b <-> (row chunk J, column site i), i < min(N - 1, FN_PG (J + 1) - 1): chunk J has FN_PG J + FN_PG - 1 column sites
-// (every site left of its last row), but for the last chunk, which is clipped at N - 1
-__device__ __forceinline__ void fn_decode(long long b, int &J, int &i)
+// FN_MAXU: 16-byte loads per thread that hold a workgroup's image, ceil(s (FN_PG s / 2) / 256).  SDIM: s as a compile-time
+// constant (20 = the q = 21 alphabet: the loops over a block unroll, their LDS reads are issued back to back instead of one
+// round trip per addition) or 0 = run-time s.
+template <int FN_MAXU, int SDIM>
+__global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t ld, int N, int sdim_rt, double *__restrict__ S)
 {
-    // b = FN_PG J (J - 1) / 2 + (FN_PG - 1) J + i
-    int jj = (int)((sqrt((double)(FN_PG - 2) * (FN_PG - 2) / 4.0 + 2.0 * FN_PG * (double)b) - (FN_PG - 2) / 2.0) / FN_PG);
-    auto first = [](long long x) { return (long long)FN_PG * x * (x - 1) / 2 + (long long)(FN_PG - 1) * x; };
-    while (jj > 0 && first(jj) > b) --jj;
-    while (first(jj + 1) <= b) ++jj;
-    J = jj;
-    i = (int)(b - first(jj));
-}
-
-__global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t ld, int N, int sdim, double *__restrict__ S)
-{
+    const int sdim = SDIM ? SDIM : sdim_rt;
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ss = sdim * sdim;
-    int J, i;
-    fn_decode((long long)blockIdx.x, J, i);
+    // grid: x = row chunk counted from the column site's first one, y = column site -- consecutive workgroups walk DOWN the s
+    // columns of one site, so the reads in flight at any moment are s long sequential streams (with the column site running
+    // fastest they were thousands of 1280-byte pieces 8 ld bytes apart)
+    const int i = blockIdx.y, J = (i + 1) / FN_PG + (int)blockIdx.x;
+    if (J * FN_PG >= N) return;
     const int j_lo = max(J * FN_PG, i + 1), j_hi = min(N, J * FN_PG + FN_PG);
     const int L = (j_hi - j_lo) * sdim;          // rows of the run
     const int Lp = FN_PG * sdim + 2;             // row stride of the LDS image (even: 16-byte stores stay aligned)
     double *img = fsm;                           // img[c * Lp + (row of the run)]
     double *rm = fsm + (size_t)sdim * Lp + (size_t)wv * 64, *cm = rm + 32;
     const double *src = A + (size_t)j_lo * sdim + (size_t)i * sdim * ld;
-    if (((j_lo * sdim) & 1) == 0 && (L & 1) == 0) {
-        const int L2 = L >> 1;
-        for (int e = tid; e < sdim * L2; e += 256) {
+    if (((j_lo * sdim) & 1) == 0 && (L & 1) == 0 && sdim * (L >> 1) <= 256 * FN_MAXU) {
+        // every load of the thread is issued before the first one is stored: the workgroup's whole image is in flight at once
+        // (as a load / store loop each trip waited out its own load: 1-2 us apiece under load, seven trips at s = 20)
+        const int L2 = L >> 1, total = sdim * L2;
+        double2 v[FN_MAXU];
+        int off[FN_MAXU];
+#pragma unroll
+        for (int u = 0; u < FN_MAXU; ++u) {
+            const int e = min(tid + 256 * u, total - 1);  // (past the end: the last unit once more, loaded and not stored)
             const int c = e / L2, r2 = e - c * L2;
-            const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)c * ld + 2 * r2);
-            *reinterpret_cast<double2 *>(img + c * Lp + 2 * r2) = v;
+            off[u] = c * Lp + 2 * r2;
+            v[u] = *reinterpret_cast<const double2 *>(src + (size_t)c * ld + 2 * r2);
         }
+#pragma unroll
+        for (int u = 0; u < FN_MAXU; ++u)
+            if (tid + 256 * u < total) *reinterpret_cast<double2 *>(img + off[u]) = v[u];
     } else {
         for (int e = tid; e < sdim * L; e += 256) {
             const int c = e / L, r = e - c * L;
@@ -80,28 +84,42 @@ __global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t
         }
     }
     __syncthreads();
+    // The scoring of a pair is bound by instruction issue, not by LDS or HBM (one wave per pair; ~2700 clocks a pair as first
+    // written): no integer division in the loops (a lane's (r, c) advances by 64 elements at a time), row means and column means
+    // in ONE loop (lanes 0.. take rows, lanes 32.. columns: the same sums in the same order).
+    const int r_step = 64 % sdim, c_step = 64 / sdim;
+    const int r0 = lane % sdim, c0 = lane / sdim;
+    const bool is_row = lane < 32;
+    const int mlane = is_row ? lane : lane - 32;
     for (int t = wv; t < j_hi - j_lo; t += 4) {   // (wave-uniform trip count: the barriers below are per wave, not per workgroup)
         const double *blk = img + t * sdim;       // element (r, c) of the pair's block: blk[r + c * Lp]
-        if (lane < sdim) {
+        if (mlane < sdim) {
+            // rows: sum over c of blk[lane + c Lp];  columns: sum over r of blk[r + c Lp]
+            const double *q = blk + (is_row ? mlane : mlane * Lp);
+            const int step = is_row ? Lp : 1;
             double a = 0.0;
-            for (int c = 0; c < sdim; ++c) a += blk[lane + c * Lp];
-            rm[lane] = a / (double)sdim;
-        } else if (lane >= 32 && lane - 32 < sdim) {
-            const int c = lane - 32;
-            double a = 0.0;
-            for (int r = 0; r < sdim; ++r) a += blk[r + c * Lp];
-            cm[c] = a / (double)sdim;
+#pragma unroll
+            for (int k = 0; k < sdim; ++k) a += q[k * step];
+            (is_row ? rm : cm)[mlane] = a / (double)sdim;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         double tot = 0.0;
+#pragma unroll
         for (int r = 0; r < sdim; ++r) tot += rm[r];
         tot /= (double)sdim;  // = sum(block) / s^2
         double f = 0.0;
+        int r = r0, c = c0;
+#pragma unroll
         for (int e = lane; e < ss; e += 64) {
-            const int r = e % sdim, c = e / sdim;
             const double kx = blk[r + c * Lp] - rm[r] - cm[c] + tot;
             f += kx * kx;
+            r += r_step;
+            c += c_step;
+            if (r >= sdim) {
+                r -= sdim;
+                ++c;
+            }
         }
         f = wave_sum(f);
         if (lane == 0) {
@@ -119,10 +137,19 @@ void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, 
 {
     (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
     if (N < 2) return;
-    const long long nJ = (N + FN_PG - 1) / FN_PG;   // row chunks; the last one is clipped to the N - 1 column sites that exist
-    const long long nwg = (long long)FN_PG * (nJ - 1) * (nJ - 2) / 2 + (long long)(FN_PG - 1) * (nJ - 1) + (N - 1);
+    const int nJ = (N + FN_PG - 1) / FN_PG;   // row chunks (a column site's workgroups past its last chunk leave at once)
+    const dim3 nwg((unsigned)nJ, (unsigned)(N - 1));
     const size_t lds = ((size_t)sdim * (FN_PG * sdim + 2) + 4 * 64) * sizeof(double);
-    hipLaunchKernelGGL(k_fn, dim3((unsigned)nwg), dim3(256), lds, s, A, ld, N, sdim, S);
+    const int units = (sdim * (FN_PG * sdim / 2) + 255) / 256;   // s = 20: 7
+    constexpr int units20 = (20 * (FN_PG * 20 / 2) + 255) / 256;
+    if (sdim == 20)
+        hipLaunchKernelGGL((k_fn<units20, 20>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+    else if (units <= 4)
+        hipLaunchKernelGGL((k_fn<4, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+    else if (units <= 7)
+        hipLaunchKernelGGL((k_fn<7, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+    else
+        hipLaunchKernelGGL((k_fn<16, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
 }
 
 // ---- Cholesky factors of the diagonal blocks of C ------------------------------------------------------
