@@ -449,12 +449,12 @@ def main():
             out["end_to_end_gdca_sec"] = end_to_end(meas["Zh"][0], q, args.score, meas["pc"], meas["ctxs"][0])
         release(meas)
         # every other single-GPU configuration of BASELINE.json in the same run: :DI at the headline size, B
-        # (alone and four at a time through the merged sweep), D and a 32-family prefix of the batch E
+        # (alone and eight at a time through the merged sweep), D and a 32-family prefix of the batch E
         if world == 1 and args.config == "C" and args.score == "frob" and not args.no_other_configs and not (args.N or args.M):
             others = {}
             plan = (("C_DI", "C", "DI", 20, 3, 1, False, 256), ("B", "B", "frob", 40, 5, 1, False, 256),
-                    ("B_merged4", "B", "frob", 40, 5, 4, True, 256), ("D", "D", "frob", 5, 1, 1, False, 256),
-                    ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_phased4", "E", "frob", 2, 1, 4, True, 32))
+                    ("B_merged8", "B", "frob", 80, 8, 8, True, 256), ("D", "D", "frob", 5, 1, 1, False, 256),
+                    ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_phased8", "E", "frob", 2, 1, 8, True, 32))
             for key, cname, sc, st_, wu, P_, ph_, nf in plan:
                 try:
                     a2 = argparse.Namespace(**vars(args))

@@ -96,7 +96,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"REM_TAIL", &t->rem_tail, -1, 1 << 20}, {"PANEL_HALVES", &t->panel_halves, -1, 1}, {"SLAB", &t->slab, 0, 1},
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
-        {"MERGE_MCUS", &t->merge_mcus, -1, 16},
+        {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -124,13 +124,15 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->ring = 8;
     t->mcus = -1;
     t->hamming_mode = -1;
-    t->merge = 4;
-    t->merge_blocks = 48;
+    t->merge = 8;
+    t->merge_blocks = 57;
     t->merge_mcus = -1;
+    t->merge_group = -1;
+    t->merge_tiles = 2300;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_SWEEP_TRACE"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_SWEEP_TRACE"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -705,11 +707,12 @@ static gdca_status run_inverse(gdca_ctx *ctx)
 // The inverses of K members of a phase batch as ONE merged launch on the batch's stream (k_sweep_merged: small matrices, which
 // leave most of the chip idle when they run alone).  Every member keeps its own workspace, flags and scalars; the events around
 // the launch are the first member's.
-static gdca_status run_inverse_merged(gdca_ctx *const *mem, int K)
+static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int K)
 {
     gdca_ctx *ctx = mem[0];
     hipStream_t s = ctx->stream;
     gdca_inverse_job jobs[8];
+    gdca_tuning tun[8];  // a member's schedule switches are its own context's, the switches of the merged launch the leader's
     double flops[8];
     if (K > gdca_inverse_max_merge() || K > 8) return fail(ctx, GDCA_EINVAL, "too many members in a merged inverse%s%s", "", "");
     bool timed = true;
@@ -720,7 +723,11 @@ static gdca_status run_inverse_merged(gdca_ctx *const *mem, int K)
     for (int k = 0; k < K; ++k) {
         if (mem[k]->pend_timed) HIPCHK(hipEventRecord(mem[k]->ev[6], s));
         CHK(inverse_job(mem[k], mem[k]->pend_n, mem[k]->pend_npad, &jobs[k]));
-        if (ctx->tune.sweep_debug & 16) CHK(poison_inverse_ws(mem[k], s));
+        tun[k] = mem[k]->tune;
+        tun[k].merge_group = lead->tune.merge_group;
+        tun[k].merge_mcus = lead->tune.merge_mcus;
+        jobs[k].tune = &tun[k];
+        if (lead->tune.sweep_debug & 16) CHK(poison_inverse_ws(mem[k], s));
     }
     hipEvent_t *uev = nullptr;
     if (timed) {
@@ -776,13 +783,31 @@ static gdca_status run_inverses(gdca_ctx *lead, gdca_ctx *const *ctxs, int K)
         else
             st = run_inverse(ctxs[k]);
     }
-    // (groups of equal size rather than full ones and a remainder: 5 members at merge = 4 go 3 + 2)
-    const int n_grp = n_small ? (n_small + merge - 1) / merge : 0;
-    for (int gi = 0, at = 0; gi < n_grp && st == GDCA_OK; ++gi) {
-        const int cnt = n_small / n_grp + (gi < n_small % n_grp ? 1 : 0);
+    // A launch is closed when it holds `merge` members or its members together offer MERGE_TILES tile items per update step
+    // (sum of nblk^2 / 2: enough work beside a member's chain -- ~250 us per group of four blocks against ~0.2 us per tile item
+    // on the whole chip; 20-block matrices go eight to a launch, 47-block ones two).  A lone last member joins the launch
+    // before it.
+    int start[65], n_grp = 0;
+    {
+        long long tiles = 0;
+        int cnt = 0;
+        for (int k = 0; k < n_small; ++k) {
+            if (cnt == 0) start[n_grp++] = k;
+            const long long nb = small[k]->pend_npad / GDCA_TILE;
+            tiles += nb * nb / 2;
+            ++cnt;
+            if (cnt == merge || tiles >= lead->tune.merge_tiles) {
+                cnt = 0;
+                tiles = 0;
+            }
+        }
+        start[n_grp] = n_small;
+        if (n_grp >= 2 && start[n_grp] - start[n_grp - 1] == 1 && start[n_grp - 1] - start[n_grp - 2] < merge) start[--n_grp] = n_small;
+    }
+    for (int gi = 0; gi < n_grp && st == GDCA_OK; ++gi) {
+        const int at = start[gi], cnt = start[gi + 1] - at;
         // (option SWEEP_DEBUG bit 3, tests: the merged kernel for a single member too)
-        st = (cnt == 1 && !(lead->tune.sweep_debug & 8)) ? run_inverse(small[at]) : run_inverse_merged(small + at, cnt);
-        at += cnt;
+        st = (cnt == 1 && !(lead->tune.sweep_debug & 8)) ? run_inverse(small[at]) : run_inverse_merged(lead, small + at, cnt);
     }
     return st;
 }

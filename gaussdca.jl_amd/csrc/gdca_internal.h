@@ -44,6 +44,8 @@ struct gdca_tuning {
     int merge;              // GDCA_MERGE: families one merged sweep launch may carry in gdca_run_dev_phased (1 = never merge)
     int merge_blocks;       // GDCA_MERGE_BLOCKS: largest member of a merged launch, in 128-blocks
     int merge_mcus;         // GDCA_MERGE_MCUS: chain compute units per member of a merged launch
+    int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
+    int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
     char sweep_trace[256];  // GDCA_SWEEP_TRACE: file the in-kernel trace of the next inverse is written to ("" = off)
 };
 void gdca_tuning_from_env(gdca_tuning *t);

@@ -2084,13 +2084,17 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
 //     items): the families advance side by side, and a workgroup parked on an item of family A that waits for A's chain keeps
 //     nothing of family B from running.
 // Items of one family are still handed out in that family's list order, so the no-deadlock argument of k_sweep holds family by
-// family.  Members are single-block schedules (MULTI = false): the chain-bound sizes, which are the ones that leave the chip idle.
+// family.  With the chains of K families side by side a member's chain no longer sets the pace -- it has the other members' tile
+// items to hide behind -- so a member of a merged launch takes the multi-block groups (tile items of depth K = 256 .. 512: a half
+// to a quarter of the C-tile traffic per flop) that pay only from 49 .. 58 blocks on when it runs alone (plan_sweep).  MULTI:
+// some member has multi-block groups.
 #define SWEEP_MAX_MERGE 8
 struct SweepBatch {
     SweepDesc fam[SWEEP_MAX_MERGE];
     int K;
 };
 
+template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
 {
     __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
@@ -2176,7 +2180,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
                 continue;
             }
             e -= 2 * sz;
-            sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
+            if (MULTI && sz > 1)
+                sweep_tile_item<true>(D, q, c0 + rr, c0 + e, Gs, Hs);
+            else
+                sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
         }
     }
     // ---- the main lists, the families in turn ----
@@ -2233,14 +2240,19 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
             const NextTake nt{nxt, &s_next, &s_ready, &B.fam[fn], pn, fn, &s_fam};
             if (D.rl < T && it.a == D.nblk - 1)
                 sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
+            else if (MULTI && g_size(D, it.p) > 1)
+                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
             else
                 sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt,
                                        D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
             continue;
         }
-        if (it.kind == 0)
-            sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
-        else if (it.kind == 2)
+        if (it.kind == 0) {
+            if (MULTI && D.ppb == 1)
+                sweep_panel_item<4>(D, it.p, it.a, it.b, Gs, Hs);
+            else
+                sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
+        } else if (it.kind == 2)
             sweep_wb_item(D, it.p, it.a, Gs);
         if (threadIdx.x == 0) {
             s_next = nxt;
@@ -2301,7 +2313,10 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     // N x g x chain CUs): g = 1 is fastest up to 48 blocks (beyond, its K = 128 updates are bound by the traffic of the C tiles, not
     // by the chain), 2 to 54, 3 to 57, 4 from 58 on (with the super-block inverse as row-slab jobs; as half-tile jobs its chain hid only
     // from 71 blocks).
-    int g = merged ? 1 : (tu.group >= 1 ? std::min(tu.group, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1))));
+    // A member of a merged launch: its chain hides behind the other members' tile items, so what counts is the traffic of the C
+    // tiles -- groups of four from 24 blocks, of two from 12 (option GDCA_MERGE_GROUP forces a size).
+    const int g_merged = tu.merge_group >= 1 ? std::min(tu.merge_group, 4) : (nblk >= 24 ? 4 : (nblk >= 12 ? 2 : 1));
+    int g = merged ? g_merged : (tu.group >= 1 ? std::min(tu.group, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1))));
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens
@@ -2342,7 +2357,7 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     const int rem_tail = tu.rem_tail >= 0 ? tu.rem_tail : (g >= 3 ? 2 * ws.update_cus : 0);
     // main-list panel items: one 128 x 128 item per pivot block and row where the panels are throughput (multi-block groups of
     // three and four), two 128 x 64 halves where their latency counts
-    const int ppb = merged ? 2 : (tu.panel_halves >= 0 ? (tu.panel_halves ? 2 : 1) : (g >= 3 ? 1 : 2));
+    const int ppb = tu.panel_halves >= 0 ? (tu.panel_halves ? 2 : 1) : (g >= 3 ? 1 : 2);
     // single-block groups: the chain between two pivots as fused row-slab items (sweep_slab_item; GDCA_SLAB=0: panel and tile items)
     bool slab = tu.slab != 0;
     bool single = true;
@@ -2431,8 +2446,8 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     // with 6, 16.85 with 12, 20.8 with 4), 4 up to 120, 2 beyond (n = 20 000: 123.1 ms with 2, 123.75 with 4); between single blocks (a pivot and three times eight slab items per step) 12
     // CUs below 28 blocks, 8 above
     const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 63 ? 16 : (nblk <= 68 ? 12 : (nblk <= 74 ? 10 : (nblk <= 90 ? 6 : (nblk <= 120 ? 4 : 2)))));
-    // a member of a merged launch: its own rule unless that would hand more than a quarter of the chip to the chains
-    const int mcu_merged = tu.merge_mcus >= 1 ? tu.merge_mcus : std::min(mcu_rule, std::max(2, ws.update_cus / (4 * std::max(1, members))));
+    // a member of a merged launch: its own rule unless that would hand more than an eighth of the chip to the chains
+    const int mcu_merged = tu.merge_mcus >= 1 ? tu.merge_mcus : std::min(mcu_rule, std::max(2, ws.update_cus / (8 * std::max(1, members))));
     D.n_mcu = merged ? std::min(mcu_merged, 16) : (tu.mcus >= 1 ? std::min(tu.mcus, 16) : mcu_rule);
     D.n_real = n_real;
     D.rl = rl;
@@ -2489,16 +2504,21 @@ void gdca_launch_spd_inverse_merged(hipStream_t s0, const gdca_inverse_job *jobs
     SweepBatch B{};
     B.K = K;
     int cus = 0;
+    bool multi = false;
     for (int k = 0; k < K; ++k) {
         SweepPlan P = plan_sweep(s0, jobs[k], true, K);
         B.fam[k] = P.D;
+        multi = multi || P.g > 1;
         if (upd_flops) upd_flops[k] = 2.0 * T * T * KC * P.chunks;
         cus = std::max(cus, jobs[k].ws.update_cus);
     }
     const unsigned grid = (unsigned)(2 * cus);
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
-    hipLaunchKernelGGL(k_sweep_merged, dim3(grid), dim3(256), 0, s0, B);
+    if (multi)
+        hipLaunchKernelGGL(k_sweep_merged<true>, dim3(grid), dim3(256), 0, s0, B);
+    else
+        hipLaunchKernelGGL(k_sweep_merged<false>, dim3(grid), dim3(256), 0, s0, B);
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
 }
 

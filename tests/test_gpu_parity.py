@@ -324,6 +324,7 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
             ref_st.append(ctx.run_dev(zd.data_ptr(), z.shape[1], z.shape[0], 21, pc, -1.0, score, S.data_ptr()))
             ref.append(S.cpu())
         cs = [g.Context(0) for _ in fams]
+        first = []
         for rep in range(2):
             outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
             g.run_dev_phased(cs, [zd.data_ptr() for zd in Zd], [z.shape[1] for z in fams], [z.shape[0] for z in fams],
@@ -334,11 +335,30 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
             for k in reversed(range(len(cs))):
                 sts[k] = cs[k].collect()
             for k in range(len(cs)):
-                assert torch.equal(outs[k].cpu(), ref[k]), (score, rep, k)
+                # (a member of a merged launch sweeps in larger pivot groups than a launch of its own would at that size: the same
+                # inverse to rounding -- the scores agree to ~1e-13 --, and bit for bit from one batch to the next)
+                if sizes[k][0] * 20 > 57 * 128:
+                    assert torch.equal(outs[k].cpu(), ref[k]), (score, rep, k)
+                else:
+                    assert torch.allclose(outs[k].cpu(), ref[k], rtol=1e-10, atol=1e-12 * float(ref[k].abs().max())), (score, rep, k)
+                if rep == 0:
+                    first = first + [outs[k].cpu()] if k else [outs[k].cpu()]
+                else:
+                    assert torch.equal(outs[k].cpu(), first[k]), (score, rep, k)
                 assert sts[k]["Meff"] == ref_st[k]["Meff"] and sts[k]["thresh"] == ref_st[k]["thresh"] and sts[k]["info"] == 0
                 assert sts[k]["ms_inverse"] > 0 and sts[k]["sweep_ghz"] > 1.0
             # the four small members shared ONE merged sweep launch (its first member accounts for it), N = 430 had its own
             assert [st_["inverse_batch"] for st_ in sts] == [4, 4, 4, 1, 4] and sum(st_["update_launches"] for st_ in sts) == 2
+        # MERGE_GROUP=1 (single-block groups in merged launches too): bit for bit the launches of their own, for members up to 48 blocks
+        cs[0].set_options(MERGE_GROUP=1)
+        outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
+        g.run_dev_phased(cs, [zd.data_ptr() for zd in Zd], [z.shape[1] for z in fams], [z.shape[0] for z in fams],
+                         [21] * len(fams), pc, -1.0, score, [x.data_ptr() for x in outs])
+        for c in cs:
+            c.collect()
+        for k in range(len(cs)):
+            assert torch.equal(outs[k].cpu(), ref[k]), (score, "group 1", k)
+        cs[0].set_options(MERGE_GROUP=-1)
         with pytest.raises(g.ArgumentError):
             g.run_dev_phased([cs[0], cs[0]], [Zd[0].data_ptr()] * 2, [40] * 2, [500] * 2, [21] * 2, pc, -1.0, score,
                              [outs[0].data_ptr()] * 2)               # the same context twice
@@ -498,26 +518,32 @@ def test_merged_inverses_equal_single_launches(g, ctx):
             As = [mat(n) for n in ns]
             ref = []
             for A in As:
+                # (the reference: a launch of its own swept in the pivot groups a merged member of that size takes)
+                nb = (A.shape[0] + 127) // 128
+                ctx.set_option("GROUP", 4 if nb >= 24 else (2 if nb >= 12 else 1))
                 d = torch.from_numpy(A).cuda()
                 info = g._lib.C.c_int32()
                 ctx.check(ctx.lib.gdca_spd_inverse_dev(ctx.h, g._lib.C.c_void_p(d.data_ptr()), A.shape[0], g._lib.C.byref(info)))
                 ref.append(d.cpu().numpy())
                 V = rng.standard_normal((A.shape[0], 2))
                 assert np.max(np.abs(A @ (ref[-1] @ V) - V)) < 1e-9
+            ctx.set_option("GROUP", -1)
             for merge, extra in ((8, {}), (4, {"MERGE_MCUS": 2}), (2, {"SLAB": rnd % 2}), (3, {"RING": 2 + rnd % 5})):
                 K = len(ns)
                 if extra.get("SLAB", 1) == 0:   # another schedule, another summation order: its own single launches are the reference
                     ctx.set_option("SLAB", 0)
                     ref_here = []
                     for A in As:
+                        nb = (A.shape[0] + 127) // 128
+                        ctx.set_option("GROUP", 4 if nb >= 24 else (2 if nb >= 12 else 1))
                         d = torch.from_numpy(A).cuda()
                         info = g._lib.C.c_int32()
                         ctx.check(ctx.lib.gdca_spd_inverse_dev(ctx.h, g._lib.C.c_void_p(d.data_ptr()), A.shape[0], g._lib.C.byref(info)))
                         ref_here.append(d.cpu().numpy())
-                    ctx.set_option("SLAB", 1)
+                    ctx.set_options(SLAB=1, GROUP=-1)
                 else:
                     ref_here = ref
-                cs[0].set_options(MERGE=merge, MERGE_BLOCKS=48, SWEEP_DEBUG=24, MERGE_MCUS=-1, SLAB=1, RING=8)
+                cs[0].set_options(MERGE=merge, MERGE_BLOCKS=48, MERGE_TILES=1 << 20, SWEEP_DEBUG=24, MERGE_MCUS=-1, SLAB=1, RING=8)
                 cs[0].set_options(**extra)
                 for c in cs[1:K]:   # (a member's schedule switches are its own context's)
                     c.set_options(SLAB=extra.get("SLAB", 1), RING=extra.get("RING", 8))

@@ -21,7 +21,9 @@ ap.add_argument("--ks", nargs="*", type=int, default=[1, 2, 4, 8])
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--theta", type=float, default=0.2)
 ap.add_argument("--mcus", type=int, default=-1, help="MERGE_MCUS: chain compute units per member")
-ap.add_argument("--blocks", type=int, default=48, help="MERGE_BLOCKS")
+ap.add_argument("--blocks", type=int, default=64, help="MERGE_BLOCKS")
+ap.add_argument("--group", type=int, default=-1, help="MERGE_GROUP: pivot blocks per group of a merged member (-1: the rule)")
+ap.add_argument("--tiles", type=int, default=1 << 20, help="MERGE_TILES (default: no limit, K members per launch)")
 args = ap.parse_args()
 sizes = [tuple(int(x) for x in s.split(":")) for s in args.sizes]
 KMAX = max(args.ks)
@@ -45,9 +47,10 @@ cs2 = [g.Context(0) for _ in range(KMAX)]
 outs = [torch.empty((f[0], f[0]), dtype=torch.float64, device="cuda") for f in fams]
 outs2 = [torch.empty((f[0], f[0]), dtype=torch.float64, device="cuda") for f in fams]
 ok = True
+worst_dev = 0.0
 for K in args.ks:
     for lead in (cs[0], cs2[0]):
-        lead.set_options(MERGE=K, MERGE_BLOCKS=args.blocks, MERGE_MCUS=args.mcus)
+        lead.set_options(MERGE=K, MERGE_BLOCKS=args.blocks, MERGE_MCUS=args.mcus, MERGE_GROUP=args.group, MERGE_TILES=args.tiles)
     f = fams[:K]
 
     def enqueue(cset, oset):
@@ -65,9 +68,11 @@ for K in args.ks:
         wall.append((time.perf_counter() - t0) * 1e3)
         inv.append(sum(s["ms_inverse_update"] for s in st))
         for k in range(K):
-            if not torch.equal(outs[k].cpu(), ref[f[k]]):
+            dev = float(((outs[k].cpu() - ref[f[k]]).abs().max() / ref[f[k]].abs().max()))
+            worst_dev = max(worst_dev, dev)
+            if not dev < 1e-9:
                 ok = False
-                print("  MISMATCH K=%d member %d (N=%d): max abs dev %.3e" % (K, k, f[k][0], float((outs[k].cpu() - ref[f[k]]).abs().max())))
+                print("  MISMATCH K=%d member %d (N=%d): max rel dev %.3e" % (K, k, f[k][0], dev))
     # throughput form: two context sets alternate, the next batch is enqueued before the previous one is collected
     torch.cuda.synchronize()
     nb = 12
@@ -84,5 +89,5 @@ for K in args.ks:
     print("K=%d: batch %s  merged launch %.3f ms = %.3f ms per family (best %.3f); batch wall %.3f ms; pipelined %.3f ms per family "
           "(batch sizes %s)" % (K, [s["inverse_batch"] for s in st], float(np.mean(inv[1:])), float(np.mean(inv[1:])) / K, min(inv) / K,
                                 float(np.mean(wall[1:])), dt / (nb * K), [x[0] for x in f]), flush=True)
-print("bit-identical to single runs: %s" % ok)
+print("scores equal to single runs (worst relative deviation %.2e; 0 = bit-identical): %s" % (worst_dev, ok))
 sys.exit(0 if ok else 1)
