@@ -231,6 +231,15 @@ class Context:
         self.check(rc, st.info)
         return S, st.as_dict()
 
+    def run_ptr(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int, apc: bool = True):
+        """gdca_run on a HOST matrix given by address (N x M int8, column-major: e.g. gdca_fasta_data).  Returns (S, stats)."""
+        S = np.empty((N, N), dtype=np.float64)
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        st = Stats()
+        rc = self.lib.gdca_run(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), _p(S), C.byref(st))
+        self.check(rc, st.info)
+        return S, st.as_dict()
+
     def run_dev(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int,
                 S_ptr: int, apc: bool = True):
         """Device-pointer form (Z and S resident in HBM).  Returns the stats dict."""

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <string_view>
@@ -27,54 +28,80 @@
 
 #include "gdca.h"
 
-// a byte buffer that is NOT zero-filled when it grows (the reader overwrites every byte it keeps; zero-filling 50 MB per
-// family is a serial 10 ms the batch driver's parser threads can do without)
-// Big buffers come 2 MiB-aligned with a transparent-huge-page hint: a fresh 50 MB matrix is 25 page faults instead of
-// 12 000, which is what the batch driver's parser threads were queueing up on in the kernel.
-template <class Tp>
-struct default_init_alloc {
-    using value_type = Tp;
-    template <class U>
-    struct rebind {
-        using other = default_init_alloc<U>;
-    };
-    default_init_alloc() = default;
-    template <class U>
-    default_init_alloc(const default_init_alloc<U> &) noexcept {}
-    Tp *allocate(size_t n)
+// The parsed matrix lives in a buffer that is NOT zero-filled (the reader overwrites every byte it keeps; zero-filling 50 MB per
+// family is a serial 10 ms) and that is REUSED: gdca_fasta_close hands it to a small process-wide pool, the next gdca_fasta_open
+// takes one that is large enough.  A batch driver parses hundreds of families on dozens of threads; as malloc / free of 2 MiB-
+// aligned, huge-page-hinted blocks every matrix was an mmap + thousands of page faults + an munmap, all serialised on the
+// process's memory-map lock -- that lock, not parsing, was what the parser threads queued on (profiles/r03_parse_bench.log:
+// slower at 64 threads than at 32).  The pool holds at most POOL_SLOTS buffers and POOL_BYTES bytes; what does not fit is freed.
+namespace {
+struct MatBuf {
+    int8_t *p = nullptr;
+    size_t cap = 0;
+};
+constexpr size_t POOL_SLOTS = 96, POOL_BYTES = (size_t)6 << 30;
+std::mutex g_pool_mu;
+struct Pool : std::vector<MatBuf> {
+    ~Pool()  // process exit: the pooled buffers go back (nothing is left for a leak checker to find)
     {
-        const size_t bytes = n * sizeof(Tp);
-        if (bytes >= ((size_t)4 << 20)) {
-            void *q = nullptr;
-            const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-            if (posix_memalign(&q, (size_t)2 << 20, len) != 0) throw std::bad_alloc();
-            (void)madvise(q, len, MADV_HUGEPAGE);
-            return static_cast<Tp *>(q);
-        }
-        void *q = malloc(bytes ? bytes : 1);
-        if (!q) throw std::bad_alloc();
-        return static_cast<Tp *>(q);
-    }
-    void deallocate(Tp *q, size_t) noexcept { free(q); }
-    template <class U>
-    bool operator==(const default_init_alloc<U> &) const noexcept { return true; }
-    template <class U>
-    bool operator!=(const default_init_alloc<U> &) const noexcept { return false; }
-    template <class U>
-    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
-    {
-        ::new (static_cast<void *>(p)) U;
-    }
-    template <class U, class... Args>
-    void construct(U *p, Args &&...args)
-    {
-        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+        for (MatBuf &b : *this) free(b.p);
     }
 };
+Pool g_pool;
+size_t g_pool_bytes = 0;
+
+MatBuf matbuf_get(size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        // best fit among the pooled buffers that are large enough (and not absurdly larger: a 100 MB buffer is not spent on 1 MB)
+        size_t best = g_pool.size();
+        for (size_t k = 0; k < g_pool.size(); ++k)
+            if (g_pool[k].cap >= bytes && g_pool[k].cap <= 8 * bytes + ((size_t)4 << 20) && (best == g_pool.size() || g_pool[k].cap < g_pool[best].cap))
+                best = k;
+        if (best != g_pool.size()) {
+            MatBuf b = g_pool[best];
+            g_pool[best] = g_pool.back();
+            g_pool.pop_back();
+            g_pool_bytes -= b.cap;
+            return b;
+        }
+    }
+    MatBuf b;
+    if (bytes >= ((size_t)4 << 20)) {
+        const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *q = nullptr;
+        if (posix_memalign(&q, (size_t)2 << 20, len) != 0) return b;
+        (void)madvise(q, len, MADV_HUGEPAGE);
+        b.p = static_cast<int8_t *>(q);
+        b.cap = len;
+    } else {
+        b.p = static_cast<int8_t *>(malloc(bytes));
+        b.cap = b.p ? bytes : 0;
+    }
+    return b;
+}
+
+void matbuf_put(MatBuf b)
+{
+    if (!b.p) return;
+    if (b.cap >= ((size_t)1 << 20)) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < POOL_SLOTS && g_pool_bytes + b.cap <= POOL_BYTES) {
+            g_pool.push_back(b);
+            g_pool_bytes += b.cap;
+            return;
+        }
+    }
+    free(b.p);
+}
+}  // namespace
 
 struct gdca_fasta {
     int32_t N = 0, M = 0, qmax = 0;
-    std::vector<int8_t, default_init_alloc<int8_t>> Z;  // [M][N]
+    MatBuf Z;  // [M][N]
+    ~gdca_fasta() { matbuf_put(Z); }
 };
 
 namespace {
@@ -144,10 +171,32 @@ bool slurp(const char *path, FileText &out)
     const size_t fsz = (size_t)sb.st_size;
     unsigned char magic[2] = {0, 0};
     const bool gz = fsz >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    std::string &buf = inflate_buffer();
+    // the thread's buffer is kept between files, but not a huge one for ever: beyond 256 MiB and four times what this file needs
+    // it goes back to the system (a batch with a few giant families would otherwise pin ~1 GiB per parser thread)
+    const size_t need_guess = gz ? 8 * fsz : fsz;
+    if (buf.capacity() > ((size_t)256 << 20) && buf.capacity() > 4 * need_guess) std::string().swap(buf);
     if (!gz) {
         if (fsz == 0) {
             close(fd);
             out.text = std::string_view();
+            return true;
+        }
+        if (fasta_threads() == 1) {
+            // one reader thread per file = a batch driver parsing many files at once: read() into the thread's own buffer (mapped
+            // and faulted in once) instead of mapping every file -- an mmap / fault / munmap cycle per file takes the process's
+            // memory-map lock three times, and with dozens of parser threads that lock was the bottleneck.  A file that shrinks
+            // under the reader is a short read (GDCA_EINVAL), not a SIGBUS.
+            if (buf.size() < fsz) buf.resize(fsz);
+            size_t len = 0;
+            while (len < fsz) {
+                const ssize_t n = pread(fd, &buf[len], fsz - len, (off_t)len);
+                if (n <= 0) break;
+                len += (size_t)n;
+            }
+            close(fd);
+            if (len != fsz) return false;
+            out.text = std::string_view(buf.data(), len);
             return true;
         }
         void *m = mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -159,16 +208,17 @@ bool slurp(const char *path, FileText &out)
         out.text = std::string_view((const char *)m, fsz);
         return true;
     }
-    // gzip: the trailer's ISIZE (uncompressed size mod 2^32) sizes the buffer up front
+    // gzip: the trailer's ISIZE (uncompressed size mod 2^32) sizes the buffer up front -- as a HINT from an untrusted file: never
+    // more than 64 times the compressed size (FASTA text deflates 3-10x; a crafted trailer must not make every parser thread
+    // allocate 4 GiB), the buffer grows by doubling if the file really holds more
     size_t hint = 0;
     unsigned char t[4];
     if (fsz >= 4 && pread(fd, t, 4, (off_t)fsz - 4) == 4) hint = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    hint = std::min(hint, 64 * fsz + ((size_t)1 << 16));
     close(fd);
     gzFile f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
-    std::string &buf = inflate_buffer();
-    if (buf.capacity() > ((size_t)1 << 30) && hint < ((size_t)1 << 28)) std::string().swap(buf);  // do not sit on a huge one
     if (buf.size() < std::max<size_t>(hint, 1 << 16)) buf.resize(std::max<size_t>(hint, 1 << 16));
     size_t len = 0;
     for (;;) {
@@ -247,7 +297,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     if (!path || !out || !N || !M) return GDCA_EINVAL;
     *out = nullptr;
     // GDCA_FASTA_TRACE=1: per-file phase times on stderr (debug aid for the feed-rate benchmark, tools/parse_bench.sh)
-    static const bool trace = getenv("GDCA_FASTA_TRACE") != nullptr;
+    const bool trace = getenv("GDCA_FASTA_TRACE") != nullptr;
     auto tick = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_open = trace ? tick() : 0.0;
     FileText file;
@@ -299,7 +349,11 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     gdca_fasta *h = new (std::nothrow) gdca_fasta();
     if (!h) return GDCA_ENOMEM;
     h->N = n;
-    h->Z.resize((size_t)n * R);
+    h->Z = matbuf_get((size_t)n * R);
+    if (!h->Z.p) {
+        delete h;
+        return GDCA_ENOMEM;
+    }
     std::vector<uint8_t> keep(R, 0);
     std::vector<int> qmax_t((size_t)T, 0);  // largest symbol among the rows each thread keeps
     std::atomic<bool> misaligned{false};
@@ -314,7 +368,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
                 misaligned = true;  // "inputs are not aligned"
                 return;
             }
-            int8_t *row = h->Z.data() + r * (size_t)n;
+            int8_t *row = h->Z.p + r * (size_t)n;
             if (all_match) {
                 // one pass over the record: letter map, gap count, and "inconsistent inputs" = any insert character
                 unsigned ins = 0;
@@ -377,14 +431,13 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     size_t m = 0;
     for (size_t r = 0; r < R; ++r)
         if (keep[r]) {
-            if (m != r) memcpy(h->Z.data() + m * (size_t)n, h->Z.data() + r * (size_t)n, (size_t)n);
+            if (m != r) memcpy(h->Z.p + m * (size_t)n, h->Z.p + r * (size_t)n, (size_t)n);
             ++m;
         }
     h->M = (int32_t)m;
     for (int v : qmax_t) h->qmax = std::max(h->qmax, (int32_t)v);
     if (trace)
         fprintf(stderr, "fasta-trace %s bytes %zu threads %d read/inflate %.2f ms parse %.2f ms\n", path, L, T, t_read - t_open, tick() - t_read);
-    h->Z.resize(m * (size_t)n);
     *out = h;
     *N = h->N;
     *M = h->M;
@@ -394,13 +447,13 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
 gdca_status gdca_fasta_copy(const gdca_fasta *h, int8_t *Z)
 {
     if (!h || !Z) return GDCA_EINVAL;
-    if (!h->Z.empty()) memcpy(Z, h->Z.data(), h->Z.size());
+    if (h->M > 0) memcpy(Z, h->Z.p, (size_t)h->M * (size_t)h->N);
     return GDCA_OK;
 }
 
 const int8_t *gdca_fasta_data(const gdca_fasta *h)
 {
-    return h ? h->Z.data() : nullptr;
+    return h ? h->Z.p : nullptr;
 }
 
 int32_t gdca_fasta_max_symbol(const gdca_fasta *h)

@@ -65,6 +65,40 @@ def read_fasta_alignment(filename: str, max_gap_fraction: float) -> np.ndarray:
     return Z
 
 
+class FastaAlignment:
+    """A parsed alignment kept where the native reader put it (gdca_fasta_open): `.ptr` = the N x M int8 matrix
+    (gdca_fasta_data), `.N`, `.M`, `.q` = maximum(Z) (gdca_fasta_max_symbol).  A context manager: the matrix is freed on exit."""
+
+    def __init__(self, filename: str, max_gap_fraction: float):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        N, M = C.c_int32(), C.c_int32()
+        st = self.lib.gdca_fasta_open(str(filename).encode(), float(max_gap_fraction), C.byref(self.h), C.byref(N), C.byref(M))
+        if st != 0:
+            self.h = None
+            raise ValueError(f"cannot read FASTA alignment {filename} (empty, unreadable or not aligned)")
+        self.N, self.M = int(N.value), int(M.value)
+        self.ptr = int(self.lib.gdca_fasta_data(self.h) or 0)
+        self.q = int(self.lib.gdca_fasta_max_symbol(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.gdca_fasta_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def remove_duplicate_sequences(Z) -> Tuple[np.ndarray, np.ndarray]:
     """-> (Z without repeated columns, 1-based indices kept)  (reference call site src/GaussDCA.jl:21-23)"""
     lib = _lib.load()

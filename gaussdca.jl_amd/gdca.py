@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import ArgumentError, default_context
-from .dcautils import (_theta_arg, compute_ranking, read_fasta_alignment, remove_duplicate_sequences)
+from .dcautils import (FastaAlignment, _theta_arg, compute_ranking, read_fasta_alignment, remove_duplicate_sequences)
 
 last_stats = None  # stats of the most recent gDCA call (theta, threshold, Meff, device timings)
 
@@ -55,15 +55,20 @@ def gDCA(filename: str, pseudocount: float = 0.8, theta=":auto", max_gap_fractio
         raise TypeError(f"gDCA() got unexpected keyword arguments {sorted(kw)}")
     check_arguments(filename, pseudocount, theta, max_gap_fraction, score, min_separation)
 
-    Z = read_fasta_alignment(filename, max_gap_fraction)
-    if remove_dups:
-        Z, _ = remove_duplicate_sequences(Z)
-    N, M = Z.shape
-    q = int(Z.max())
-    if q >= 32:
-        raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
-
     ctx = ctx or default_context()
-    S, last_stats = ctx.run(np.asfortranarray(Z), q, float(pseudocount), _theta_arg(theta), _score_arg(score),
-                            apc=True)
+    if remove_dups:
+        Z = read_fasta_alignment(filename, max_gap_fraction)
+        Z, _ = remove_duplicate_sequences(Z)
+        q = int(Z.max())
+        if q >= 32:
+            raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
+        S, last_stats = ctx.run(np.asfortranarray(Z), q, float(pseudocount), _theta_arg(theta), _score_arg(score), apc=True)
+    else:
+        # the parsed matrix goes to gdca_run where the native reader left it (gdca_fasta_data), q = maximum(Z) comes from the
+        # reader (gdca_fasta_max_symbol): no copy into an array of the host language, no second pass over Z
+        with FastaAlignment(filename, max_gap_fraction) as fa:
+            q = fa.q
+            if q >= 32:
+                raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
+            S, last_stats = ctx.run_ptr(fa.ptr, fa.N, fa.M, q, float(pseudocount), _theta_arg(theta), _score_arg(score), apc=True)
     return compute_ranking(S, int(min_separation))

@@ -39,10 +39,16 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
         with pytest.raises(g.PosDefException):
             ctx.run(Z, q, pc, -1.0 if theta == "auto" else float(theta), 1 if score == "DI" else 0)
         return
-    if np.linalg.cond(o.compute_C(*o.add_pseudocount(*o.compute_frequencies(Zo, q, W_o, Meff_o), pc, q))) > 1e9:
-        return  # numerically singular covariance: both sides are dominated by rounding
+    # The bar scales with the conditioning of the covariance instead of giving up on it: both inverses carry ~cond * 2^-53 of
+    # relative error, so the scores may differ by a multiple of that (1e-6 up to cond ~ 1e8).  Beyond cond ~ 1e13 neither side
+    # has a correct digit left: only "finite where the oracle is finite" is asked for.
+    cond = np.linalg.cond(o.compute_C(*o.add_pseudocount(*o.compute_frequencies(Zo, q, W_o, Meff_o), pc, q)))
     S, stt = ctx.run(Z, q, pc, -1.0 if theta == "auto" else float(theta), 1 if score == "DI" else 0)
     assert stt["thresh"] == thr_o and stt["Meff"] == Meff_o and stt["theta"] == th_o
+    if cond > 1e13:
+        assert np.array_equal(np.isfinite(S), np.isfinite(S_o)) or not np.isfinite(S_o).all()
+        return
+    slack = max(1.0, 64.0 * cond * 2.0 ** -53 / 1e-6)
     if not np.isfinite(S_o).all():
         # degenerate input (e.g. pseudocount 1: every score is 0 and APC divides 0 by 0, in the reference too):
         # the GPU path must be non-finite in the same places
@@ -64,5 +70,5 @@ def test_fused_path_matches_oracle(env, seed, M, N, q, theta, pc, score):
     # near 1 the couplings vanish, the scores drop to ~1e-10 and BOTH implementations (and DCAUtils, which evaluates the
     # same expression) carry s * 2^-53-sized rounding noise in them; that floor is not a parity error
     atol_abs = 4.0 * (q - 1) * 2.0 ** -53 * 16 if score == "DI" else 0.0
-    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6, atol_frac=1e-9, atol_abs=atol_abs)
-    assert ok, (max_rel, max_abs)
+    ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6 * slack, atol_frac=1e-9 * slack, atol_abs=atol_abs)
+    assert ok, (max_rel, max_abs, cond)
