@@ -49,11 +49,11 @@ class Stats(C.Structure):
         ("theta", C.c_double), ("Meff", C.c_double), ("pair_identity_sum", C.c_uint64),
         ("thresh", C.c_int32), ("info", C.c_int32),
         ("N", C.c_int32), ("M", C.c_int32), ("q", C.c_int32), ("n", C.c_int32), ("n_pad", C.c_int32),
-        ("update_launches", C.c_int32), ("inverse_batch", C.c_int32),
+        ("update_launches", C.c_int32), ("inverse_batch", C.c_int32), ("refined", C.c_int32),
         ("ms_total", C.c_double), ("ms_theta", C.c_double), ("ms_weights", C.c_double),
         ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
         ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
-        ("sweep_ghz", C.c_double),
+        ("sweep_ghz", C.c_double), ("inverse_norm1", C.c_double),
     ]
 
     def as_dict(self):

@@ -37,6 +37,7 @@ struct gdca_ctx {
     char err[512];
     // named device buffers (grow-only)
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
+    gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
     hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
     int ncu;                   // compute units of the device
     int *item0_host;           // pinned staging of the sweep's item table
@@ -52,6 +53,10 @@ struct gdca_ctx {
     bool pend_timed;
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
     int pend_batch;            // families that shared this run's SPD-inverse launch (1: a launch of its own)
+    const int8_t *pend_Z;      // what a refinement at collect time needs to build C again and to score again
+    double *pend_S;
+    gdca_params pend_p;
+    int pend_refined;
     hipEvent_t pend_upd_ev[2]; // the two events around that launch (a merged launch's are its first member's)
     double pend_upd_flops;
 };
@@ -90,7 +95,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         return true;
     }
     long x = 0;
-    if (!parse_long(value, &x)) return false;
+    if (strcmp(k, "REFINE") && strcmp(k, "REFINE_COND") && !parse_long(value, &x)) return false;
     struct { const char *name; int *field; long lo, hi; } ints[] = {
         {"GROUP", &t->group, -1, 4},        {"RAMP", &t->ramp, 0, 1},          {"RAGGED", &t->ragged, 0, 1},
         {"REM_TAIL", &t->rem_tail, -1, 1 << 20}, {"PANEL_HALVES", &t->panel_halves, -1, 1}, {"SLAB", &t->slab, 0, 1},
@@ -104,6 +109,21 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
             *e.field = (int)x;
             return true;
         }
+    if (!strcmp(k, "REFINE")) {
+        const char c = (char)tolower((unsigned char)value[0]);
+        if (c == 'a' || !strcmp(value, "-1")) t->refine = -1;
+        else if (!strcmp(value, "0") || !strcasecmp(value, "off") || c == 'n') t->refine = 0;
+        else if (!strcmp(value, "1") || !strcasecmp(value, "on") || c == 'y') t->refine = 1;
+        else return false;
+        return true;
+    }
+    if (!strcmp(k, "REFINE_COND")) {
+        char *end = nullptr;
+        const double x = strtod(value, &end);
+        if (end == value || *end || !(x > 0.0)) return false;
+        t->refine_cond = x;
+        return true;
+    }
     if (!strcmp(k, "SWEEP_TIMEOUT_MS")) {
         if (x < 0) return false;
         t->sweep_timeout_ms = x;
@@ -129,10 +149,12 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_mcus = -1;
     t->merge_group = -1;
     t->merge_tiles = 2300;
+    t->refine = -1;
+    t->refine_cond = 1e6;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_SWEEP_TRACE"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_SWEEP_TRACE"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -284,7 +306,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
-                        &ctx->Tws, &ctx->colsum, &ctx->sc};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -556,6 +578,25 @@ static gdca_status not_pending(gdca_ctx *ctx)
     return GDCA_OK;
 }
 
+// ||X||_1 of the inverse the sweep has just left in ctx->A (sc->inv_norm1): what the collect decides a refinement on
+static gdca_status inverse_norm_stage(gdca_ctx *ctx, int n, int n_pad)
+{
+    if (ctx->tune.refine == 0) return GDCA_OK;
+    CHK(ensure(ctx, ctx->normws, (size_t)n_pad * sizeof(double)));
+    gdca_launch_inverse_norm1(ctx->stream, (const double *)ctx->A.p, n_pad, n, (double *)ctx->normws.p,
+                              &((gdca_dev_scalars *)ctx->sc.p)->inv_norm1);
+    return check_launch(ctx, "inverse_norm1");
+}
+
+static bool wants_refinement(const gdca_ctx *ctx, const gdca_dev_scalars &h)
+{
+    if (h.info != 0 || ctx->tune.refine == 0) return false;
+    if (ctx->tune.refine == 1) return true;
+    // kappa_1 = ||C||_1 ||X||_1 where ||C||_1 was at hand (operator-level entry); in the fused path ||X||_1 alone: the covariance of
+    // indicator variables has entries <= 1/4 and ||C||_1 of order one
+    return h.inv_norm1 * (h.mat_norm1 > 0.0 ? h.mat_norm1 : 1.0) > ctx->tune.refine_cond;
+}
+
 static gdca_status begin(gdca_ctx *ctx)
 {
     CHK(not_pending(ctx));
@@ -574,6 +615,26 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     HIPCHK(hipSetDevice(ctx->device));
     ctx->pending = false;
     CHK(fetch_scalars(ctx));
+    if (wants_refinement(ctx, *ctx->sc_host) && !ctx->sc_host->bad_symbol) {
+        // The inverse looks ill-conditioned (||X||_1 beyond the threshold): the block sweep's error grows like cond^2, so it gets
+        // one Newton-Schulz step against the covariance -- built again from the tallies: the sweep worked in place -- and the
+        // scores are computed again from the refined inverse.  Synchronous and several times the cost of the run itself: a path
+        // for rare inputs (pseudocounts far below the 0.2 .. 0.8 gDCA is used with), taken here so that the enqueue side stays lean.
+        gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+        const int N = ctx->pend_N, M = ctx->pend_M, q = ctx->pend_q, n_pad = ctx->pend_npad, n = ctx->pend_n;
+        const size_t mat = (size_t)n_pad * n_pad * sizeof(double);
+        CHK(ensure(ctx, ctx->C2, mat));
+        CHK(ensure(ctx, ctx->B0, mat));
+        CHK(ensure(ctx, ctx->Rt, mat));
+        CHK(tally_stage(ctx, ctx->pend_Z, N, M, q, &sc->Meff, ctx->pend_p.pseudocount, 1, nullptr, (double *)ctx->C2.p, (size_t)n_pad));
+        gdca_launch_pad_identity(ctx->stream, (double *)ctx->C2.p, n, n_pad);
+        gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad);
+        CHK(check_launch(ctx, "newton_schulz"));
+        HIPCHK(hipMemsetAsync(&sc->di_noconv, 0, sizeof(int), ctx->stream));
+        CHK(score_stage(ctx, N, q - 1, n_pad, ctx->pend_p.score, ctx->pend_p.apc, ctx->pend_S));
+        ctx->pend_refined = 1;
+        CHK(fetch_scalars(ctx));
+    }
     const gdca_dev_scalars &h = *ctx->sc_host;
     hipEvent_t *ev = ctx->ev;
     if (st) {
@@ -590,6 +651,8 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->n_pad = ctx->pend_npad;
         st->update_launches = ctx->pend_nupd;
         st->inverse_batch = ctx->pend_batch;
+        st->refined = ctx->pend_refined;
+        st->inverse_norm1 = h.inv_norm1;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
@@ -668,6 +731,9 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
     CHK(check_launch(ctx, "covariance"));
     if (timed) HIPCHK(hipEventRecord(ev[3], s));
     ctx->pend_timed = timed;
+    ctx->pend_Z = Z_dev;
+    ctx->pend_p = *p;
+    ctx->pend_refined = 0;
     ctx->pend_N = N;
     ctx->pend_M = M;
     ctx->pend_q = q;
@@ -761,6 +827,8 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
 
 static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
+    ctx->pend_S = S_dev;
+    CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;
@@ -1082,6 +1150,26 @@ gdca_status gdca_covariance_dev(gdca_ctx *ctx, const double *Pi_dev, const doubl
     return check_launch(ctx, "covariance");
 }
 
+// operator-level inverse: kappa_1 = ||C||_1 ||X||_1 (the caller's matrix is still in A_dev) and, beyond the threshold, one
+// Newton-Schulz step before the result is copied out.  Synchronises (the caller of an operator waits for `info` anyway).
+static gdca_status operator_norms_and_refine(gdca_ctx *ctx, const double *A_dev, int n, int n_pad)
+{
+    if (ctx->tune.refine == 0) return GDCA_OK;
+    gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+    CHK(ensure(ctx, ctx->normws, (size_t)n_pad * sizeof(double)));
+    gdca_launch_matrix_norm1(ctx->stream, A_dev, (size_t)n, n, (double *)ctx->normws.p, &sc->mat_norm1);
+    CHK(inverse_norm_stage(ctx, n, n_pad));
+    CHK(fetch_scalars(ctx));
+    if (!wants_refinement(ctx, *ctx->sc_host)) return GDCA_OK;
+    const size_t mat = (size_t)n_pad * n_pad * sizeof(double);
+    CHK(ensure(ctx, ctx->C2, mat));
+    CHK(ensure(ctx, ctx->B0, mat));
+    CHK(ensure(ctx, ctx->Rt, mat));
+    gdca_launch_copy_in(ctx->stream, A_dev, n, (double *)ctx->C2.p, n_pad);
+    gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad);
+    return check_launch(ctx, "newton_schulz");
+}
+
 gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
 {
     if (!ctx || !A_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
@@ -1092,6 +1180,7 @@ gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_
     gdca_launch_copy_in(s, A_dev, n, (double *)ctx->A.p, n_pad);
     int n_upd = 0;
     CHK(inverse_stage(ctx, n, n_pad, false, &n_upd, nullptr));
+    CHK(operator_norms_and_refine(ctx, A_dev, n, n_pad));
     gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, A_dev, n);
     CHK(check_launch(ctx, "copy_out"));
     CHK(fetch_scalars(ctx));

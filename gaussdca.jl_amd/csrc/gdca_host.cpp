@@ -137,7 +137,7 @@ int fasta_threads()
         const int v = atoi(e);
         if (v >= 1) return std::min(v, 64);
     }
-    return (int)std::min(16u, hw);
+    return (int)(hw >= 64 ? std::min(32u, hw) : std::min(16u, hw));  // (25 MB of FASTA on a 256-thread host: 12.4 / 9 / 8.2 ms at 8 / 16 / 32 threads)
 }
 
 // The text of a file: a plain file is mapped (parsed where the page cache holds it: no copy, no buffer to fault in), a gzip

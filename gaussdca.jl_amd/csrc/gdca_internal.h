@@ -22,6 +22,8 @@ struct gdca_dev_scalars {
     int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement
     int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
+    double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
+    double mat_norm1;  // ||C||_1 where the caller's matrix was at hand (operator-level inverse), else 0
 };
 
 // Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
@@ -46,6 +48,8 @@ struct gdca_tuning {
     int merge_mcus;         // GDCA_MERGE_MCUS: chain compute units per member of a merged launch
     int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
+    int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
+    double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: kappa_1 estimate (||C||_1 ||X||_1; fused path: ||X||_1 alone)
     char sweep_trace[256];  // GDCA_SWEEP_TRACE: file the in-kernel trace of the next inverse is written to ("" = off)
 };
 void gdca_tuning_from_env(gdca_tuning *t);
@@ -147,6 +151,14 @@ int gdca_inverse_max_merge(void);
 void gdca_launch_spd_inverse_merged(hipStream_t s, const gdca_inverse_job *jobs, int K, hipEvent_t *upd_ev, int max_upd_ev,
                                     double *upd_flops);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
+// *out = ||X||_1 of the symmetric matrix whose lower block triangle is A (= -X, the sweep's storage; first n rows / columns);
+// colsum_ws: n_pad doubles
+void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out);
+// *out = ||C||_1 of a plain n x n matrix
+void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out);
+// one Newton-Schulz step on the sweep's result: A (-X0 lower block triangle -> -X1), C2 = the matrix that was inverted (full
+// symmetric, n_pad x n_pad, identity padding), B0 and Rt: n_pad x n_pad workspaces
+void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad);
 
 // ---- k_score.hip ---------------------------------------------------------------------------
 // S (N x N) from the lower triangle of A = -mJ (ld).  Diagonal 0.

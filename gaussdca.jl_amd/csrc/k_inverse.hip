@@ -2584,6 +2584,151 @@ static void write_sweep_trace(const char *trace_path, const SweepPlan &P, unsign
     }
 }
 
+// =====================================================================================================================
+// How good is the inverse?  A norm estimate and, for ill-conditioned matrices, one Newton-Schulz step
+// =====================================================================================================================
+// The block sweep is Gauss-Jordan elimination: its forward error grows like cond(C)^2 u where LAPACK's potrf + potri (the
+// reference's inv(cholesky(C)), src/GaussDCA.jl:34) stays near cond(C) u (tests/test_gpu_conditioning.py, against columns refined
+// in extended precision: 60 x LAPACK's error at cond 2e5, 5e4 x at cond 1e8).  At the pseudocounts gDCA is used with (0.2 .. 0.8:
+// cond 1e2 .. 1e4) both are at rounding level; a tiny pseudocount is legal input, though (:50).  So every inverse gets a cheap
+// measure of its conditioning -- ||X||_1 from the lower triangle it has just produced; with ||C||_1 that is kappa_1 -- and
+// beyond a threshold ONE step of Newton-Schulz iteration
+//       X1 = X0 + X0 (I - C X0)
+// which squares the residual I - C X0 (it converges while that residual is below 1: cond up to ~1e7 for this sweep) and leaves
+// the error at the cond u level of the two f64 products themselves.  Two plain tiled products on the sweep's 128 x 128 x 128 MFMA
+// tile product (3 n^3 flops at ~30 TFLOP/s: several times the inverse itself -- a path for rare inputs, not a fast one).
+
+// colsum[c] += sum_r |A(r, c)| over the FULL symmetric matrix whose lower block triangle (diagonal tiles in full) is A: tile (I, J),
+// I >= J, feeds the columns of block J and, mirrored, those of block I
+__global__ __launch_bounds__(256) void k_sym_colabs(const double *__restrict__ A, size_t ld, int nblk, double *__restrict__ colsum)
+{
+    int I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long long)I * (I + 1) / 2 > (long long)blockIdx.x) --I;
+    while ((long long)(I + 1) * (I + 2) / 2 <= (long long)blockIdx.x) ++I;
+    const int J = (int)(blockIdx.x - (long long)I * (I + 1) / 2);
+    const double *At = A + (size_t)I * T + (size_t)J * T * ld;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // a wave walks 32 columns; a column is two coalesced loads (rows lane, lane + 64), its sum a butterfly; the lanes keep the
+    // row sums of their two rows over the wave's columns (= column sums of the mirror tile)
+    double r0 = 0.0, r1 = 0.0;
+    for (int c = 32 * wv; c < 32 * wv + 32; ++c) {
+        const double a0 = fabs(At[(size_t)lane + (size_t)c * ld]), a1 = fabs(At[(size_t)lane + 64 + (size_t)c * ld]);
+        r0 += a0;
+        r1 += a1;
+        double cs = a0 + a1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o, 64);
+        if (lane == 0) atomicAdd(&colsum[(size_t)J * T + c], cs);
+    }
+    if (I != J) {
+        atomicAdd(&colsum[(size_t)I * T + lane], r0);
+        atomicAdd(&colsum[(size_t)I * T + lane + 64], r1);
+    }
+}
+
+// column sums of |.| of a plain n x n matrix (ld): the caller's C of the operator-level entry
+__global__ __launch_bounds__(256) void k_colabs_full(const double *__restrict__ C, size_t ld, int n, double *__restrict__ colsum)
+{
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double a = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) a += fabs(C[(size_t)r + (size_t)c * ld]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) colsum[c] = red[0];
+}
+
+// *out = max over the n entries of colsum
+__global__ __launch_bounds__(256) void k_vec_max(const double *__restrict__ v, int n, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < n; k += 256) a = fmax(a, v[k]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out)
+{
+    (void)hipMemsetAsync(colsum_ws, 0, (size_t)n_pad * sizeof(double), s);
+    const int nblk = n_pad / T;
+    hipLaunchKernelGGL(k_sym_colabs, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, A, (size_t)n_pad, nblk, colsum_ws);
+    hipLaunchKernelGGL(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);   // (the padding's unit columns stay out of it)
+}
+
+void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out)
+{
+    hipLaunchKernelGGL(k_colabs_full, dim3((unsigned)n), dim3(256), 0, s, C, ld, n, colsum_ws);
+    hipLaunchKernelGGL(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);
+}
+
+// One 128 x 128 tile of  G H^T  over the whole inner dimension (nblk blocks of 128), G(r, k) = G[r + k ld], H(c, k) = H[c + k ld]
+// (both operands are symmetric matrices or stored transposed by the caller), then
+//   MODE 0:  Out = I - G H^T                       (all tiles: Rt = I - X0 C = (I - C X0)^T)
+//   MODE 1:  Out = -(X0 + G H^T)                   (tiles I >= J: the new -X1 = -(X0 + X0 (I - C X0)) in the sweep's storage)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_ns_gemm(const double *__restrict__ G, const double *__restrict__ H, size_t ld, int nblk,
+                                                    double *__restrict__ Out, const double *__restrict__ X0)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    int I, J;
+    if (MODE == 0) {
+        I = (int)(blockIdx.x / (unsigned)nblk);
+        J = (int)(blockIdx.x % (unsigned)nblk);
+    } else {
+        I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+        while ((long long)I * (I + 1) / 2 > (long long)blockIdx.x) --I;
+        while ((long long)(I + 1) * (I + 2) / 2 <= (long long)blockIdx.x) ++I;
+        J = (int)(blockIdx.x - (long long)I * (I + 1) / 2);
+    }
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double *g = G + (size_t)I * T, *h = H + (size_t)J * T;
+#pragma unroll 1
+    for (int K = 0; K < nblk; ++K)
+        tile_product<false, 4>(acc, g + (size_t)K * T * ld, ld, h + (size_t)K * T * ld, ld, GHs[0], GHs[1], nullptr, 0);
+    double *Ot = Out + (size_t)I * T + (size_t)J * T * ld;
+    const double *Xt = MODE == 1 ? X0 + (size_t)I * T + (size_t)J * T * ld : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = wr * 64 + tn * 16 + l15;
+                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
+                const size_t e = (size_t)r + (size_t)c * ld;
+                if (MODE == 0)
+                    Ot[e] = ((I == J && r == c) ? 1.0 : 0.0) - acc[tm][tn][reg];
+                else
+                    Ot[e] = -(Xt[e] + acc[tm][tn][reg]);
+            }
+}
+
+// A: the sweep's result (-X0 in the lower block triangle, ld = n_pad) on entry, -X1 there on exit.  C2: the matrix that was
+// inverted, full symmetric, padded with the identity.  B0, Rt: n_pad x n_pad workspaces.
+void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad)
+{
+    const int nblk = n_pad / T;
+    gdca_launch_copy_out_neg_sym(s, A, n_pad, B0, n_pad);                                      // B0 = X0, full symmetric
+    hipLaunchKernelGGL(k_ns_gemm<0>, dim3((unsigned)(nblk * nblk)), dim3(256), 0, s, B0, C2, (size_t)n_pad, nblk, Rt, nullptr);
+    hipLaunchKernelGGL(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0);
+}
+
 // -------------------------------------------------------------------------------------------------
 // f64 MFMA issue-rate probe (register-resident, 8 independent accumulators per wave).
 // -------------------------------------------------------------------------------------------------

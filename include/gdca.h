@@ -80,6 +80,8 @@ typedef struct gdca_stats {
     int32_t update_launches;    /* launches of the dominant kernel this run accounts for (a merged launch: its first member) */
     int32_t inverse_batch;      /* families that shared this run's SPD-inverse launch (gdca_run_dev_phased merges the small ones;
                                    1 = a launch of its own).  ms_inverse and ms_inverse_update are the launch's time divided by it */
+    int32_t refined;            /* 1: the inverse looked ill-conditioned (inverse_norm1 beyond REFINE_COND) and got a Newton-Schulz
+                                   step, the scores were computed again from it (the ms_* are those of the first pass) */
     /* device time (HIP events on the ctx stream), milliseconds */
     double ms_total;            /* Z in HBM -> S in HBM                                     */
     double ms_theta;            /* column histograms + theta                                */
@@ -92,6 +94,8 @@ typedef struct gdca_stats {
     double update_flops;        /* flops executed by all launches of the dominant kernel    */
     double sweep_ghz;           /* shader clock during the SPD-inverse kernel, measured by the kernel itself
                                    (s_memtime cycles / 100 MHz wall-clock ticks, summed over its workgroups); 0 if no inverse ran */
+    double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it: with ||C||_1 of order one (a covariance of indicator variables)
+                                   an estimate of cond(C); 0 if not measured (option REFINE=0) */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */
@@ -118,7 +122,10 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
  * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
- * 128-blocks), MERGE_MCUS.  Results never depend on them.  GDCA_EINVAL: unknown key or unusable value. */
+ * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS; REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
+ * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6).  The schedule switches change results
+ * at rounding level at most (another summation order); REFINE improves an ill-conditioned inverse.  GDCA_EINVAL: unknown key
+ * or unusable value. */
 gdca_status gdca_ctx_set_option(gdca_ctx *ctx, const char *key, const char *value);
 
 /* ---- fused hot path: replaces src/GaussDCA.jl:28-42 in one call ------------------------ */

@@ -33,11 +33,11 @@ end
 mutable struct GdcaStats
     theta::Cdouble; Meff::Cdouble; pair_identity_sum::UInt64
     thresh::Int32; info::Int32; N::Int32; M::Int32; q::Int32; n::Int32; n_pad::Int32; update_launches::Int32
-    inverse_batch::Int32
+    inverse_batch::Int32; refined::Int32
     ms_total::Cdouble; ms_theta::Cdouble; ms_weights::Cdouble; ms_covariance::Cdouble
     ms_inverse::Cdouble; ms_inverse_update::Cdouble; ms_score::Cdouble
     inverse_flops::Cdouble; update_flops::Cdouble
-    sweep_ghz::Cdouble
+    sweep_ghz::Cdouble; inverse_norm1::Cdouble
     GdcaStats() = new()
 end
 

@@ -28,6 +28,7 @@ int main(void)
     F(gdca_stats, n_pad);
     F(gdca_stats, update_launches);
     F(gdca_stats, inverse_batch);
+    F(gdca_stats, refined);
     F(gdca_stats, ms_total);
     F(gdca_stats, ms_theta);
     F(gdca_stats, ms_weights);
@@ -38,6 +39,7 @@ int main(void)
     F(gdca_stats, inverse_flops);
     F(gdca_stats, update_flops);
     F(gdca_stats, sweep_ghz);
+    F(gdca_stats, inverse_norm1);
     printf("status GDCA_OK %d 0\nstatus GDCA_EINVAL %d 0\nstatus GDCA_ENOTPD %d 0\nstatus GDCA_EHIP %d 0\n"
            "status GDCA_ENOMEM %d 0\nstatus GDCA_ENOCONV %d 0\n",
            GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV);

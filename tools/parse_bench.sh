@@ -22,7 +22,7 @@ for sub in plain gz; do
   echo "== $sub: $(du -sh $D/$sub | cut -f1)"
   cat $D/$sub/* > /dev/null   # page cache warm: the files were just written, but be explicit about what is measured
   for p in $PS; do
-    [ $p -le $((2 * $(nproc))) ] && $CLI --batch $D/$sub --parse-only --parsers $p 2>&1 | tail -1
+    [ $p -le $((2 * $(nproc))) ] && $CLI --batch $D/$sub --parse-only --parsers $p --passes ${PASSES:-1} 2>&1 | tail -1
   done
 done
 rm -rf $D
