@@ -588,10 +588,20 @@ static gdca_status inverse_norm_stage(gdca_ctx *ctx, int n, int n_pad)
     return check_launch(ctx, "inverse_norm1");
 }
 
+// The screen every fused run pays for (n diagonal entries): max_i X(i, i) <= ||X||_1 <= n max_i X(i, i) for the SPD inverse.  Only
+// where it comes within a factor 256 of the threshold does the collect spend a pass over the triangle on ||X||_1 itself.
+static gdca_status inverse_screen_stage(gdca_ctx *ctx, int n, int n_pad)
+{
+    if (ctx->tune.refine == 0) return GDCA_OK;
+    gdca_launch_inverse_diagmax(ctx->stream, (const double *)ctx->A.p, n_pad, n, &((gdca_dev_scalars *)ctx->sc.p)->inv_diagmax);
+    return check_launch(ctx, "inverse_diagmax");
+}
+
 static bool wants_refinement(const gdca_ctx *ctx, const gdca_dev_scalars &h)
 {
     if (h.info != 0 || ctx->tune.refine == 0) return false;
     if (ctx->tune.refine == 1) return true;
+    if (!(h.inv_norm1 > 0.0)) return false;  // the screen (max diagonal entry) stayed far below the threshold
     // kappa_1 = ||C||_1 ||X||_1 where ||C||_1 was at hand (operator-level entry); in the fused path ||X||_1 alone: the covariance of
     // indicator variables has entries <= 1/4 and ||C||_1 of order one
     return h.inv_norm1 * (h.mat_norm1 > 0.0 ? h.mat_norm1 : 1.0) > ctx->tune.refine_cond;
@@ -615,6 +625,11 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     HIPCHK(hipSetDevice(ctx->device));
     ctx->pending = false;
     CHK(fetch_scalars(ctx));
+    if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
+        (ctx->tune.refine == 1 || ctx->sc_host->inv_diagmax * 256.0 > ctx->tune.refine_cond)) {
+        CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));   // the screen says "maybe": ||X||_1 itself
+        CHK(fetch_scalars(ctx));
+    }
     if (wants_refinement(ctx, *ctx->sc_host) && !ctx->sc_host->bad_symbol) {
         // The inverse looks ill-conditioned (||X||_1 beyond the threshold): the block sweep's error grows like cond^2, so it gets
         // one Newton-Schulz step against the covariance -- built again from the tallies: the sweep worked in place -- and the
@@ -652,7 +667,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->update_launches = ctx->pend_nupd;
         st->inverse_batch = ctx->pend_batch;
         st->refined = ctx->pend_refined;
-        st->inverse_norm1 = h.inv_norm1;
+        st->inverse_norm1 = h.inv_norm1 > 0.0 ? h.inv_norm1 : h.inv_diagmax;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
@@ -828,7 +843,7 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
 static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
     ctx->pend_S = S_dev;
-    CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));
+    CHK(inverse_screen_stage(ctx, ctx->pend_n, ctx->pend_npad));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;

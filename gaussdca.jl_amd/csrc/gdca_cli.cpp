@@ -23,6 +23,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <malloc.h>
 #include <thread>
 #include <vector>
 
@@ -269,6 +270,10 @@ int run_batch(const Options &o)
         const unsigned per_file = o.parsers >= 8 ? 1u : std::max(1u, std::min(16u, hw / (unsigned)std::max(1, o.parsers)));
         setenv("GDCA_FASTA_THREADS", std::to_string(per_file).c_str(), 1);
     }
+    // dozens of parser threads allocating and freeing megabyte-sized vectors per file: keep those blocks inside malloc's arenas
+    // instead of one mmap / munmap pair each (both take the process-wide memory-map lock)
+    (void)mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    (void)mallopt(M_TRIM_THRESHOLD, 1 << 30);
     if (o.parse_only) {
         // the host side of the batch alone: P parser threads over the whole directory (read, inflate, column filter, letter
         // map, gap filter, optional duplicate removal), results dropped.  This is the rate the GPUs of a node have to be fed

@@ -215,24 +215,57 @@ bool slurp(const char *path, FileText &out)
     unsigned char t[4];
     if (fsz >= 4 && pread(fd, t, 4, (off_t)fsz - 4) == 4) hint = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
     hint = std::min(hint, 64 * fsz + ((size_t)1 << 16));
+    // the compressed bytes into a second per-thread buffer, then zlib's inflate() straight into the text buffer (gzip members one
+    // after the other, as gzread would): no gz* stream layer with its own megabyte buffers allocated and freed per file
+    static thread_local std::string zin;
+    if (zin.capacity() > ((size_t)256 << 20) && zin.capacity() > 4 * fsz) std::string().swap(zin);
+    if (zin.size() < fsz) zin.resize(fsz);
+    size_t got = 0;
+    while (got < fsz) {
+        const ssize_t n = pread(fd, &zin[got], fsz - got, (off_t)got);
+        if (n <= 0) break;
+        got += (size_t)n;
+    }
     close(fd);
-    gzFile f = gzopen(path, "rb");
-    if (!f) return false;
-    gzbuffer(f, 1 << 20);
+    if (got != fsz) return false;
     if (buf.size() < std::max<size_t>(hint, 1 << 16)) buf.resize(std::max<size_t>(hint, 1 << 16));
-    size_t len = 0;
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+    zs.next_in = (Bytef *)zin.data();
+    size_t in_left = fsz, len = 0;
+    bool ok = true;
     for (;;) {
         if (len == buf.size()) buf.resize(buf.size() * 2);
-        const unsigned want = (unsigned)std::min<size_t>(buf.size() - len, 1u << 30);
-        const int n = gzread(f, &buf[len], want);
-        if (n < 0) {
-            gzclose(f);
-            return false;
+        zs.avail_in = (uInt)std::min<size_t>(in_left, 1u << 30);
+        zs.next_out = (Bytef *)&buf[len];
+        zs.avail_out = (uInt)std::min<size_t>(buf.size() - len, 1u << 30);
+        const uInt in0 = zs.avail_in, out0 = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        in_left -= in0 - zs.avail_in;
+        len += out0 - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            if (in_left == 0) break;
+            // another gzip member follows (concatenated .gz files are one stream to gzip -d and to gzread)
+            Bytef *next = zs.next_in;
+            if (inflateReset(&zs) != Z_OK) {
+                ok = false;
+                break;
+            }
+            zs.next_in = next;
+            continue;
         }
-        if (n == 0) break;
-        len += (size_t)n;
+        if (rc != Z_OK && rc != Z_BUF_ERROR) {
+            ok = false;
+            break;
+        }
+        if (rc == Z_BUF_ERROR && in_left == 0 && zs.avail_out != 0) {
+            ok = false;  // truncated stream
+            break;
+        }
     }
-    gzclose(f);
+    inflateEnd(&zs);
+    if (!ok) return false;
     out.text = std::string_view(buf.data(), len);
     return true;
 }

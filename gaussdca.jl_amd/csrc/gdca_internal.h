@@ -23,6 +23,7 @@ struct gdca_dev_scalars {
     int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
+    double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
     double mat_norm1;  // ||C||_1 where the caller's matrix was at hand (operator-level inverse), else 0
 };
 
@@ -154,6 +155,8 @@ void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int block
 // *out = ||X||_1 of the symmetric matrix whose lower block triangle is A (= -X, the sweep's storage; first n rows / columns);
 // colsum_ws: n_pad doubles
 void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out);
+// *out = max_i |A(i, i)|, i < n
+void gdca_launch_inverse_diagmax(hipStream_t s, const double *A, int n_pad, int n, double *out);
 // *out = ||C||_1 of a plain n x n matrix
 void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out);
 // one Newton-Schulz step on the sweep's result: A (-X0 lower block triangle -> -X1), C2 = the matrix that was inverted (full

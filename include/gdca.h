@@ -94,8 +94,9 @@ typedef struct gdca_stats {
     double update_flops;        /* flops executed by all launches of the dominant kernel    */
     double sweep_ghz;           /* shader clock during the SPD-inverse kernel, measured by the kernel itself
                                    (s_memtime cycles / 100 MHz wall-clock ticks, summed over its workgroups); 0 if no inverse ran */
-    double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it: with ||C||_1 of order one (a covariance of indicator variables)
-                                   an estimate of cond(C); 0 if not measured (option REFINE=0) */
+    double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it -- with ||C||_1 of order one (a covariance of indicator variables)
+                                   an estimate of cond(C) -- where it was needed to decide on a refinement; else its lower bound
+                                   max_i inv(C)(i, i), the screen every run computes; 0 with option REFINE=0 */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */
