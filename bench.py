@@ -142,9 +142,18 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
     from oracle import gdca_oracle as o
 
     try:
-        avail = len(os.sched_getaffinity(0))      # the cores this process may run on (cgroup / affinity aware)
+        avail = len(os.sched_getaffinity(0))      # the cores this process may run on (affinity aware)
     except AttributeError:
         avail = os.cpu_count() or 1
+    # ... capped by the cgroup CPU quota: the GPU box shows 256 hardware threads and grants "1600000 100000" in cpu.max = 16 CPUs'
+    # worth of time; threads beyond that are throttled (which is why every probe below finds 16 threads fastest there)
+    hw_threads = avail
+    try:
+        import gaussdca.jl_amd as _g
+
+        avail = max(1, min(avail, int(_g.load().gdca_host_cpus())))
+    except Exception:  # noqa: BLE001
+        pass
     s = q - 1
     n = N * s
     t_all = time.time()
@@ -153,7 +162,7 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
     # threads and 4-5x slower at 256 (tools/cpu_scaling.py, profiles/r03_cpu_scaling.log), so "all cores" would understate
     # the CPU.  Candidates: all, 128, 64, 32, 16; the fastest on a probe wins, for the OpenMP loops and for OpenBLAS
     # separately; `cores` in the JSON is what was used.
-    cands = sorted({c for c in (avail, 128, 64, 32, 16) if c <= avail} or {avail}, reverse=True)
+    cands = sorted({c for c in (avail, 128, 64, 32, 16, 8) if c <= avail} or {avail}, reverse=True)
     thr0 = o.hamming_threshold(0.3, N)
     Zs = Z[:min(M, 16000)]
     probe_omp = {}
@@ -310,7 +319,7 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         blas_limit.restore_original_limits()
     inv_flops = (n ** 3 / 3.0 + n * n / 2.0 + n / 6.0) + (2.0 * n ** 3 / 3.0 + n * n / 2.0 + 5.0 * n / 6.0)
     return dict(value=1.0 / sec, unit="families/s", cores=max(cores, blas_threads),
-                threads={"omp": cores, "blas": blas_threads}, host_threads_available=avail,
+                threads={"omp": cores, "blas": blas_threads}, host_threads_available=avail, host_hardware_threads=hw_threads,
                 thread_choice={"openmp_probe_sec": {str(k): round(v, 4) for k, v in probe_omp.items()},
                                "blas_probe_sec_at_half_n": {str(k): round(v, 4) for k, v in probe_blas.items()},
                                "blas_inv_sec_at_n": {str(k): round(v, 4) for k, v in blas_full.items()}},

@@ -117,6 +117,7 @@ SYMBOLS = {
     "gdca_fn": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_di": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gdca_apc": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
+    "gdca_host_cpus": (C.c_int32, []),
     "gdca_fasta_open": (C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_void_p), _i32p, _i32p]),
     "gdca_fasta_copy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gdca_fasta_data": (C.c_void_p, [C.c_void_p]),

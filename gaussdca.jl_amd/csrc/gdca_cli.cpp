@@ -266,7 +266,7 @@ int run_batch(const Options &o)
     // (measured on the 256-thread host of the GPU box, tools/parse_bench.sh: with 8 or more files in flight nested threads only
     // add contention in the kernel's memory-map lock -- 946 families/s with one thread per file against 497 with eight)
     if (!getenv("GDCA_FASTA_THREADS")) {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned hw = (unsigned)std::max(1, gdca_host_cpus());
         const unsigned per_file = o.parsers >= 8 ? 1u : std::max(1u, std::min(16u, hw / (unsigned)std::max(1, o.parsers)));
         setenv("GDCA_FASTA_THREADS", std::to_string(per_file).c_str(), 1);
     }
@@ -527,7 +527,11 @@ int main(int argc, char **argv)
         else o.positional.push_back(s);
     }
     check_arguments(o);
-    if (o.parsers <= 0) o.parsers = (int)std::min(32u, std::max(4u, std::thread::hardware_concurrency() / 8u));
+    // parser threads: an eighth of a big host (32 at most), three quarters of a small one or of a small CPU quota
+    if (o.parsers <= 0) {
+        const int cpus = std::max(1, gdca_host_cpus());
+        o.parsers = cpus >= 64 ? std::min(32, cpus / 8) : std::max(2, cpus * 3 / 4);
+    }
     if (!o.batch_dir.empty()) {
         if (o.out_dir.empty() && !o.parse_only) die("--batch needs --out OUTDIR");
         return run_batch(o);

@@ -130,9 +130,37 @@ const InsertMap kIns;
 
 // threads one gdca_fasta_open call may use on a big file: GDCA_FASTA_THREADS, default min(16, hardware threads).  The batch
 // driver, which already parses several files at once, sets it to hardware threads / parser threads.
+// CPUs this process can really use: the hardware threads, capped by the cgroup's CFS quota (a container that sees 256 threads
+// but is given "1600000 100000" in cpu.max runs 16 of them at a time and is THROTTLED beyond that: on the GPU box every host
+// loop of this project was fastest at 16 threads and slower at 32, 64, 128 for exactly this reason)
+unsigned effective_cpus()
+{
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    auto from = [&](const char *path_quota, const char *path_period) {
+        FILE *f = fopen(path_quota, "r");
+        if (!f) return;
+        long long q = -1, per = 100000;
+        char word[64] = {0};
+        if (path_period) {
+            if (fscanf(f, "%lld", &q) != 1) q = -1;
+            if (FILE *g = fopen(path_period, "r")) {
+                if (fscanf(g, "%lld", &per) != 1) per = 100000;
+                fclose(g);
+            }
+        } else if (fscanf(f, "%63s %lld", word, &per) == 2 && strcmp(word, "max") != 0) {
+            q = atoll(word);
+        }
+        fclose(f);
+        if (q > 0 && per > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (q + per - 1) / per));
+    };
+    from("/sys/fs/cgroup/cpu.max", nullptr);
+    from("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    return hw;
+}
+
 int fasta_threads()
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = effective_cpus();
     if (const char *e = getenv("GDCA_FASTA_THREADS")) {
         const int v = atoi(e);
         if (v >= 1) return std::min(v, 64);
@@ -324,6 +352,11 @@ std::string_view body_sequence(std::string_view text, Span body, std::string &sc
 }  // namespace
 
 extern "C" {
+
+int32_t gdca_host_cpus(void)
+{
+    return (int32_t)effective_cpus();
+}
 
 gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fasta **out, int32_t *N, int32_t *M)
 {

@@ -235,6 +235,9 @@ gdca_status gdca_di(gdca_ctx *ctx, const double *mJ, const double *C, int32_t N,
 gdca_status gdca_apc(gdca_ctx *ctx, double *S, int32_t N);
 
 /* ---- host-side utilities around the hot path (plain C++, no GPU): the reference's callers of the path -------- */
+/* CPUs this process can really use: hardware threads capped by the cgroup CPU quota (a container may see 256 threads and be given
+ * 16 CPUs' worth of time; threads beyond the quota are throttled).  What the reader's and the batch driver's thread counts go by. */
+int32_t gdca_host_cpus(void);
 typedef struct gdca_fasta gdca_fasta;
 /* DCAUtils.read_fasta_alignment(filename, max_gap_fraction) (src/GaussDCA.jl:20): parses a FASTA file (plain or
  * gzip), keeps the columns of the first record that are neither '.' nor lowercase, drops sequences with more
