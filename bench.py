@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
 SPEC_SHADER_GHZ = 2.4  # the clock the spec peak is quoted at; the clock of the timed launches is measured by k_sweep itself
-PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_update_traffic.json")
+PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_update_traffic.json")
 
 CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
     "B": dict(N=128, M=10000, theta=0.2, seed=0xB128, ref="BASELINE.json configs[1]"),
@@ -265,11 +265,13 @@ def cpu_baseline(N, M, q, pc, theta, score_name, seed, budget_s=60.0):
         C = o.compute_C(Pi2, Pij2)
         stage["cov"] = time.time() - t
         del Pi, Pij, Pij2
-        # potrf + potri on the family's own covariance with every candidate thread count whose n/2 estimate is within 1.6x of
-        # the best (at most three): the stage time is the fastest of them
+        # potrf + potri on the family's own covariance with the best candidate thread counts of the n/2 estimate: the stage time
+        # is the fastest of them
         if threadpool_limits is not None and probe_blas:
+            # (the two best of the n/2 ranking always -- on the GPU box it put 8 threads ahead of 16 and the full size had it the
+            # other way round, 2.03 s against 1.53 s -- and a third if it was within 1.3x)
             ranked = sorted(probe_blas, key=probe_blas.get)
-            tryc = [c for c in ranked if probe_blas[c] <= 1.6 * probe_blas[ranked[0]]][:3]
+            tryc = ranked[:2] + [c for c in ranked[2:3] if probe_blas[c] <= 1.3 * probe_blas[ranked[0]]]
             mJ = None
             for c in tryc:
                 with threadpool_limits(limits=c, user_api="blas"):
