@@ -771,6 +771,17 @@ t = time.time()
 X = g.inv_cholesky(A, ctx=ctx)
 out = {"rel": float(np.max(np.abs(X - np.linalg.inv(A))) / np.max(np.abs(X))), "seconds": time.time() - t,
        "enabled_cus": sum(bin(w).count("1") for w in words)}
+# ... and a merged launch on the same masked stream: three families, each chain claimed by whichever XCD gets there
+cs = [ctx] + [g.Context(0, stream=stream.value) for _ in range(2)]
+ns = [1500, 2300, 900]
+As = []
+for m in ns:
+    B = rng.standard_normal((m, 40))
+    As.append((B @ B.T) / 40 + np.diag(0.3 + rng.random(m)))
+ds = [g.DeviceBuffer.from_array(c, a) for c, a in zip(cs, As)]
+ctx.set_options(MERGE=4)
+g.spd_inverse_batch_dev(cs, [d.ptr for d in ds], ns)
+out["rel_merged"] = max(float(np.max(np.abs(d.download((m, m)) - np.linalg.inv(a))) / np.max(np.abs(np.linalg.inv(a)))) for d, a, m in zip(ds, As, ns))
 print(json.dumps(out))
 """
 
@@ -792,4 +803,4 @@ def test_inverse_on_a_cu_masked_stream_without_xcc0(n):
                        env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="3000"), timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["enabled_cus"] == 208 and out["rel"] <= 1e-10, out
+    assert out["enabled_cus"] == 208 and out["rel"] <= 1e-10 and out["rel_merged"] <= 1e-10, out
