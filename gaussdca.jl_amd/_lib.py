@@ -225,7 +225,7 @@ class Context:
     def run(self, Zf: np.ndarray, q: int, pseudocount: float, theta: float, score: int, apc: bool = True):
         """Zf: int8, shape (N, M), Fortran-contiguous.  Returns (S[N,N], stats dict)."""
         N, M = Zf.shape
-        S = np.empty((N, N), dtype=np.float64)
+        S = np.empty((N, N), dtype=np.float64, order="F")  # (the library writes column-major; compute_ranking takes it as it is)
         prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
         st = Stats()
         rc = self.lib.gdca_run(self.h, _p(Zf), N, M, int(q), C.byref(prm), _p(S), C.byref(st))
@@ -234,7 +234,7 @@ class Context:
 
     def run_ptr(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int, apc: bool = True):
         """gdca_run on a HOST matrix given by address (N x M int8, column-major: e.g. gdca_fasta_data).  Returns (S, stats)."""
-        S = np.empty((N, N), dtype=np.float64)
+        S = np.empty((N, N), dtype=np.float64, order="F")
         prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
         st = Stats()
         rc = self.lib.gdca_run(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), _p(S), C.byref(st))

@@ -641,9 +641,25 @@ gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int
     // radix sort on a 64-bit key that orders doubles the way isless does (-0.0 < 0.0, every NaN greatest), bits
     // flipped for the descending direction; equal scores keep their generation order (i ascending, then j).
     const size_t n = (size_t)len;
-    std::vector<uint64_t> key(n), key2(n);
-    std::vector<uint32_t> idx(n), idx2(n);
-    std::vector<int32_t> gi(n), gj(n);
+    // (scratch of the calling thread, kept between calls: six arrays of n entries are 4 MB at N = 500 -- as fresh vectors every
+    // call paid for mapping and faulting them in, which cost more than the sort)
+    static thread_local std::vector<uint64_t> key, key2;
+    static thread_local std::vector<uint32_t> idx, idx2;
+    static thread_local std::vector<int32_t> gi, gj;
+    if (key.capacity() > 16 * n + ((size_t)1 << 22)) {  // a giant earlier call does not pin its scratch for ever
+        std::vector<uint64_t>().swap(key);
+        std::vector<uint64_t>().swap(key2);
+        std::vector<uint32_t>().swap(idx);
+        std::vector<uint32_t>().swap(idx2);
+        std::vector<int32_t>().swap(gi);
+        std::vector<int32_t>().swap(gj);
+    }
+    key.resize(n);
+    key2.resize(n);
+    idx.resize(n);
+    idx2.resize(n);
+    gi.resize(n);
+    gj.resize(n);
     size_t t = 0;
     for (int32_t i = 1; i <= N - min_separation; ++i)
         for (int32_t j = i + min_separation; j <= N; ++j, ++t) {
@@ -657,25 +673,32 @@ gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int
             gi[t] = i;
             gj[t] = j;
         }
-    constexpr int RB = 16, NB = 1 << RB;
-    std::vector<uint32_t> hist((size_t)4 * NB, 0);
-    for (size_t e = 0; e < n; ++e)
-        for (int pass = 0; pass < 4; ++pass) hist[(size_t)pass * NB + ((key[e] >> (RB * pass)) & (NB - 1))]++;
-    for (int pass = 0; pass < 4; ++pass) {
-        uint32_t *h = hist.data() + (size_t)pass * NB;
+    // Stable LSD radix sort, 11 bits a pass, six passes (2048 write streams stay in the caches; with 16 bits a pass the 65 536
+    // streams did not).  One thread: N = 500 is 1.2 ms, N = 1000 6.2 ms on the GPU box's host with the scratch above kept between
+    // calls (it was 2-3 ms and 10-15 ms with fresh vectors); a multi-threaded form (per-thread histograms, spinning barrier) was
+    // measured on the same host at 2 .. 16 threads and bought nothing reliable (1.6-2.9 ms and 4-16 ms: `tools/rank_time.cpp`).
+    constexpr int RB = 11, NB = 1 << RB, PASSES = 6;
+    static_assert(PASSES % 2 == 0, "the sorted arrays end up in key / idx");
+    uint32_t hist[NB];
+    uint64_t *src_k = key.data(), *dst_k = key2.data();
+    uint32_t *src_i = idx.data(), *dst_i = idx2.data();
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int sh = RB * pass;
+        for (int b = 0; b < NB; ++b) hist[b] = 0;
+        for (size_t e = 0; e < n; ++e) hist[(src_k[e] >> sh) & (NB - 1)]++;
         uint32_t run = 0;
-        for (int bkt = 0; bkt < NB; ++bkt) {
-            const uint32_t c = h[bkt];
-            h[bkt] = run;
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t c = hist[b];
+            hist[b] = run;
             run += c;
         }
         for (size_t e = 0; e < n; ++e) {
-            const uint32_t pos = h[(key[e] >> (RB * pass)) & (NB - 1)]++;
-            key2[pos] = key[e];
-            idx2[pos] = idx[e];
+            const uint32_t pos = hist[(src_k[e] >> sh) & (NB - 1)]++;
+            dst_k[pos] = src_k[e];
+            dst_i[pos] = src_i[e];
         }
-        key.swap(key2);
-        idx.swap(idx2);
+        std::swap(src_k, dst_k);
+        std::swap(src_i, dst_i);
     }
     for (size_t e = 0; e < n; ++e) {
         const uint32_t g = idx[e];
