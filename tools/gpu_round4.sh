@@ -8,6 +8,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -c "import torch" 2>/dev/null
+timeout 600 python __graft_entry__.py smoke > $out/entry_smoke.log 2>&1 < /dev/null; echo "entry rc $?" >> $out/entry_smoke.log; tail -2 $out/entry_smoke.log
 ( timeout 1800 python -m pytest tests -m gpu -q -x -p no:cacheprovider --durations=10 > $out/pytest_gpu.log 2>&1; echo "rc $?" >> $out/pytest_gpu.log ) < /dev/null
 tail -3 $out/pytest_gpu.log
 # the driver's command (default flags: headline + other_configs + cpu_baseline), then the full-size lines of the other configurations
@@ -44,6 +45,8 @@ timeout 200 python tools/e2e_profile.py C 5 > $out/e2e_profile_C.log 2>&1 < /dev
 timeout 200 python tools/e2e_profile.py D 3 > $out/e2e_profile_D.log 2>&1 < /dev/null
 ( cat /sys/fs/cgroup/cpu.max; nproc ) > $out/host_cpus.log 2>&1
 PASSES=6 timeout 900 bash tools/parse_bench.sh 128 /tmp/gdca_pb "1 8 16 32 64" > $out/parse_bench.log 2>&1 < /dev/null
+INFLIGHT="1 2" timeout 600 bash tools/cli_batch_bench.sh 128 /tmp/gdca_cb > $out/cli_batch.log 2>&1 < /dev/null
+[ -x tools/_bin/rank_time ] && ( tools/_bin/rank_time 500; tools/_bin/rank_time 1000 ) > $out/rank_time.log 2>&1 < /dev/null
 [ -x tools/_bin/ubench_vmcnt_order ] && timeout 120 tools/_bin/ubench_vmcnt_order 1000 > $out/ubench_vmcnt_order.log 2>&1 < /dev/null
 # kernel-trace + stats of the driver's hot path (profiled timings are not compared with un-profiled ones), both scores
 cd /tmp
