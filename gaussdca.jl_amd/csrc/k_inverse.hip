@@ -2657,25 +2657,26 @@ __global__ __launch_bounds__(256) void k_vec_max(const double *__restrict__ v, i
     if (threadIdx.x == 0) *out = red[0];
 }
 
-// *out = max_i |A(i, i)|, i < n: for the SPD inverse a lower bound of every norm of it, read off n entries -- the screen that runs
+// *out = max(*out, max_i |A(i, i)|), i < n: for the SPD inverse a lower bound of every norm of it, read off n entries -- the screen that runs
 // after every inverse (the full ||X||_1 costs a pass over the lower triangle: 0.11 ms at n = 10 000, half a percent of a family)
-__global__ __launch_bounds__(1024) void k_diag_absmax(const double *__restrict__ A, size_t ld, int n, double *__restrict__ out)
+__global__ __launch_bounds__(256) void k_diag_absmax(const double *__restrict__ A, size_t ld, int n, double *__restrict__ out)
 {
-    __shared__ double red[1024];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) a = fmax(a, fabs(A[(size_t)i + (size_t)i * ld]));
-    red[threadIdx.x] = a;
+    __shared__ double red[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    red[threadIdx.x] = i < n ? fabs(A[(size_t)i + (size_t)i * ld]) : 0.0;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0];
+    // non-negative doubles order like their bit patterns: one integer atomic per workgroup (*out was zeroed with the scalars)
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(red[0]));
 }
 
 void gdca_launch_inverse_diagmax(hipStream_t s, const double *A, int n_pad, int n, double *out)
 {
-    hipLaunchKernelGGL(k_diag_absmax, dim3(1), dim3(1024), 0, s, A, (size_t)n_pad, n, out);
+    // (*out lives in the run's scalar block, which every run zeroes when it begins)
+    hipLaunchKernelGGL(k_diag_absmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, (size_t)n_pad, n, out);
 }
 
 void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out)
