@@ -465,7 +465,8 @@ def main():
             others = {}
             plan = (("C_DI", "C", "DI", 20, 3, 1, False, 256), ("B", "B", "frob", 40, 5, 1, False, 256),
                     ("B_merged8", "B", "frob", 80, 8, 8, True, 256), ("D", "D", "frob", 5, 1, 1, False, 256),
-                    ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_phased8", "E", "frob", 2, 1, 8, True, 32))
+                    ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_p2", "E", "frob", 2, 1, 2, False, 32),
+                    ("E32_phased8", "E", "frob", 2, 1, 8, True, 32))
             for key, cname, sc, st_, wu, P_, ph_, nf in plan:
                 try:
                     a2 = argparse.Namespace(**vars(args))
