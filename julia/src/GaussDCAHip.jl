@@ -64,6 +64,12 @@ end
 
 theta_arg(θ) = θ === :auto ? -1.0 : Float64(θ)
 
+# tuning switch of the context (include/gdca.h: gdca_ctx_set_option), e.g. set_option("REFINE", "0") or set_option("GROUP", 4);
+# the GDCA_* environment variables are read once, when the context is created
+function set_option(key::AbstractString, value)
+    check(ccall((:gdca_ctx_set_option, libgdca), Cint, (Ptr{Cvoid}, Cstring, Cstring), ctx(), String(key), string(value)))
+end
+
 # ---- the fused hot path: src/GaussDCA.jl:28-42 in one call --------------------------------
 function hot_path(Z::Matrix{Int8}, q::Integer, pseudocount::Real, θ, score::Symbol)
     N, M = size(Z)
