@@ -643,12 +643,15 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         CHK(ensure(ctx, ctx->Rt, mat));
         CHK(tally_stage(ctx, ctx->pend_Z, N, M, q, &sc->Meff, ctx->pend_p.pseudocount, 1, nullptr, (double *)ctx->C2.p, (size_t)n_pad));
         gdca_launch_pad_identity(ctx->stream, (double *)ctx->C2.p, n, n_pad);
-        gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad);
+        gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad,
+                                  &sc->ns_resid);
         CHK(check_launch(ctx, "newton_schulz"));
         HIPCHK(hipMemsetAsync(&sc->di_noconv, 0, sizeof(int), ctx->stream));
         CHK(score_stage(ctx, N, q - 1, n_pad, ctx->pend_p.score, ctx->pend_p.apc, ctx->pend_S));
-        ctx->pend_refined = 1;
         CHK(fetch_scalars(ctx));
+        // the step squares I - X0 C: with that residual at one or beyond (cond(C) past ~1e10: the sweep's own error is of order one
+        // there) it cannot have converged, and the caller is told so instead of being handed the result as if it were refined
+        ctx->pend_refined = ctx->sc_host->ns_resid < 1.0 ? 1 : -1;
     }
     const gdca_dev_scalars &h = *ctx->sc_host;
     hipEvent_t *ev = ctx->ev;
@@ -1181,7 +1184,8 @@ static gdca_status operator_norms_and_refine(gdca_ctx *ctx, const double *A_dev,
     CHK(ensure(ctx, ctx->B0, mat));
     CHK(ensure(ctx, ctx->Rt, mat));
     gdca_launch_copy_in(ctx->stream, A_dev, n, (double *)ctx->C2.p, n_pad);
-    gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad);
+    gdca_launch_newton_schulz(ctx->stream, (double *)ctx->A.p, (const double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, n_pad,
+                              &sc->ns_resid);
     return check_launch(ctx, "newton_schulz");
 }
 

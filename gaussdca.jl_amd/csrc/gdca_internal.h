@@ -24,6 +24,7 @@ struct gdca_dev_scalars {
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
     double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
+    double ns_resid;     // max |I - X0 C| seen by the Newton-Schulz step (0: no step)
     double mat_norm1;  // ||C||_1 where the caller's matrix was at hand (operator-level inverse), else 0
 };
 
@@ -161,7 +162,8 @@ void gdca_launch_inverse_diagmax(hipStream_t s, const double *A, int n_pad, int 
 void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out);
 // one Newton-Schulz step on the sweep's result: A (-X0 lower block triangle -> -X1), C2 = the matrix that was inverted (full
 // symmetric, n_pad x n_pad, identity padding), B0 and Rt: n_pad x n_pad workspaces
-void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad);
+// *resid (optional): max |I - X0 C|, the residual the step squares -- below one or the step cannot have converged
+void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad, double *resid);
 
 // ---- k_score.hip ---------------------------------------------------------------------------
 // S (N x N) from the lower triangle of A = -mJ (ld).  Diagonal 0.

@@ -2697,9 +2697,11 @@ void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, 
 // (both operands are symmetric matrices or stored transposed by the caller), then
 //   MODE 0:  Out = I - G H^T                       (all tiles: Rt = I - X0 C = (I - C X0)^T)
 //   MODE 1:  Out = -(X0 + G H^T)                   (tiles I >= J: the new -X1 = -(X0 + X0 (I - C X0)) in the sweep's storage)
+//   resid (MODE 0): max |I - G H^T| over the matrix, as the bit pattern of a non-negative double (atomicMax): the step converges only
+//   while the residual is below one -- the caller reports a refinement that could not have worked instead of returning it silently
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_ns_gemm(const double *__restrict__ G, const double *__restrict__ H, size_t ld, int nblk,
-                                                    double *__restrict__ Out, const double *__restrict__ X0)
+                                                    double *__restrict__ Out, const double *__restrict__ X0, double *__restrict__ resid)
 {
     __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
     int I, J;
@@ -2725,6 +2727,7 @@ __global__ __launch_bounds__(256, 2) void k_ns_gemm(const double *__restrict__ G
         tile_product<false, 4>(acc, g + (size_t)K * T * ld, ld, h + (size_t)K * T * ld, ld, GHs[0], GHs[1], nullptr, 0);
     double *Ot = Out + (size_t)I * T + (size_t)J * T * ld;
     const double *Xt = MODE == 1 ? X0 + (size_t)I * T + (size_t)J * T * ld : nullptr;
+    double worst = 0.0;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -2734,21 +2737,30 @@ __global__ __launch_bounds__(256, 2) void k_ns_gemm(const double *__restrict__ G
                 const int r = wr * 64 + tn * 16 + l15;
                 const int c = wc * 64 + tm * 16 + lq + 4 * reg;
                 const size_t e = (size_t)r + (size_t)c * ld;
-                if (MODE == 0)
-                    Ot[e] = ((I == J && r == c) ? 1.0 : 0.0) - acc[tm][tn][reg];
-                else
+                if (MODE == 0) {
+                    const double v = ((I == J && r == c) ? 1.0 : 0.0) - acc[tm][tn][reg];
+                    Ot[e] = v;
+                    worst = fmax(worst, v == v ? fabs(v) : __builtin_huge_val());   // (a NaN counts as "diverged")
+                } else {
                     Ot[e] = -(Xt[e] + acc[tm][tn][reg]);
+                }
             }
+    if (MODE == 0 && resid) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(resid), (unsigned long long)__double_as_longlong(worst));
+    }
 }
 
 // A: the sweep's result (-X0 in the lower block triangle, ld = n_pad) on entry, -X1 there on exit.  C2: the matrix that was
-// inverted, full symmetric, padded with the identity.  B0, Rt: n_pad x n_pad workspaces.
-void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad)
+// inverted, full symmetric, padded with the identity.  B0, Rt: n_pad x n_pad workspaces.  *resid (optional) receives max |I - X0 C|.
+void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, double *B0, double *Rt, int n_pad, double *resid)
 {
     const int nblk = n_pad / T;
+    if (resid) (void)hipMemsetAsync(resid, 0, sizeof(double), s);
     gdca_launch_copy_out_neg_sym(s, A, n_pad, B0, n_pad);                                      // B0 = X0, full symmetric
-    hipLaunchKernelGGL(k_ns_gemm<0>, dim3((unsigned)(nblk * nblk)), dim3(256), 0, s, B0, C2, (size_t)n_pad, nblk, Rt, nullptr);
-    hipLaunchKernelGGL(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0);
+    hipLaunchKernelGGL(k_ns_gemm<0>, dim3((unsigned)(nblk * nblk)), dim3(256), 0, s, B0, C2, (size_t)n_pad, nblk, Rt, nullptr, resid);
+    hipLaunchKernelGGL(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -71,4 +71,10 @@ def gDCA(filename: str, pseudocount: float = 0.8, theta=":auto", max_gap_fractio
             if q >= 32:
                 raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
             S, last_stats = ctx.run_ptr(fa.ptr, fa.N, fa.M, q, float(pseudocount), _theta_arg(theta), _score_arg(score), apc=True)
+    if last_stats.get("refined", 0) < 0:
+        import warnings
+
+        warnings.warn("gDCA: the covariance is too ill-conditioned for the block sweep even with its refinement step "
+                      f"(||inv(C)||_1 = {last_stats['inverse_norm1']:.3g}; pseudocount {pseudocount}): scores are unreliable",
+                      RuntimeWarning, stacklevel=2)
     return compute_ranking(S, int(min_separation))

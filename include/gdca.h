@@ -81,7 +81,9 @@ typedef struct gdca_stats {
     int32_t inverse_batch;      /* families that shared this run's SPD-inverse launch (gdca_run_dev_phased merges the small ones;
                                    1 = a launch of its own).  ms_inverse and ms_inverse_update are the launch's time divided by it */
     int32_t refined;            /* 1: the inverse looked ill-conditioned (inverse_norm1 beyond REFINE_COND) and got a Newton-Schulz
-                                   step, the scores were computed again from it (the ms_* are those of the first pass) */
+                                   step, the scores were computed again from it (the ms_* are those of the first pass);
+                                   -1: the step was taken but cannot have converged (residual |I - X C| >= 1: cond(C) beyond ~1e10,
+                                   where the sweep's own error is of order one) -- the scores are not to be trusted */
     /* device time (HIP events on the ctx stream), milliseconds */
     double ms_total;            /* Z in HBM -> S in HBM                                     */
     double ms_theta;            /* column histograms + theta                                */

@@ -146,3 +146,27 @@ def test_scores_at_small_pseudocounts_match_oracle(env, name, pc, score):
     assert st["refined"] == (1 if st["inverse_norm1"] > 1e6 else 0) and (st["refined"] == 1) == (pc < 0.01)
     ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6 * slack, atol_frac=1e-9 * slack, atol_abs=atol_abs)
     assert ok, (name, pc, score, max_rel, max_abs, slack)
+
+
+def test_a_refinement_that_cannot_converge_is_reported(env):
+    """Far beyond cond 1e10 the sweep's own error is of order one and the Newton-Schulz step diverges (|I - X0 C| >= 1): the run
+    must say so (gdca_stats.refined = -1) instead of passing the result off as refined; the statuses stay those of the reference
+    (a covariance LAPACK still factors is not an error)."""
+    g, o, ctx = env
+    from gaussdca.jl_amd import synth
+
+    Zo = synth.synth_family(430, 600, 21, 0x1C0D)
+    seen = {}
+    for pc in (1e-6, 1e-9, 1e-11):
+        try:
+            S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 0)
+        except g.PosDefException:
+            seen[pc] = "not PD"
+            continue
+        seen[pc] = (st["refined"], st["inverse_norm1"])
+        assert st["refined"] != 0 and st["inverse_norm1"] > 1e6
+        if st["refined"] == 1:
+            assert np.isfinite(S).all()
+    print("\nrefined by pseudocount:", seen)
+    assert seen[1e-6][0] == 1
+    assert any(v == "not PD" or v[0] == -1 for v in seen.values()), seen
