@@ -1247,6 +1247,9 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
         m->pend_timed = false;
     }
     if (st == GDCA_OK) st = run_inverses(lead, ctxs, K);
+    // kappa_1 and, where it is beyond the threshold, the Newton-Schulz step: member by member, as gdca_spd_inverse_dev does (the
+    // caller's matrices are still intact; each member's switches are its own context's)
+    for (int k = 0; k < K && st == GDCA_OK; ++k) st = operator_norms_and_refine(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad);
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
         gdca_launch_copy_out_neg_sym(lead->stream, (const double *)ctxs[k]->A.p, ctxs[k]->pend_npad, A_dev[k], n[k]);
         st = check_launch(lead, "copy_out");

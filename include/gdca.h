@@ -198,7 +198,8 @@ gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_
  * replaced by its inverse; info[k] as gdca_spd_inverse (info may be NULL).  The small members -- up to MERGE_BLOCKS 128-blocks,
  * which leave most of the chip idle when they run alone -- share launches of the sweep kernel, MERGE of them at a time
  * (gdca_ctx_set_option on ctxs[0]); every result is bit for bit that of gdca_spd_inverse_dev.  K <= 64 distinct contexts of
- * one device (a member's workspace is its context's).  Synchronous.  GDCA_ENOTPD if any member is not positive definite. */
+ * one device (a member's workspace is its context's).  Synchronous.  GDCA_ENOTPD if any member is not positive definite.  Like
+ * gdca_spd_inverse_dev, a member whose kappa_1 = ||A||_1 ||inv A||_1 is beyond REFINE_COND gets one Newton-Schulz step. */
 gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double *const *A_dev, const int32_t *n, int32_t *info);
 gdca_status gdca_fn_dev(gdca_ctx *ctx, const double *mJ_dev, int32_t N, int32_t q, double *S_dev);
 gdca_status gdca_di_dev(gdca_ctx *ctx, const double *mJ_dev, const double *C_dev, int32_t N, int32_t q, double *S_dev);
