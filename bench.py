@@ -377,6 +377,8 @@ def main():
                          "reweighting/tallies (VALU, LDS) overlap family f's SPD inverse (MFMA); 1 = strictly serial")
     ap.add_argument("--gate", action="store_true",
                     help="with --pipeline > 1: let the SPD-inverse stages of the families in flight take turns")
+    ap.add_argument("--phased-one-set", action="store_true",
+                    help="with --phased: one set of P contexts instead of two alternating ones (no batch is enqueued while another runs)")
     ap.add_argument("--phased", action="store_true",
                     help="with --pipeline K: batch the K families in flight BY PHASE on one stream (gdca_run_dev_phased): K front "
                          "ends, then K SPD inverses back to back, then K score stages -- the matrix pipes see one load step per "
@@ -554,8 +556,12 @@ def measure(args, config, score_name, steps, warmup, rank, world, local, dev, di
         pending = None
         for b, a in enumerate(range(0, len(work), P)):
             grp = work[a:a + P]
-            cset = (ctxs if b % 2 == 0 else ctxs2)[:len(grp)]
-            sset = (Sd if b % 2 == 0 else Sd2)[:len(grp)]
+            alt = b % 2 == 1 and not args.phased_one_set
+            cset = (ctxs2 if alt else ctxs)[:len(grp)]
+            sset = (Sd2 if alt else Sd)[:len(grp)]
+            if args.phased_one_set and pending is not None:   # one set of contexts: the batch before must be collected first
+                sink.extend(c.collect() for c in pending)
+                pending = None
             g.run_dev_phased(cset, [Zd[fi].data_ptr() for fi in grp], [fams[fi][1] for fi in grp],
                              [fams[fi][2] for fi in grp], [q] * len(grp), pc, cfg["theta"], score,
                              [x.data_ptr() for x in sset])
