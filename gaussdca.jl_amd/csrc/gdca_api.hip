@@ -38,6 +38,7 @@ struct gdca_ctx {
     // named device buffers (grow-only)
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
     gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
+    gdca_buf Wd;                  // Cholesky fallback: the inverses of the diagonal tiles of the factor
     hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
     int ncu;                   // compute units of the device
     int *item0_host;           // pinned staging of the sweep's item table
@@ -102,6 +103,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
+        {"CHOLESKY", &t->cholesky, 0, 2},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -151,10 +153,11 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_tiles = 2300;
     t->refine = -1;
     t->refine_cond = 1e6;
+    t->cholesky = 1;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_SWEEP_TRACE"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -306,7 +309,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
-                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -607,6 +610,30 @@ static bool wants_refinement(const gdca_ctx *ctx, const gdca_dev_scalars &h)
     return h.inv_norm1 * (h.mat_norm1 > 0.0 ? h.mat_norm1 : 1.0) > ctx->tune.refine_cond;
 }
 
+// The reference's own factorisation as the last resort (option CHOLESKY: 0 never, 1 where the sweep gave up, 2 always [tests]):
+// the sweep reported a non-positive pivot -- beyond cond ~1e10 that can be its own rounding, LAPACK's dpotrf still factors such
+// matrices -- or its Newton-Schulz step could not converge.  `h`: the scalars as fetched after the sweep / the refinement.
+static bool wants_cholesky(const gdca_ctx *ctx, const gdca_dev_scalars &h, int refined)
+{
+    if (ctx->tune.cholesky == 0 || h.bad_symbol || h.info == INT32_MIN) return false;
+    return ctx->tune.cholesky == 2 || h.info > 0 || refined < 0;
+}
+
+// ctx->C2 holds the matrix (n_pad x n_pad, identity padding, at least its lower block triangle): dpotrf + dpotri by blocks, -inverse
+// into ctx->A where the sweep would have left it; sc->info becomes dpotrf's
+static gdca_status cholesky_stage(gdca_ctx *ctx, int n, int n_pad)
+{
+    gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+    const size_t mat = (size_t)n_pad * n_pad * sizeof(double);
+    CHK(ensure(ctx, ctx->B0, mat));
+    CHK(ensure(ctx, ctx->Rt, mat));
+    CHK(ensure(ctx, ctx->Wd, (size_t)(n_pad / GDCA_TILE) * GDCA_TILE * GDCA_TILE * sizeof(double)));
+    HIPCHK(hipMemsetAsync(&sc->info, 0, sizeof(int), ctx->stream));
+    gdca_launch_cholesky_inverse(ctx->stream, (double *)ctx->C2.p, (double *)ctx->B0.p, (double *)ctx->Rt.p, (double *)ctx->Wd.p, (double *)ctx->A.p,
+                                 n_pad, n, sc);
+    return check_launch(ctx, "cholesky_inverse");
+}
+
 static gdca_status begin(gdca_ctx *ctx)
 {
     CHK(not_pending(ctx));
@@ -652,6 +679,22 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         // the step squares I - X0 C: with that residual at one or beyond (cond(C) past ~1e10: the sweep's own error is of order one
         // there) it cannot have converged, and the caller is told so instead of being handed the result as if it were refined
         ctx->pend_refined = ctx->sc_host->ns_resid < 1.0 ? 1 : -1;
+    }
+    if (wants_cholesky(ctx, *ctx->sc_host, ctx->pend_refined)) {
+        // the sweep gave up on this covariance (a non-positive pivot, or a refinement that cannot converge): once more the
+        // reference's way -- the covariance from the tallies again, blocked dpotrf + dpotri, the scores from that inverse.  Its
+        // verdict on positive definiteness is LAPACK's.
+        gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+        const int N = ctx->pend_N, M = ctx->pend_M, q = ctx->pend_q, n_pad = ctx->pend_npad, n = ctx->pend_n;
+        CHK(ensure(ctx, ctx->C2, (size_t)n_pad * n_pad * sizeof(double)));
+        CHK(tally_stage(ctx, ctx->pend_Z, N, M, q, &sc->Meff, ctx->pend_p.pseudocount, 1, nullptr, (double *)ctx->C2.p, (size_t)n_pad));
+        gdca_launch_pad_identity(ctx->stream, (double *)ctx->C2.p, n, n_pad);
+        CHK(cholesky_stage(ctx, n, n_pad));
+        CHK(inverse_norm_stage(ctx, n, n_pad));
+        HIPCHK(hipMemsetAsync(&sc->di_noconv, 0, sizeof(int), ctx->stream));
+        CHK(score_stage(ctx, N, q - 1, n_pad, ctx->pend_p.score, ctx->pend_p.apc, ctx->pend_S));
+        CHK(fetch_scalars(ctx));
+        ctx->pend_refined = 2;
     }
     const gdca_dev_scalars &h = *ctx->sc_host;
     hipEvent_t *ev = ctx->ev;
@@ -1189,6 +1232,18 @@ static gdca_status operator_norms_and_refine(gdca_ctx *ctx, const double *A_dev,
     return check_launch(ctx, "newton_schulz");
 }
 
+// ... and the Cholesky fallback where the sweep gave up (non-positive pivot) or the step above cannot have converged.  Leaves the
+// member's scalars fetched (sc_host) and its stream idle.
+static gdca_status operator_fallback(gdca_ctx *ctx, const double *A_dev, int n, int n_pad)
+{
+    CHK(fetch_scalars(ctx));
+    if (!wants_cholesky(ctx, *ctx->sc_host, ctx->sc_host->ns_resid >= 1.0 ? -1 : 0)) return GDCA_OK;
+    CHK(ensure(ctx, ctx->C2, (size_t)n_pad * n_pad * sizeof(double)));
+    gdca_launch_copy_in(ctx->stream, A_dev, n, (double *)ctx->C2.p, n_pad);
+    CHK(cholesky_stage(ctx, n, n_pad));
+    return fetch_scalars(ctx);
+}
+
 gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
 {
     if (!ctx || !A_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
@@ -1200,9 +1255,10 @@ gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_
     int n_upd = 0;
     CHK(inverse_stage(ctx, n, n_pad, false, &n_upd, nullptr));
     CHK(operator_norms_and_refine(ctx, A_dev, n, n_pad));
+    CHK(operator_fallback(ctx, A_dev, n, n_pad));
     gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, A_dev, n);
     CHK(check_launch(ctx, "copy_out"));
-    CHK(fetch_scalars(ctx));
+    HIPCHK(hipStreamSynchronize(s));
     if (ctx->sc_host->info == INT32_MIN) {
         if (info) *info = 0;
         return fail(ctx, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
@@ -1250,6 +1306,7 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
     // kappa_1 and, where it is beyond the threshold, the Newton-Schulz step: member by member, as gdca_spd_inverse_dev does (the
     // caller's matrices are still intact; each member's switches are its own context's)
     for (int k = 0; k < K && st == GDCA_OK; ++k) st = operator_norms_and_refine(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad);
+    for (int k = 0; k < K && st == GDCA_OK; ++k) st = operator_fallback(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad);
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
         gdca_launch_copy_out_neg_sym(lead->stream, (const double *)ctxs[k]->A.p, ctxs[k]->pend_npad, A_dev[k], n[k]);
         st = check_launch(lead, "copy_out");
@@ -1260,9 +1317,7 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
     gdca_status worst = GDCA_OK;
     for (int k = 0; k < K; ++k) {
         gdca_ctx *m = ctxs[k];
-        st = fetch_scalars(m);
-        if (st != GDCA_OK) return st;
-        const int inf = m->sc_host->info;
+        const int inf = m->sc_host->info;   // (fetched by operator_fallback)
         if (inf == INT32_MIN)
             worst = fail(lead, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
         else if (inf != 0) {

@@ -52,6 +52,7 @@ struct gdca_tuning {
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
     int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
     double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: kappa_1 estimate (||C||_1 ||X||_1; fused path: ||X||_1 alone)
+    int cholesky;           // GDCA_CHOLESKY: the blocked dpotrf + dpotri fallback: 0 = never, 1 = where the sweep gave up (default), 2 = always
     char sweep_trace[256];  // GDCA_SWEEP_TRACE: file the in-kernel trace of the next inverse is written to ("" = off)
 };
 void gdca_tuning_from_env(gdca_tuning *t);
@@ -153,6 +154,11 @@ int gdca_inverse_max_merge(void);
 void gdca_launch_spd_inverse_merged(hipStream_t s, const gdca_inverse_job *jobs, int K, hipEvent_t *upd_ev, int max_upd_ev,
                                     double *upd_flops);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
+// The reference's own way (dpotrf + dpotri) as a fallback for matrices the sweep cannot handle: C2 (n_pad x n_pad, identity
+// padding; overwritten by its Cholesky factor), U and Tm: n_pad x n_pad workspaces, Wd: (n_pad / 128) tiles of 128 x 128; Aout
+// receives -inverse in its lower block triangle (the sweep's storage); sc->info = dpotrf's index of a non-positive pivot
+void gdca_launch_cholesky_inverse(hipStream_t s, double *C2, double *U, double *Tm, double *Wd, double *Aout, int n_pad, int n_real,
+                                  gdca_dev_scalars *sc);
 // *out = ||X||_1 of the symmetric matrix whose lower block triangle is A (= -X, the sweep's storage; first n rows / columns);
 // colsum_ws: n_pad doubles
 void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out);

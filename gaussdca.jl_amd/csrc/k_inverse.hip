@@ -2763,6 +2763,196 @@ void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, doubl
     hipLaunchKernelGGL(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0, nullptr);
 }
 
+// =====================================================================================================================
+// The stable way round for the inputs the sweep cannot handle: blocked Cholesky + triangular inverse + U U^T
+// =====================================================================================================================
+// Beyond cond ~1e10 the sweep's Schur complements go non-positive through rounding (it reports "not positive definite" where
+// LAPACK's dpotrf still factors the matrix) or its Newton-Schulz step cannot converge.  For exactly those runs -- never on the
+// ordinary path -- the inverse is computed again the way the reference does it (src/GaussDCA.jl:34: dpotrf + dpotri), as plain
+// multi-launch blocked algorithms on the 128 x 128 x 128 MFMA tile product:
+//     1. right-looking Cholesky, block column k:  diagonal tile (one workgroup, in LDS; also W_kk = L_kk^-1),
+//        panel  L_Ik = A_Ik W_kk^T,  trailing update  A_IJ -= L_Ik L_Jk^T                                    [n^3 / 3]
+//     2. U = L^-T by block forward substitution, block row i:  T_ij = sum_{k=j}^{i-1} L_ik U_jk^T,  U_ji = -T_ij^T W_ii^T  [n^3 / 3]
+//     3. X = U U^T on the lower block triangle, written as -X into the sweep's storage                         [n^3 / 3]
+// ~5 nblk launches, a few TFLOP/s: tens of milliseconds where the sweep needs ten -- a fallback, not a fast path.  Its `info` is
+// dpotrf's by construction (the first non-positive pivot of the Cholesky factorisation).
+
+// acc(r, c) += sum over `count` blocks of 128:  G(r, k) H(c, k),  G / H advancing by gstep / hstep doubles per block
+template <bool GT>
+__device__ __forceinline__ void chol_tile_acc(double4_t (&acc)[4][4], const double *g, size_t gld, size_t gstep, const double *h, size_t hld,
+                                              size_t hstep, int count, double (*Gs)[LDS_LD], double (*Hs)[LDS_LD])
+{
+#pragma unroll 1
+    for (int k = 0; k < count; ++k) tile_product<GT, 4>(acc, g + (size_t)k * gstep, gld, h + (size_t)k * hstep, hld, Gs, Hs, nullptr, 0);
+}
+
+#define CHOL_ACC_ZERO(acc)                                   \
+    _Pragma("unroll") for (int tm_ = 0; tm_ < 4; ++tm_)      \
+        _Pragma("unroll") for (int tn_ = 0; tn_ < 4; ++tn_) acc[tm_][tn_] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+// out(r, c) = f(old, acc) for the workgroup's tile: MODE 0: acc;  1: old - acc;  2: -acc
+template <int MODE>
+__device__ __forceinline__ void chol_tile_store(const double4_t (&acc)[4][4], double *Ot, size_t ld)
+{
+    const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
+    const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const size_t e = (size_t)(wr * 64 + tn * 16 + l15) + (size_t)(wc * 64 + tm * 16 + lq + 4 * reg) * ld;
+                Ot[e] = MODE == 0 ? acc[tm][tn][reg] : (MODE == 1 ? Ot[e] - acc[tm][tn][reg] : -acc[tm][tn][reg]);
+            }
+}
+
+// diagonal tile k: Cholesky in LDS (lower L written back, upper part zeroed), W = L^-1 to Wd (128 x 128, ld 128), U_kk = W^T (full tile)
+__global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ Lm, size_t ld, int k, double *__restrict__ Wd, double *__restrict__ U,
+                                                   int n_real, gdca_dev_scalars *sc)
+{
+    extern __shared__ __attribute__((aligned(16))) double a[];  // [c][r], 128 x 128
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    double *At = Lm + (size_t)k * T + (size_t)k * T * ld;
+    for (int e = tid; e < T * T; e += 256) a[e] = At[(size_t)(e & 127) + (size_t)(e >> 7) * ld];
+    if (tid == 0) bad = 0;
+    for (int j = 0; j < T; ++j) {
+        __syncthreads();
+        double d = a[j + j * T];
+        if (!(d > 0.0)) {
+            if (tid == 0 && bad == 0) bad = j + 1;
+            d = 1.0;  // keep going with finite numbers: the result is discarded
+        }
+        const double sq = sqrt(d);
+        __syncthreads();
+        if (tid >= j && tid < T) a[tid + j * T] = (tid == j) ? sq : a[tid + j * T] / sq;
+        __syncthreads();
+        for (int e = tid; e < T * T; e += 256) {
+            const int r = e & 127, c = e >> 7;
+            if (c > j && r >= c) a[e] -= a[r + j * T] * a[c + j * T];
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && bad != 0) {
+        const int idx = k * T + bad;
+        if (idx <= n_real && sc->info == 0) sc->info = idx;   // (tiles are factored one after the other: the first report is the smallest index)
+    }
+    for (int e = tid; e < T * T; e += 256) {
+        const int r = e & 127, c = e >> 7;
+        At[(size_t)r + (size_t)c * ld] = r >= c ? a[e] : 0.0;
+    }
+    // W = L^-1, column c by thread c (forward substitution; the thread reads back its own earlier entries)
+    double *W = Wd;
+    if (tid < T) {
+        const int c = tid;
+        for (int r = 0; r < c; ++r) W[r + c * T] = 0.0;
+        W[c + c * T] = 1.0 / a[c + c * T];
+        for (int r = c + 1; r < T; ++r) {
+            double sacc = 0.0;
+            for (int m = c; m < r; ++m) sacc += a[r + m * T] * W[m + c * T];
+            W[r + c * T] = -sacc / a[r + r * T];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    double *Ut = U + (size_t)k * T + (size_t)k * T * ld;
+    for (int e = tid; e < T * T; e += 256) {
+        const int r = e & 127, c = e >> 7;        // U_kk(r, c) = W(c, r) for c >= r, else 0
+        Ut[(size_t)r + (size_t)c * ld] = c >= r ? W[c + r * T] : 0.0;
+    }
+}
+
+// panel of block column k: tile (I, k), I = k + 1 + blockIdx.x  <-  tile W_kk^T   (in place: a workgroup reads only the tile it writes)
+__global__ __launch_bounds__(256, 2) void k_chol_panel(double *__restrict__ Lm, size_t ld, int k, const double *__restrict__ Wd)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    const int I = k + 1 + (int)blockIdx.x;
+    double4_t acc[4][4];
+    CHOL_ACC_ZERO(acc);
+    double *At = Lm + (size_t)I * T + (size_t)k * T * ld;
+    chol_tile_acc<false>(acc, At, ld, 0, Wd, (size_t)T, 0, 1, GHs[0], GHs[1]);
+    __syncthreads();
+    chol_tile_store<0>(acc, At, ld);
+}
+
+// trailing update after block column k: tile (I, J), I >= J > k  -=  L_Ik L_Jk^T
+__global__ __launch_bounds__(256, 2) void k_chol_trail(double *__restrict__ Lm, size_t ld, int k)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    int a_ = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long long)a_ * (a_ + 1) / 2 > (long long)blockIdx.x) --a_;
+    while ((long long)(a_ + 1) * (a_ + 2) / 2 <= (long long)blockIdx.x) ++a_;
+    const int b_ = (int)(blockIdx.x - (long long)a_ * (a_ + 1) / 2);
+    const int I = k + 1 + a_, J = k + 1 + b_;
+    double4_t acc[4][4];
+    CHOL_ACC_ZERO(acc);
+    chol_tile_acc<false>(acc, Lm + (size_t)I * T + (size_t)k * T * ld, ld, 0, Lm + (size_t)J * T + (size_t)k * T * ld, ld, 0, 1, GHs[0], GHs[1]);
+    chol_tile_store<1>(acc, Lm + (size_t)I * T + (size_t)J * T * ld, ld);
+}
+
+// forward substitution, block row i, first half: T_ij = sum_{k=j}^{i-1} L_ik U_jk^T, j = blockIdx.x < i   (Tm: tile (i, j))
+__global__ __launch_bounds__(256, 2) void k_chol_fwd_t(const double *__restrict__ Lm, const double *__restrict__ U, double *__restrict__ Tm, size_t ld, int i)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    const int j = (int)blockIdx.x;
+    double4_t acc[4][4];
+    CHOL_ACC_ZERO(acc);
+    chol_tile_acc<false>(acc, Lm + (size_t)i * T + (size_t)j * T * ld, ld, (size_t)T * ld, U + (size_t)j * T + (size_t)j * T * ld, ld, (size_t)T * ld, i - j,
+                         GHs[0], GHs[1]);
+    chol_tile_store<0>(acc, Tm + (size_t)i * T + (size_t)j * T * ld, ld);
+}
+
+// ... second half: U_ji = -T_ij^T W_ii^T
+__global__ __launch_bounds__(256, 2) void k_chol_fwd_u(const double *__restrict__ Tm, const double *__restrict__ Wd, double *__restrict__ U, size_t ld, int i)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    const int j = (int)blockIdx.x;
+    double4_t acc[4][4];
+    CHOL_ACC_ZERO(acc);
+    // out(c, r) = sum_m T_ij(m, c) W_ii(r, m):  G(c, m) = T_ij[m + c ld] (transposed access), H(r, m) = W_ii[r + m 128]
+    chol_tile_acc<true>(acc, Tm + (size_t)i * T + (size_t)j * T * ld, ld, 0, Wd, (size_t)T, 0, 1, GHs[0], GHs[1]);
+    chol_tile_store<2>(acc, U + (size_t)j * T + (size_t)i * T * ld, ld);
+}
+
+// X = U U^T on the lower block triangle: tile (I, J), I >= J:  sum_{k >= I} U_Ik U_Jk^T, written as -X (the sweep's storage)
+__global__ __launch_bounds__(256, 2) void k_chol_uut(const double *__restrict__ U, double *__restrict__ Aout, size_t ld, int nblk)
+{
+    __shared__ __attribute__((aligned(16))) double GHs[2][KC][LDS_LD];
+    int I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long long)I * (I + 1) / 2 > (long long)blockIdx.x) --I;
+    while ((long long)(I + 1) * (I + 2) / 2 <= (long long)blockIdx.x) ++I;
+    const int J = (int)(blockIdx.x - (long long)I * (I + 1) / 2);
+    double4_t acc[4][4];
+    CHOL_ACC_ZERO(acc);
+    chol_tile_acc<false>(acc, U + (size_t)I * T + (size_t)I * T * ld, ld, (size_t)T * ld, U + (size_t)J * T + (size_t)I * T * ld, ld, (size_t)T * ld, nblk - I,
+                         GHs[0], GHs[1]);
+    chol_tile_store<2>(acc, Aout + (size_t)I * T + (size_t)J * T * ld, ld);
+}
+
+// C2: the matrix (full symmetric or lower block triangle, n_pad x n_pad, identity padding) -- overwritten by its Cholesky factor;
+// U, Tm: n_pad x n_pad workspaces; Wd: 128 x 128; Aout receives -inverse in its lower block triangle.  sc->info: dpotrf's index.
+void gdca_launch_cholesky_inverse(hipStream_t s, double *C2, double *U, double *Tm, double *Wd, double *Aout, int n_pad, int n_real,
+                                  gdca_dev_scalars *sc)
+{
+    const int nblk = n_pad / T;
+    const size_t ld = (size_t)n_pad;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, T * T * (int)sizeof(double));
+    for (int k = 0; k < nblk; ++k) {
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), T * T * sizeof(double), s, C2, ld, k, Wd + (size_t)k * T * T, U, n_real, sc);
+        const int below = nblk - k - 1;
+        if (below > 0) {
+            hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)below), dim3(256), 0, s, C2, ld, k, Wd + (size_t)k * T * T);
+            hipLaunchKernelGGL(k_chol_trail, dim3((unsigned)(below * (below + 1) / 2)), dim3(256), 0, s, C2, ld, k);
+        }
+    }
+    for (int i = 1; i < nblk; ++i) {
+        hipLaunchKernelGGL(k_chol_fwd_t, dim3((unsigned)i), dim3(256), 0, s, C2, U, Tm, ld, i);
+        hipLaunchKernelGGL(k_chol_fwd_u, dim3((unsigned)i), dim3(256), 0, s, Tm, Wd + (size_t)i * T * T, U, ld, i);
+    }
+    hipLaunchKernelGGL(k_chol_uut, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, U, Aout, ld, nblk);
+}
+
 // -------------------------------------------------------------------------------------------------
 // f64 MFMA issue-rate probe (register-resident, 8 independent accumulators per wave).
 // -------------------------------------------------------------------------------------------------

@@ -83,7 +83,11 @@ typedef struct gdca_stats {
     int32_t refined;            /* 1: the inverse looked ill-conditioned (inverse_norm1 beyond REFINE_COND) and got a Newton-Schulz
                                    step, the scores were computed again from it (the ms_* are those of the first pass);
                                    -1: the step was taken but cannot have converged (residual |I - X C| >= 1: cond(C) beyond ~1e10,
-                                   where the sweep's own error is of order one) -- the scores are not to be trusted */
+                                   where the sweep's own error is of order one) and option CHOLESKY is 0 -- the scores are not
+                                   to be trusted;
+                                   2: the sweep gave up (a non-positive pivot of its own, or the step above could not converge) and
+                                   the inverse was computed again by blocked Cholesky (dpotrf + dpotri, as the reference does);
+                                   `info` and the scores are those of that factorisation */
     /* device time (HIP events on the ctx stream), milliseconds */
     double ms_total;            /* Z in HBM -> S in HBM                                     */
     double ms_theta;            /* column histograms + theta                                */
@@ -126,7 +130,8 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
  * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS; REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
- * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6).  The schedule switches change results
+ * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6); CHOLESKY (0 | 1 | 2: the blocked
+ * dpotrf + dpotri fallback never / where the sweep gave up [default] / for every inverse).  The schedule switches change results
  * at rounding level at most (another summation order); REFINE improves an ill-conditioned inverse.  GDCA_EINVAL: unknown key
  * or unusable value. */
 gdca_status gdca_ctx_set_option(gdca_ctx *ctx, const char *key, const char *value);

@@ -149,24 +149,94 @@ def test_scores_at_small_pseudocounts_match_oracle(env, name, pc, score):
 
 
 def test_a_refinement_that_cannot_converge_is_reported(env):
-    """Far beyond cond 1e10 the sweep's own error is of order one and the Newton-Schulz step diverges (|I - X0 C| >= 1): the run
-    must say so (gdca_stats.refined = -1) instead of passing the result off as refined; the statuses stay those of the reference
-    (a covariance LAPACK still factors is not an error)."""
+    """Far beyond cond 1e10 the sweep's own error is of order one and the Newton-Schulz step diverges (|I - X0 C| >= 1).  With the
+    Cholesky fallback switched off (option CHOLESKY=0) the run must say so (gdca_stats.refined = -1) instead of passing the result
+    off as refined, or report the sweep's non-positive pivot."""
     g, o, ctx = env
     from gaussdca.jl_amd import synth
 
     Zo = synth.synth_family(430, 600, 21, 0x1C0D)
     seen = {}
-    for pc in (1e-6, 1e-9, 1e-11):
-        try:
-            S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 0)
-        except g.PosDefException:
-            seen[pc] = "not PD"
-            continue
-        seen[pc] = (st["refined"], st["inverse_norm1"])
-        assert st["refined"] != 0 and st["inverse_norm1"] > 1e6
-        if st["refined"] == 1:
-            assert np.isfinite(S).all()
-    print("\nrefined by pseudocount:", seen)
+    ctx.set_option("CHOLESKY", 0)
+    try:
+        for pc in (1e-6, 1e-9, 1e-11):
+            try:
+                S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 0)
+            except g.PosDefException:
+                seen[pc] = "not PD"
+                continue
+            seen[pc] = (st["refined"], st["inverse_norm1"])
+            assert st["refined"] in (1, -1) and st["inverse_norm1"] > 1e6
+            if st["refined"] == 1:
+                assert np.isfinite(S).all()
+    finally:
+        ctx.set_option("CHOLESKY", 1)
+    print("\nrefined by pseudocount (CHOLESKY=0):", seen)
     assert seen[1e-6][0] == 1
     assert any(v == "not PD" or v[0] == -1 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("pc", [1e-8, 1e-9, 1e-11])
+def test_where_the_sweep_gives_up_the_cholesky_fallback_answers_like_lapack(env, pc):
+    """Default options, cond(C) from 1e11 upwards: the sweep reports a non-positive pivot of its own making, or its refinement
+    cannot converge -- the run falls back to blocked dpotrf + dpotri (gdca_stats.refined = 2).  Status as the reference's
+    `cholesky(C)` (src/GaussDCA.jl:34: LAPACK still factors these matrices), an inverse as accurate as LAPACK's on columns refined
+    in extended precision, scores within what that conditioning leaves of them."""
+    g, o, ctx = env
+    from gaussdca.jl_amd import synth
+
+    Zo = synth.synth_family(430, 600, 21, 0x1C0D)
+    S_o = o.scores_from_Z(Zo, 21, pc, "auto", "frob")       # LAPACK: no exception
+    S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 0)
+    assert st["info"] == 0 and st["refined"] == 2, st
+    u = 2.0 ** -53
+    dev = float(np.abs(S - S_o).max() / np.abs(S_o).max())
+    print("\npc=%g: ||X||_1 = %.2e, max |dS| / max |S| = %.2e (||X||_1 u = %.1e)" % (pc, st["inverse_norm1"], dev, st["inverse_norm1"] * u))
+    assert np.isfinite(S).all() and dev <= 2.0 * st["inverse_norm1"] * u
+    if pc < 1e-9:
+        return   # (beyond cond ~1e14 the extended-precision reference itself stops converging)
+    C = _covariance(o, Zo, 21, pc)
+    rng = np.random.default_rng(3)
+    cols = sorted(set(int(c) for c in rng.integers(0, C.shape[0], size=4)) | {0, C.shape[0] - 1})
+    X_dev = g.inv_cholesky(C, ctx=ctx)
+    X_lap = o.spd_inverse(C)
+    ref = _refined_columns(C, cols, iters=30)
+    scale = max(float(np.max(np.abs(x))) for x in ref)
+    e_dev, e_lap = (max(float(np.max(np.abs(X[:, j].astype(np.longdouble) - x))) for j, x in zip(cols, ref)) / scale for X in (X_dev, X_lap))
+    print("forward error on refined columns: device %.2e, LAPACK %.2e" % (e_dev, e_lap))
+    assert e_dev <= 8.0 * e_lap + 64 * u
+
+
+@pytest.mark.parametrize("n", [100, 129, 1000, 2689])
+def test_cholesky_fallback_is_potrf_potri(env, n):
+    """The fallback on its own (option CHOLESKY=2: every inverse goes through it) on well-conditioned matrices, one to 22 blocks,
+    ragged last block: LAPACK's inverse to rounding, symmetric, reproducible; the index of a non-positive pivot is dpotrf's."""
+    g, o, ctx = env
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n + 50))
+    C = A @ A.T / (n + 50) + 0.05 * np.eye(n)
+    ctx.set_option("CHOLESKY", 2)
+    try:
+        X = g.inv_cholesky(C, ctx=ctx)
+        X2 = g.inv_cholesky(C, ctx=ctx)
+        X_l = o.spd_inverse(C)
+        assert np.array_equal(X, X.T) and np.array_equal(X, X2)
+        assert float(np.abs(X - X_l).max() / np.abs(X_l).max()) < 1e-12
+        for bad in sorted({0, n // 3, n - 1}):
+            Cb = C.copy()
+            Cb[bad, bad] = -1.0
+            with pytest.raises(o.NotPositiveDefinite) as eo:
+                o.spd_inverse(Cb)
+            with pytest.raises(g.PosDefException) as eg:
+                g.inv_cholesky(Cb, ctx=ctx)
+            assert eg.value.info == eo.value.info == bad + 1
+        # the fused path through it: the scores of a small family, against the oracle
+        from gdca_testutil import random_msa
+
+        Zo = random_msa(np.random.default_rng(n + 1), 300, 40)
+        S, st = ctx.run(np.asfortranarray(Zo.T), 21, 0.8, -1.0, 1)
+        assert st["refined"] == 2
+        ok, max_rel, _ = score_close(S, o.scores_from_Z(Zo, 21, 0.8, "auto", "DI"), atol_abs=4.0 * 20 * 2.0 ** -53 * 16)
+        assert ok, max_rel
+    finally:
+        ctx.set_option("CHOLESKY", 1)
