@@ -126,6 +126,9 @@ SYMBOLS = {
     "gdca_remove_duplicates": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32p]),
     "gdca_ranking_length": (C.c_int64, [C.c_int32, C.c_int32]),
     "gdca_ranking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdca_ranking_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdca_run_ranked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_write_rank": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "gdca_synth_family": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p]),
     "gdca_write_fasta": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -240,6 +243,30 @@ class Context:
         rc = self.lib.gdca_run(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), _p(S), C.byref(st))
         self.check(rc, st.info)
         return S, st.as_dict()
+
+    def run_ranked_ptr(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int, min_separation: int,
+                       apc: bool = True):
+        """gdca_run_ranked on a HOST matrix given by address: src/GaussDCA.jl:28-44 in one call, the ranking is sorted on the
+        device and only it comes back.  Returns (i, j, score, stats): int32, int32, float64 arrays."""
+        n = max(int(self.lib.gdca_ranking_length(int(N), int(min_separation))), 0)
+        ii = np.empty(n, dtype=np.int32)
+        jj = np.empty(n, dtype=np.int32)
+        sc = np.empty(n, dtype=np.float64)
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        st = Stats()
+        rc = self.lib.gdca_run_ranked(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), int(min_separation), _p(ii), _p(jj),
+                                      _p(sc), C.byref(st))
+        self.check(rc, st.info)
+        return ii, jj, sc, st.as_dict()
+
+    def ranking_dev(self, S_ptr: int, N: int, min_separation: int):
+        """compute_ranking of a score matrix in HBM (device pointer), sorted on the device: (i, j, score) host arrays."""
+        n = max(int(self.lib.gdca_ranking_length(int(N), int(min_separation))), 0)
+        ii = np.empty(n, dtype=np.int32)
+        jj = np.empty(n, dtype=np.int32)
+        sc = np.empty(n, dtype=np.float64)
+        self.check(self.lib.gdca_ranking_dev(self.h, C.c_void_p(S_ptr), int(N), int(min_separation), _p(ii), _p(jj), _p(sc)))
+        return ii, jj, sc
 
     def run_dev(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int,
                 S_ptr: int, apc: bool = True):

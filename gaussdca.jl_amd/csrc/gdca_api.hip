@@ -39,6 +39,7 @@ struct gdca_ctx {
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
     gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
     gdca_buf Wd;                  // Cholesky fallback: the inverses of the diagonal tiles of the factor
+    gdca_buf rankws;              // device ranking: keys, values, histograms, the three output arrays
     hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
     int ncu;                   // compute units of the device
     int *item0_host;           // pinned staging of the sweep's item table
@@ -309,7 +310,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
-                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd, &ctx->rankws};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -1043,6 +1044,65 @@ gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, 
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return GDCA_OK;
+}
+
+// ---- compute_ranking on the device (src/GaussDCA.jl:88-99, call :44) ---------------------------------------
+static gdca_status ranking_stage(gdca_ctx *ctx, const double *S_dev, int N, int sep, long long len, int32_t **ii, int32_t **jj, double **sc)
+{
+    CHK(ensure(ctx, ctx->rankws, gdca_ranking_ws_bytes(len)));
+    gdca_launch_ranking(ctx->stream, S_dev, N, sep, len, ctx->rankws.p, ii, jj, sc);
+    return check_launch(ctx, "ranking");
+}
+
+static gdca_status ranking_to_host(gdca_ctx *ctx, long long len, const int32_t *ii, const int32_t *jj, const double *sc, int32_t *i_out, int32_t *j_out,
+                                   double *score_out)
+{
+    HIPCHK(hipMemcpyAsync(i_out, ii, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(j_out, jj, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(score_out, sc, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GDCA_OK;
+}
+
+gdca_status gdca_ranking_dev(gdca_ctx *ctx, const double *S_dev, int32_t N, int32_t min_separation, int32_t *i_out, int32_t *j_out, double *score_out)
+{
+    if (!ctx || !S_dev || N < 1 || N > 65535 || min_separation < 1) return GDCA_EINVAL;
+    CHK(not_pending(ctx));
+    HIPCHK(hipSetDevice(ctx->device));
+    const long long len = gdca_ranking_length(N, min_separation);
+    if (len == 0) return GDCA_OK;
+    if (!i_out || !j_out || !score_out) return GDCA_EINVAL;
+    int32_t *ii, *jj;
+    double *sc;
+    CHK(ranking_stage(ctx, S_dev, N, min_separation, len, &ii, &jj, &sc));
+    return ranking_to_host(ctx, len, ii, jj, sc, i_out, j_out, score_out);
+}
+
+gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation,
+                            int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+{
+    CHK(validate(ctx, N, M, q));
+    if (!Z_host || min_separation < 1) return fail(ctx, GDCA_EINVAL, "null pointer or min_separation < 1%s%s", "", "");
+    const long long len = gdca_ranking_length(N, min_separation);
+    if (len > 0 && (!i_out || !j_out || !score_out)) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->scratch[0], (size_t)N * M));
+    CHK(ensure(ctx, ctx->scratch[1], (size_t)N * N * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z_host, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
+    double *S_dev = (double *)ctx->scratch[1].p;
+    CHK(gdca_run_dev_async(ctx, (const int8_t *)ctx->scratch[0].p, N, M, q, p, S_dev));
+    // the ranking is enqueued behind the scores before anybody waits: one synchronisation for the whole run
+    int32_t *ii = nullptr, *jj = nullptr;
+    double *sc = nullptr;
+    gdca_status rs = len > 0 ? ranking_stage(ctx, S_dev, N, min_separation, len, &ii, &jj, &sc) : GDCA_OK;
+    gdca_stats own;
+    gdca_status cs = gdca_run_collect(ctx, st ? st : &own);
+    if (cs != GDCA_OK) return cs;
+    if (rs != GDCA_OK) return rs;
+    if (len == 0) return GDCA_OK;
+    // (a run whose inverse was refined or recomputed at collect time has new scores: rank those)
+    if (ctx->pend_refined != 0) CHK(ranking_stage(ctx, S_dev, N, min_separation, len, &ii, &jj, &sc));
+    return ranking_to_host(ctx, len, ii, jj, sc, i_out, j_out, score_out);
 }
 
 // ---- caller-visible device buffers ----------------------------------------------------------------------

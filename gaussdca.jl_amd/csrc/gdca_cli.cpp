@@ -145,12 +145,20 @@ bool load_family(const Options &o, Family &f)
     return true;
 }
 
-// the hot path for one parsed family on one context: S (N x N) comes back
-bool compute(gdca_ctx *ctx, const Options &o, const Family &f, std::vector<double> &S, gdca_stats *st, std::string *err)
+// the ranking of one family as the library hands it back (src/GaussDCA.jl:28-44: hot path + compute_ranking on the device)
+struct RankOut {
+    std::vector<int32_t> i, j;
+    std::vector<double> s;
+};
+
+bool compute(gdca_ctx *ctx, const Options &o, const Family &f, RankOut &R, gdca_stats *st, std::string *err)
 {
-    S.resize((size_t)f.N * f.N);
+    const int64_t len = std::max<int64_t>(gdca_ranking_length(f.N, o.min_separation), 0);
+    R.i.resize((size_t)len);
+    R.j.resize((size_t)len);
+    R.s.resize((size_t)len);
     gdca_params p{o.pseudocount, o.theta, o.score, 1};
-    const gdca_status rc = gdca_run(ctx, f.Z(), f.N, f.M, f.q, &p, S.data(), st);
+    const gdca_status rc = gdca_run_ranked(ctx, f.Z(), f.N, f.M, f.q, &p, o.min_separation, R.i.data(), R.j.data(), R.s.data(), st);
     if (rc == GDCA_ENOTPD) {
         *err = "PosDefException: matrix is not positive definite; Cholesky factorization failed (info " +
                std::to_string(st->info) + ")";
@@ -163,19 +171,13 @@ bool compute(gdca_ctx *ctx, const Options &o, const Family &f, std::vector<doubl
     return true;
 }
 
-// compute_ranking + printrank (src/GaussDCA.jl:88-99, :67-74): host work, off the GPU worker's thread in batch mode
-bool emit(const Options &o, const std::vector<double> &S, int32_t N, const std::string &out_path, std::string *err)
+// printrank (src/GaussDCA.jl:67-74): host work, off the GPU worker's thread in batch mode
+bool emit(const RankOut &R, const std::string &out_path, std::string *err)
 {
-    const int64_t len = gdca_ranking_length(N, o.min_separation);
-    std::vector<int32_t> ri((size_t)len), rj((size_t)len);
-    std::vector<double> rs((size_t)len);
-    if (gdca_ranking(S.data(), N, o.min_separation, ri.data(), rj.data(), rs.data()) != GDCA_OK) {
-        *err = "ranking failed";
-        return false;
-    }
+    const int64_t len = (int64_t)R.i.size();
     if (out_path.empty()) {
-        for (int64_t t = 0; t < len; ++t) printf("%i %i %e\n", ri[(size_t)t], rj[(size_t)t], rs[(size_t)t]);
-    } else if (gdca_write_rank(out_path.c_str(), ri.data(), rj.data(), rs.data(), len) != GDCA_OK) {
+        for (int64_t t = 0; t < len; ++t) printf("%i %i %e\n", R.i[(size_t)t], R.j[(size_t)t], R.s[(size_t)t]);
+    } else if (gdca_write_rank(out_path.c_str(), R.i.data(), R.j.data(), R.s.data(), len) != GDCA_OK) {
         *err = "cannot write " + out_path;
         return false;
     }
@@ -185,8 +187,8 @@ bool emit(const Options &o, const std::vector<double> &S, int32_t N, const std::
 bool process(gdca_ctx *ctx, const Options &o, const Family &f, const std::string &out_path, gdca_stats *st,
              std::string *err)
 {
-    std::vector<double> S;
-    return compute(ctx, o, f, S, st, err) && emit(o, S, f.N, out_path, err);
+    RankOut R;
+    return compute(ctx, o, f, R, st, err) && emit(R, out_path, err);
 }
 
 bool has_suffix(const std::string &s, const char *suf)
@@ -368,11 +370,10 @@ int run_batch(const Options &o)
             cv_ready.notify_all();
         }
     };
-    // rankings are sorted and written by their own threads: the GPU worker goes straight to the next family
+    // rankings (sorted on the device) are formatted and written by their own threads: the GPU worker goes straight to the next family
     struct Result {
         std::string name;
-        int32_t N;
-        std::vector<double> S;
+        RankOut R;
     };
     std::mutex omu;
     std::condition_variable cv_out;
@@ -389,7 +390,7 @@ int run_batch(const Options &o)
                 outq.pop_front();
             }
             std::string err;
-            if (!emit(o, r.S, r.N, o.out_dir + "/" + r.name + ".rank.txt", &err)) {
+            if (!emit(r.R, o.out_dir + "/" + r.name + ".rank.txt", &err)) {
                 fprintf(stderr, "ERROR: %s: %s\n", r.name.c_str(), err.c_str());
                 ++failures;
             }
@@ -430,7 +431,7 @@ int run_batch(const Options &o)
             std::string err;
             const double t = now();
             Result res;
-            const bool ok = compute(ctx, o, f, res.S, &st, &err);
+            const bool ok = compute(ctx, o, f, res.R, &st, &err);
             const double dt = now() - t;
             {
                 std::lock_guard<std::mutex> lk(omu);  // several workers per GPU share the counters
@@ -445,7 +446,6 @@ int run_batch(const Options &o)
             fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", devs[(size_t)g],
                     f.name.c_str(), f.N, f.M, f.q, st.theta, st.Meff, f.parse_s, st.ms_total, dt);
             res.name = f.name;
-            res.N = f.N;
             {
                 std::lock_guard<std::mutex> lk(omu);
                 outq.push_back(std::move(res));

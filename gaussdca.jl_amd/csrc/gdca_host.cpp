@@ -30,6 +30,7 @@
 #endif
 
 #include "gdca.h"
+#include "gdca_inflate.h"
 
 // The parsed matrix lives in a buffer that is NOT zero-filled (the reader overwrites every byte it keeps; zero-filling 50 MB per
 // family is a serial 10 ms) and that is REUSED: gdca_fasta_close hands it to a small process-wide pool, the next gdca_fasta_open
@@ -250,7 +251,7 @@ bool slurp(const char *path, FileText &out)
     // after the other, as gzread would): no gz* stream layer with its own megabyte buffers allocated and freed per file
     static thread_local std::string zin;
     if (zin.capacity() > ((size_t)256 << 20) && zin.capacity() > 4 * fsz) std::string().swap(zin);
-    if (zin.size() < fsz) zin.resize(fsz);
+    if (zin.size() < fsz + GDCA_INFLATE_PAD) zin.resize(fsz + GDCA_INFLATE_PAD);
     size_t got = 0;
     while (got < fsz) {
         const ssize_t n = pread(fd, &zin[got], fsz - got, (off_t)got);
@@ -259,6 +260,17 @@ bool slurp(const char *path, FileText &out)
     }
     close(fd);
     if (got != fsz) return false;
+    // the project's own decoder first (gdca_inflate.cpp: 2-3x zlib's inflate on alignment text, CRC-32 and ISIZE verified); whatever
+    // it does not accept is decoded again by zlib below, whose verdict stands.  GDCA_FASTA_ZLIB=1: zlib only (A/B measurements).
+    {
+        static const bool zlib_only = getenv("GDCA_FASTA_ZLIB") != nullptr;
+        memset(&zin[fsz], 0, GDCA_INFLATE_PAD);
+        size_t len = 0;
+        if (!zlib_only && gdca_gunzip_fast((const uint8_t *)zin.data(), fsz, buf, &len, hint)) {
+            out.text = std::string_view(buf.data(), len);
+            return true;
+        }
+    }
     if (buf.size() < std::max<size_t>(hint, 1 << 16)) buf.resize(std::max<size_t>(hint, 1 << 16));
     z_stream zs;
     memset(&zs, 0, sizeof(zs));

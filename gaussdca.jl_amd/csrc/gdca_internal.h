@@ -153,6 +153,11 @@ void gdca_launch_spd_inverse(hipStream_t s, const gdca_inverse_job &job, hipEven
 int gdca_inverse_max_merge(void);
 void gdca_launch_spd_inverse_merged(hipStream_t s, const gdca_inverse_job *jobs, int K, hipEvent_t *upd_ev, int max_upd_ev,
                                     double *upd_flops);
+// ---- k_rank.hip --------------------------------------------------------------------------
+// compute_ranking (src/GaussDCA.jl:88-99) of S_dev (N x N column-major): `len` = gdca_ranking_length(N, sep) > 0 entries, sorted,
+// left in three arrays inside the workspace `ws` (gdca_ranking_ws_bytes(len) bytes)
+size_t gdca_ranking_ws_bytes(long long len);
+void gdca_launch_ranking(hipStream_t s, const double *S_dev, int N, int sep, long long len, void *ws, int32_t **ii, int32_t **jj, double **sc);
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks);
 // The reference's own way (dpotrf + dpotri) as a fallback for matrices the sweep cannot handle: C2 (n_pad x n_pad, identity
 // padding; overwritten by its Cholesky factor), U and Tm: n_pad x n_pad workspaces, Wd: (n_pad / 128) tiles of 128 x 128; Aout

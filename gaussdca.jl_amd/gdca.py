@@ -1,8 +1,8 @@
 """gDCA(): host-side mirror of the reference's only entry point
 (/root/reference/src/GaussDCA.jl:8-47), same keyword arguments, defaults, validation order and
 messages (:49-65).  Everything between compute_weighted_frequencies (:28) and correct_APC (:42)
-is one call into libgdca.so (gdca_run): Z goes to the MI355X once, the N x N score matrix comes
-back; ranking and text output stay on the host as in the reference."""
+and compute_ranking (:44) is one call into libgdca.so (gdca_run_ranked): Z goes to the MI355X once,
+the sorted ranking comes back; text output stays on the host as in the reference."""
 from __future__ import annotations
 
 import os
@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import ArgumentError, default_context
-from .dcautils import (FastaAlignment, _theta_arg, compute_ranking, read_fasta_alignment, remove_duplicate_sequences)
+from .dcautils import (FastaAlignment, Ranking, _theta_arg, read_fasta_alignment, remove_duplicate_sequences)
 
 last_stats = None  # stats of the most recent gDCA call (theta, threshold, Meff, device timings)
 
@@ -62,7 +62,9 @@ def gDCA(filename: str, pseudocount: float = 0.8, theta=":auto", max_gap_fractio
         q = int(Z.max())
         if q >= 32:
             raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
-        S, last_stats = ctx.run(np.asfortranarray(Z), q, float(pseudocount), _theta_arg(theta), _score_arg(score), apc=True)
+        Zf = np.asfortranarray(Z, dtype=np.int8)
+        ii, jj, sc, last_stats = ctx.run_ranked_ptr(Zf.ctypes.data, Zf.shape[0], Zf.shape[1], q, float(pseudocount), _theta_arg(theta),
+                                                    _score_arg(score), int(min_separation), apc=True)
     else:
         # the parsed matrix goes to gdca_run where the native reader left it (gdca_fasta_data), q = maximum(Z) comes from the
         # reader (gdca_fasta_max_symbol): no copy into an array of the host language, no second pass over Z
@@ -70,11 +72,12 @@ def gDCA(filename: str, pseudocount: float = 0.8, theta=":auto", max_gap_fractio
             q = fa.q
             if q >= 32:
                 raise RuntimeError(f"parameter q={q} is too big (max 31 is allowed)")
-            S, last_stats = ctx.run_ptr(fa.ptr, fa.N, fa.M, q, float(pseudocount), _theta_arg(theta), _score_arg(score), apc=True)
+            ii, jj, sc, last_stats = ctx.run_ranked_ptr(fa.ptr, fa.N, fa.M, q, float(pseudocount), _theta_arg(theta), _score_arg(score),
+                                                        int(min_separation), apc=True)
     if last_stats.get("refined", 0) < 0:
         import warnings
 
         warnings.warn("gDCA: the covariance is too ill-conditioned for the block sweep even with its refinement step "
                       f"(||inv(C)||_1 = {last_stats['inverse_norm1']:.3g}; pseudocount {pseudocount}): scores are unreliable",
                       RuntimeWarning, stacklevel=2)
-    return compute_ranking(S, int(min_separation))
+    return Ranking(ii, jj, sc)

@@ -267,6 +267,14 @@ gdca_status gdca_remove_duplicates(const int8_t *Z, int32_t N, int32_t M, int8_t
 int64_t gdca_ranking_length(int32_t N, int32_t min_separation);
 gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int32_t *i_out, int32_t *j_out,
                          double *score_out);
+/* The same ranking computed on the device from a score matrix in HBM (N x N column-major, N <= 65535; a stable radix sort on the
+ * same key: entry for entry the result of gdca_ranking); outputs are host arrays of gdca_ranking_length entries. */
+gdca_status gdca_ranking_dev(gdca_ctx *ctx, const double *S_dev, int32_t N, int32_t min_separation, int32_t *i_out,
+                             int32_t *j_out, double *score_out);
+/* src/GaussDCA.jl:28-44 in one call: gdca_run followed by compute_ranking on the device -- Z (host) in, the ranking (host
+ * arrays of gdca_ranking_length(N, min_separation) entries) out; the N x N score matrix never crosses PCIe. */
+gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                            int32_t min_separation, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st);
 /* printrank(filename, R) (:67-74): one "%i %i %e" line per entry */
 gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len);
 

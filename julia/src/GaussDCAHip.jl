@@ -85,6 +85,24 @@ function hot_path(Z::Matrix{Int8}, q::Integer, pseudocount::Real, θ, score::Sym
     return S, st
 end
 
+# ... and src/GaussDCA.jl:28-44: the same followed by compute_ranking on the device; only the sorted ranking comes back
+function hot_path_ranked(Z::Matrix{Int8}, q::Integer, pseudocount::Real, θ, score::Symbol, min_separation::Integer)
+    N, M = size(Z)
+    len = max(ccall((:gdca_ranking_length, libgdca), Int64, (Int32, Int32), N, min_separation), 0)
+    ri = Vector{Int32}(undef, len)
+    rj = Vector{Int32}(undef, len)
+    rs = Vector{Float64}(undef, len)
+    p = Ref(GdcaParams(Float64(pseudocount), theta_arg(θ), score == :DI ? 1 : 0, 1))
+    st = GdcaStats()
+    GC.@preserve Z ri rj rs begin
+        rc = ccall((:gdca_run_ranked, libgdca), Cint,
+                   (Ptr{Cvoid}, Ptr{Int8}, Int32, Int32, Int32, Ref{GdcaParams}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{GdcaStats}),
+                   ctx(), Z, N, M, q, p, min_separation, ri, rj, rs, st)
+    end
+    check(rc, st.info)
+    return [(Int(ri[t]), Int(rj[t]), rs[t]) for t in 1:len], st
+end
+
 function gDCA(filename::AbstractString; pseudocount::Real = 0.8, θ = :auto, max_gap_fraction::Real = 0.9,
               score::Symbol = :frob, min_separation::Integer = 5, remove_dups::Bool = false)
     check_arguments(filename, pseudocount, θ, max_gap_fraction, score, min_separation)
@@ -94,8 +112,8 @@ function gDCA(filename::AbstractString; pseudocount::Real = 0.8, θ = :auto, max
     end
     q = Int(maximum(Z))
     q ≥ 32 && error("parameter q=$q is too big (max 31 is allowed)")
-    S, _ = hot_path(Z, q, pseudocount, θ, score)
-    return compute_ranking(S, min_separation)
+    R, _ = hot_path_ranked(Z, q, pseudocount, θ, score, min_separation)
+    return R
 end
 
 # ---- DCAUtils-named operators (call sites src/GaussDCA.jl:28,30,37,39) ----------------------

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE, not a fallback: stand-ins for the GPU-side entry points of include/gdca.h that gdca_cli.cpp calls
-// (gdca_device_count, gdca_ctx_create / destroy, gdca_run, gdca_last_error), so that the HOST code of the product --
+// (gdca_device_count, gdca_ctx_create / destroy, gdca_run, gdca_run_ranked, gdca_last_error), so that the HOST code of the product --
 // gdca_host.cpp (threaded FASTA reader, duplicate removal, ranking sort, writers) and gdca_cli.cpp (parser / worker / writer
 // queues of the batch mode) -- can run under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer on a machine
 // without a GPU (sanitizers on the CPU build only).  Linked ONLY into tests/_build/gdca_cli_{asan,tsan}
@@ -90,6 +90,19 @@ gdca_status gdca_run(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32
         st->n = N * (q - 1);
     }
     return GDCA_OK;
+}
+
+// (the product sorts on the device; the stand-in uses the host ranking of gdca_host.cpp, which the sanitizer builds link)
+gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation,
+                            int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+{
+    if (N < 1 || min_separation < 1) return GDCA_EINVAL;
+    double *S = (double *)malloc((size_t)N * N * sizeof(double));
+    if (!S) return GDCA_ENOMEM;
+    gdca_status rc = gdca_run(ctx, Z, N, M, q, p, S, st);
+    if (rc == GDCA_OK) rc = gdca_ranking(S, N, min_separation, i_out, j_out, score_out);
+    free(S);
+    return rc;
 }
 
 }  // extern "C"

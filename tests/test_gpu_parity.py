@@ -250,6 +250,58 @@ def test_not_positive_definite_is_reported_like_cholesky(g, ctx, o):
         ctx.run(Z, 21, 1.5, 0.3, 0)
 
 
+@pytest.mark.parametrize("N,sep", [(6, 1), (53, 5), (53, 52), (53, 60), (400, 5), (1000, 5), (1300, 1)])
+def test_device_ranking_equals_host_ranking(g, ctx, N, sep):
+    """compute_ranking (src/GaussDCA.jl:88-99) sorted on the device (gdca_ranking_dev: what gdca_run_ranked and gDCA() return)
+    against the host form, entry for entry: indices bit-exact, ties in generation order, NaN first, 0.0 before -0.0, infinities."""
+    from gaussdca.jl_amd import dcautils
+
+    rng = np.random.default_rng(N * 131 + sep)
+    variants = {
+        "continuous": rng.standard_normal((N, N)),
+        "heavy ties": np.round(rng.standard_normal((N, N)) * 3.0) / 3.0,           # a few dozen distinct values, many zeros
+        "all equal": np.full((N, N), 0.25),
+        "specials": rng.standard_normal((N, N)),
+    }
+    sp = variants["specials"]
+    pick = rng.integers(0, 7, size=(N, N))
+    sp[pick == 0] = 0.0
+    sp[pick == 1] = -0.0
+    sp[pick == 2] = np.nan
+    sp[(pick == 3) & (rng.random((N, N)) < 0.1)] = np.inf
+    sp[(pick == 4) & (rng.random((N, N)) < 0.1)] = -np.inf
+    sp[(pick == 5) & (rng.random((N, N)) < 0.1)] = 5e-324                            # a subnormal
+    for name, S in variants.items():
+        S = np.asfortranarray(S)
+        want = dcautils.compute_ranking(S, sep)
+        buf = g.DeviceBuffer.from_array(ctx, S)
+        try:
+            ii, jj, sc = ctx.ranking_dev(buf.ptr, N, sep)
+        finally:
+            buf.free()
+        assert len(ii) == len(want) == max(N - sep, 0) * (max(N - sep, 0) + 1) // 2
+        assert np.array_equal(ii, want.i) and np.array_equal(jj, want.j), (name, N, sep)
+        assert np.array_equal(sc.view(np.uint64), want.score.view(np.uint64)), (name, N, sep)   # the same bits (NaN payloads, -0.0)
+
+
+def test_run_ranked_equals_run_plus_host_ranking(g, ctx):
+    """gdca_run_ranked = gdca_run + compute_ranking, also when the collect computes the scores again (a refined inverse)."""
+    from gaussdca.jl_amd import dcautils
+
+    rng = np.random.default_rng(77)
+    Zo = random_msa(rng, 500, 60)
+    Zf = np.asfortranarray(Zo.T)
+    for pc, score in ((0.8, 0), (0.2, 1), (1e-5, 0)):
+        S, st = ctx.run(Zf, 21, pc, -1.0, score)
+        want = dcautils.compute_ranking(S, 5)
+        ii, jj, sc, st2 = ctx.run_ranked_ptr(Zf.ctypes.data, 60, 500, 21, pc, -1.0, score, 5)
+        print("pc=%g: refined %d" % (pc, st["refined"]))
+        assert st2["refined"] == st["refined"]
+        assert np.array_equal(ii, want.i) and np.array_equal(jj, want.j) and np.array_equal(sc, want.score)
+    with pytest.raises(g.ArgumentError):
+        ctx.run_ranked_ptr(Zf.ctypes.data, 60, 500, 21, 0.8, -1.0, 0, 0)          # min_separation < 1 (src/GaussDCA.jl:59-60)
+
+
 def test_device_pointer_entry_and_determinism(g, ctx, o):
     import torch
 
