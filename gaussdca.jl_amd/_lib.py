@@ -127,6 +127,8 @@ SYMBOLS = {
     "gdca_ranking_length": (C.c_int64, [C.c_int32, C.c_int32]),
     "gdca_ranking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_ranking_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdca_run_ranked_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "gdca_run_ranked_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_run_ranked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_write_rank": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
@@ -256,6 +258,25 @@ class Context:
         st = Stats()
         rc = self.lib.gdca_run_ranked(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), int(min_separation), _p(ii), _p(jj),
                                       _p(sc), C.byref(st))
+        self.check(rc, st.info)
+        return ii, jj, sc, st.as_dict()
+
+    def run_ranked_async_ptr(self, Z_ptr: int, N: int, M: int, q: int, pseudocount: float, theta: float, score: int, min_separation: int,
+                             apc: bool = True):
+        """First half of gdca_run_ranked: upload + enqueue, no waiting for the GPU; pair with run_ranked_collect()."""
+        prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+        self.check(self.lib.gdca_run_ranked_async(self.h, C.c_void_p(Z_ptr), int(N), int(M), int(q), C.byref(prm), int(min_separation)))
+        self._ranked = (int(N), int(min_separation))
+
+    def run_ranked_collect(self):
+        """Second half: (i, j, score, stats) of the run enqueued by run_ranked_async_ptr."""
+        N, sep = getattr(self, "_ranked", (1, 1))
+        n = max(int(self.lib.gdca_ranking_length(N, sep)), 0)
+        ii = np.empty(n, dtype=np.int32)
+        jj = np.empty(n, dtype=np.int32)
+        sc = np.empty(n, dtype=np.float64)
+        st = Stats()
+        rc = self.lib.gdca_run_ranked_collect(self.h, _p(ii), _p(jj), _p(sc), C.byref(st))
         self.check(rc, st.info)
         return ii, jj, sc, st.as_dict()
 

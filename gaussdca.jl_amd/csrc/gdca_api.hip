@@ -40,6 +40,13 @@ struct gdca_ctx {
     gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
     gdca_buf Wd;                  // Cholesky fallback: the inverses of the diagonal tiles of the factor
     gdca_buf rankws;              // device ranking: keys, values, histograms, the three output arrays
+    // an enqueued ranked run (gdca_run_ranked_async): where its ranking will be, and whether enqueueing it worked
+    bool rank_pending = false;
+    long long rank_len = 0;
+    int rank_sep = 0;
+    gdca_status rank_status = GDCA_OK;
+    int32_t *rank_i = nullptr, *rank_j = nullptr;
+    double *rank_s = nullptr;
     hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
     int ncu;                   // compute units of the device
     int *item0_host;           // pinned staging of the sweep's item table
@@ -1078,31 +1085,52 @@ gdca_status gdca_ranking_dev(gdca_ctx *ctx, const double *S_dev, int32_t N, int3
     return ranking_to_host(ctx, len, ii, jj, sc, i_out, j_out, score_out);
 }
 
-gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation,
-                            int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation)
 {
     CHK(validate(ctx, N, M, q));
+    CHK(not_pending(ctx));
     if (!Z_host || min_separation < 1) return fail(ctx, GDCA_EINVAL, "null pointer or min_separation < 1%s%s", "", "");
     const long long len = gdca_ranking_length(N, min_separation);
-    if (len > 0 && (!i_out || !j_out || !score_out)) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
     HIPCHK(hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->scratch[0], (size_t)N * M));
     CHK(ensure(ctx, ctx->scratch[1], (size_t)N * N * sizeof(double)));
+    // (from pageable memory this copy holds the calling thread until the last byte is staged -- and overlaps whatever another
+    // context of the same device is computing meanwhile: the pipelined batch driver's upload of the NEXT family)
     HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z_host, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
     double *S_dev = (double *)ctx->scratch[1].p;
     CHK(gdca_run_dev_async(ctx, (const int8_t *)ctx->scratch[0].p, N, M, q, p, S_dev));
     // the ranking is enqueued behind the scores before anybody waits: one synchronisation for the whole run
-    int32_t *ii = nullptr, *jj = nullptr;
-    double *sc = nullptr;
-    gdca_status rs = len > 0 ? ranking_stage(ctx, S_dev, N, min_separation, len, &ii, &jj, &sc) : GDCA_OK;
+    ctx->rank_len = len;
+    ctx->rank_sep = min_separation;
+    ctx->rank_status = len > 0 ? ranking_stage(ctx, S_dev, N, min_separation, len, &ctx->rank_i, &ctx->rank_j, &ctx->rank_s) : GDCA_OK;
+    ctx->rank_pending = true;
+    return GDCA_OK;
+}
+
+gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+{
+    if (!ctx) return GDCA_EINVAL;
+    if (!ctx->rank_pending) return fail(ctx, GDCA_EINVAL, "no enqueued ranked run to collect%s%s", "", "");
+    ctx->rank_pending = false;
     gdca_stats own;
     gdca_status cs = gdca_run_collect(ctx, st ? st : &own);
     if (cs != GDCA_OK) return cs;
-    if (rs != GDCA_OK) return rs;
+    if (ctx->rank_status != GDCA_OK) return ctx->rank_status;
+    const long long len = ctx->rank_len;
     if (len == 0) return GDCA_OK;
+    if (!i_out || !j_out || !score_out) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
     // (a run whose inverse was refined or recomputed at collect time has new scores: rank those)
-    if (ctx->pend_refined != 0) CHK(ranking_stage(ctx, S_dev, N, min_separation, len, &ii, &jj, &sc));
-    return ranking_to_host(ctx, len, ii, jj, sc, i_out, j_out, score_out);
+    if (ctx->pend_refined != 0)
+        CHK(ranking_stage(ctx, ctx->pend_S, ctx->pend_N, ctx->rank_sep, len, &ctx->rank_i, &ctx->rank_j, &ctx->rank_s));
+    return ranking_to_host(ctx, len, ctx->rank_i, ctx->rank_j, ctx->rank_s, i_out, j_out, score_out);
+}
+
+gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation,
+                            int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+{
+    if (ctx && gdca_ranking_length(N, min_separation) > 0 && (!i_out || !j_out || !score_out)) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
+    CHK(gdca_run_ranked_async(ctx, Z_host, N, M, q, p, min_separation));
+    return gdca_run_ranked_collect(ctx, i_out, j_out, score_out, st);
 }
 
 // ---- caller-visible device buffers ----------------------------------------------------------------------

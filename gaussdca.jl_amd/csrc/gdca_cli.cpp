@@ -399,11 +399,29 @@ int run_batch(const Options &o)
     const double t0 = now();
     std::vector<double> busy((size_t)G, 0.0);
     std::vector<int> count((size_t)G, 0);
+    double first_done = 0.0, last_done = 0.0;  // completion times of the first and the last family (steady-state rate, start-up excluded)
+    int completed = 0;
+    // One worker thread per GPU drives a PIPELINE of --inflight contexts (the leader and its peers, gdca_ctx_create_peer): family k+1
+    // is uploaded and enqueued while family k computes, and family k is collected only when its context is needed again -- the GPU
+    // never waits for an upload, a download or the host's launch latencies.  (Round 3 ran --inflight independent workers with
+    // synchronous calls instead: their kernels interleaved without any order.)
     auto worker = [&](int g) {  // g = slot in `devs`
-        gdca_ctx *ctx = nullptr;
-        if (gdca_ctx_create(devs[(size_t)g], &ctx) != GDCA_OK) {
+        struct Slot {
+            gdca_ctx *ctx = nullptr;
+            bool busy = false;
+            Result res;
+            int32_t N = 0, M = 0, q = 0;
+            double parse_s = 0.0, t_start = 0.0;
+        };
+        const int K = std::max(1, o.inflight);
+        std::vector<Slot> slots((size_t)K);
+        bool created = gdca_ctx_create(devs[(size_t)g], &slots[0].ctx) == GDCA_OK;
+        for (int k = 1; k < K && created; ++k) created = gdca_ctx_create_peer(slots[0].ctx, &slots[(size_t)k].ctx) == GDCA_OK;
+        if (!created) {
             fprintf(stderr, "ERROR: cannot create a context on GPU %d\n", devs[(size_t)g]);
             ++failures;
+            for (int k = K - 1; k >= 0; --k)
+                if (slots[(size_t)k].ctx) gdca_ctx_destroy(slots[(size_t)k].ctx);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (--live_workers == 0) abort_parsers = true;
@@ -412,9 +430,56 @@ int run_batch(const Options &o)
             cv_ready.notify_all();
             return;
         }
-        for (;;) {
-            Family f;
+        double busy_s = 0.0;
+        int done = 0;
+        auto finish = [&](Slot &sl) {
+            const double t = now();
+            gdca_stats st{};
+            const gdca_status rc = gdca_run_ranked_collect(sl.ctx, sl.res.R.i.data(), sl.res.R.j.data(), sl.res.R.s.data(), &st);
+            sl.busy = false;
+            busy_s += now() - t;
+            ++done;
             {
+                std::lock_guard<std::mutex> lk(omu);
+                last_done = now();
+                if (completed++ == 0) first_done = last_done;
+            }
+            if (rc != GDCA_OK) {
+                if (rc == GDCA_ENOTPD)
+                    fprintf(stderr, "ERROR: %s: PosDefException: matrix is not positive definite; Cholesky factorization failed (info %d)\n",
+                            sl.res.name.c_str(), st.info);
+                else
+                    fprintf(stderr, "ERROR: %s: gdca_run failed: %s\n", sl.res.name.c_str(), gdca_last_error(sl.ctx));
+                ++failures;
+                return;
+            }
+            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", devs[(size_t)g],
+                    sl.res.name.c_str(), sl.N, sl.M, sl.q, st.theta, st.Meff, sl.parse_s, st.ms_total, now() - sl.t_start);
+            {
+                std::lock_guard<std::mutex> lk(omu);
+                outq.push_back(std::move(sl.res));
+            }
+            cv_out.notify_one();
+        };
+        for (size_t k = 0;; ++k) {
+            Slot &sl = slots[k % (size_t)K];
+            if (sl.busy) finish(sl);  // (round robin: the slot needed next holds the oldest run)
+            Family f;
+            bool got = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (!ready.empty()) {
+                    f = std::move(ready.front());
+                    ready.pop_front();
+                    got = true;
+                }
+            }
+            if (!got) {
+                // nothing parsed right now: hand over what has been computed (oldest first) before waiting for the parsers
+                for (int j = 1; j < K; ++j) {
+                    Slot &t = slots[(k + (size_t)j) % (size_t)K];
+                    if (t.busy) finish(t);
+                }
                 std::unique_lock<std::mutex> lk(mu);
                 cv_ready.wait(lk, [&] { return !ready.empty() || parsed_done >= jobs.size(); });
                 if (ready.empty()) break;
@@ -425,42 +490,46 @@ int run_batch(const Options &o)
             if (!f.error.empty()) {
                 fprintf(stderr, "ERROR: %s\n", f.error.c_str());
                 ++failures;
+                --k;  // the slot stays free
                 continue;
             }
-            gdca_stats st{};
-            std::string err;
             const double t = now();
-            Result res;
-            const bool ok = compute(ctx, o, f, res.R, &st, &err);
-            const double dt = now() - t;
-            {
-                std::lock_guard<std::mutex> lk(omu);  // several workers per GPU share the counters
-                busy[(size_t)g] += dt;
-                count[(size_t)g] += 1;
-            }
-            if (!ok) {
-                fprintf(stderr, "ERROR: %s: %s\n", f.name.c_str(), err.c_str());
+            const int64_t len = std::max<int64_t>(gdca_ranking_length(f.N, o.min_separation), 0);
+            sl.res = Result();
+            sl.res.name = f.name;
+            sl.res.R.i.resize((size_t)len);
+            sl.res.R.j.resize((size_t)len);
+            sl.res.R.s.resize((size_t)len);
+            sl.N = f.N;
+            sl.M = f.M;
+            sl.q = f.q;
+            sl.parse_s = f.parse_s;
+            sl.t_start = t;
+            gdca_params p{o.pseudocount, o.theta, o.score, 1};
+            const gdca_status rc = gdca_run_ranked_async(sl.ctx, f.Z(), f.N, f.M, f.q, &p, o.min_separation);
+            busy_s += now() - t;
+            if (rc != GDCA_OK) {
+                fprintf(stderr, "ERROR: %s: gdca_run failed: %s\n", f.name.c_str(), gdca_last_error(sl.ctx));
                 ++failures;
+                --k;
                 continue;
             }
-            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", devs[(size_t)g],
-                    f.name.c_str(), f.N, f.M, f.q, st.theta, st.Meff, f.parse_s, st.ms_total, dt);
-            res.name = f.name;
-            {
-                std::lock_guard<std::mutex> lk(omu);
-                outq.push_back(std::move(res));
-            }
-            cv_out.notify_one();
+            sl.busy = true;  // (the family's host matrix is no longer needed: it goes back to the reader's pool here)
         }
-        gdca_ctx_destroy(ctx);
+        for (size_t j = 0; j < (size_t)K; ++j) {  // (the loop left at position k: oldest first from there -- order does not matter for files)
+            if (slots[j].busy) finish(slots[j]);
+        }
+        {
+            std::lock_guard<std::mutex> lk(omu);
+            busy[(size_t)g] += busy_s;
+            count[(size_t)g] += done;
+        }
+        for (int k = K - 1; k >= 0; --k) gdca_ctx_destroy(slots[(size_t)k].ctx);
     };
     std::vector<std::thread> threads, writers;
-    // --inflight contexts per GPU: while one family's latency-bound pivot chain runs, another family's kernels fill
-    // the idle CUs (independent gdca_ctx objects on the same device, no ordering between them)
-    live_workers = std::max(1, o.inflight) * G;
+    live_workers = G;
     for (int p = 0; p < std::max(1, o.parsers); ++p) threads.emplace_back(parser);
-    for (int k = 0; k < std::max(1, o.inflight); ++k)
-        for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
+    for (int g = 0; g < G; ++g) threads.emplace_back(worker, g);
     for (int w = 0; w < std::max(2, 2 * G); ++w) writers.emplace_back(writer);
     for (auto &t : threads) t.join();
     {
@@ -473,6 +542,9 @@ int run_batch(const Options &o)
     if (abort_parsers) fprintf(stderr, "ERROR: no GPU worker could start; %zu families not processed\n", jobs.size());
     fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
             (double)jobs.size() / wall, failures.load());
+    if (completed > 1 && last_done > first_done)
+        fprintf(stderr, "  steady state (first to last completed family; process start, HIP initialisation and the first parse excluded): %.2f families/s\n",
+                (double)(completed - 1) / (last_done - first_done));
     for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", devs[(size_t)g], count[(size_t)g], busy[(size_t)g]);
     return failures.load() ? 1 : 0;
 }

@@ -275,6 +275,13 @@ gdca_status gdca_ranking_dev(gdca_ctx *ctx, const double *S_dev, int32_t N, int3
  * arrays of gdca_ranking_length(N, min_separation) entries) out; the N x N score matrix never crosses PCIe. */
 gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,
                             int32_t min_separation, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st);
+/* The same in two halves, for a host thread that keeps two contexts of one GPU busy (gdca_ctx_create_peer): _async uploads Z (the
+ * calling thread is held while a pageable Z is staged -- the GPU meanwhile works on what the other context enqueued) and enqueues
+ * hot path + ranking without waiting for them; _collect waits and brings the ranking back.  Between the two calls the context
+ * accepts nothing else (GDCA_EINVAL), and Z_host may be released as soon as _async has returned. */
+gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,
+                                  int32_t min_separation);
+gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st);
 /* printrank(filename, R) (:67-74): one "%i %i %e" line per entry */
 gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len);
 

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE, not a fallback: stand-ins for the GPU-side entry points of include/gdca.h that gdca_cli.cpp calls
-// (gdca_device_count, gdca_ctx_create / destroy, gdca_run, gdca_run_ranked, gdca_last_error), so that the HOST code of the product --
+// (gdca_device_count, gdca_ctx_create / create_peer / destroy, gdca_run, gdca_run_ranked and its _async / _collect halves, gdca_last_error), so that the HOST code of the product --
 // gdca_host.cpp (threaded FASTA reader, duplicate removal, ranking sort, writers) and gdca_cli.cpp (parser / worker / writer
 // queues of the batch mode) -- can run under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer on a machine
 // without a GPU (sanitizers on the CPU build only).  Linked ONLY into tests/_build/gdca_cli_{asan,tsan}
@@ -16,6 +16,12 @@
 struct gdca_ctx {
     int device;
     char err[128];
+    // an enqueued ranked run (gdca_run_ranked_async): the stand-in computes at once and keeps S until the collect
+    double *pend_S;
+    int32_t pend_N, pend_sep;
+    gdca_status pend_rc;
+    gdca_stats pend_st;
+    bool pending;
 };
 
 static std::atomic<int> g_live_contexts{0};
@@ -47,6 +53,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
 {
     if (!ctx) return GDCA_EINVAL;
     --g_live_contexts;
+    free(ctx->pend_S);
     free(ctx);
     return GDCA_OK;
 }
@@ -102,6 +109,37 @@ gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M
     gdca_status rc = gdca_run(ctx, Z, N, M, q, p, S, st);
     if (rc == GDCA_OK) rc = gdca_ranking(S, N, min_separation, i_out, j_out, score_out);
     free(S);
+    return rc;
+}
+
+gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
+{
+    return leader ? gdca_ctx_create(leader->device, out) : GDCA_EINVAL;
+}
+
+gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation)
+{
+    if (!ctx || ctx->pending || N < 1 || min_separation < 1) return GDCA_EINVAL;
+    free(ctx->pend_S);
+    ctx->pend_S = (double *)malloc((size_t)N * N * sizeof(double));
+    if (!ctx->pend_S) return GDCA_ENOMEM;
+    ctx->pend_rc = gdca_run(ctx, Z, N, M, q, p, ctx->pend_S, &ctx->pend_st);   // (Z is read here and not again: the caller may release it)
+    if (ctx->pend_rc == GDCA_EINVAL) return GDCA_EINVAL;                       // argument errors surface at once, as in the product
+    ctx->pend_N = N;
+    ctx->pend_sep = min_separation;
+    ctx->pending = true;
+    return GDCA_OK;
+}
+
+gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
+{
+    if (!ctx || !ctx->pending) return GDCA_EINVAL;
+    ctx->pending = false;
+    if (st) *st = ctx->pend_st;
+    gdca_status rc = ctx->pend_rc;
+    if (rc == GDCA_OK) rc = gdca_ranking(ctx->pend_S, ctx->pend_N, ctx->pend_sep, i_out, j_out, score_out);
+    free(ctx->pend_S);
+    ctx->pend_S = nullptr;
     return rc;
 }
 

@@ -302,6 +302,43 @@ def test_run_ranked_equals_run_plus_host_ranking(g, ctx):
         ctx.run_ranked_ptr(Zf.ctypes.data, 60, 500, 21, 0.8, -1.0, 0, 0)          # min_separation < 1 (src/GaussDCA.jl:59-60)
 
 
+def test_ranked_runs_pipelined_over_peer_contexts(g, ctx):
+    """gdca_run_ranked_async / _collect over a leader and its peer, driven the way `gdca_cli --batch` drives them (family k+1 is
+    uploaded and enqueued before family k is collected): the same rankings as synchronous runs; a context with an enqueued run
+    refuses everything else, a second collect is an error."""
+    rng = np.random.default_rng(31)
+    fams = [np.asfortranarray(random_msa(rng, M, N).T) for M, N in ((400, 40), (900, 75), (300, 130), (700, 55), (500, 90))]
+    want = [ctx.run_ranked_ptr(Z.ctypes.data, Z.shape[0], Z.shape[1], 21, 0.8, -1.0, 0, 5) for Z in fams]
+    lead = g.Context(0)
+    peer = lead.peer()
+    try:
+        slots = [lead, peer]
+        got = {}
+        busy = {}
+        for k, Z in enumerate(fams):
+            c = slots[k % 2]
+            if c in busy:
+                got[busy.pop(c)] = c.run_ranked_collect()
+            c.run_ranked_async_ptr(Z.ctypes.data, Z.shape[0], Z.shape[1], 21, 0.8, -1.0, 0, 5)
+            busy[c] = k
+            if k == 1:
+                with pytest.raises(g.ArgumentError):      # enqueued: nothing else on this context
+                    c.run_ranked_async_ptr(Z.ctypes.data, Z.shape[0], Z.shape[1], 21, 0.8, -1.0, 0, 5)
+                with pytest.raises(g.ArgumentError):
+                    c.run(Z, 21, 0.8, -1.0, 0)
+        for c, k in list(busy.items()):
+            got[k] = c.run_ranked_collect()
+        with pytest.raises(g.ArgumentError):
+            lead.run_ranked_collect()
+        for k in range(len(fams)):
+            for a, b in zip(got[k][:3], want[k][:3]):
+                assert np.array_equal(a, b), k
+            assert got[k][3]["Meff"] == want[k][3]["Meff"]
+    finally:
+        peer.close()
+        lead.close()
+
+
 def test_device_pointer_entry_and_determinism(g, ctx, o):
     import torch
 

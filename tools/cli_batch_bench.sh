@@ -17,6 +17,6 @@ print("generated", F, "families")
 PY
 du -sh $D/in | cut -f1
 for k in ${INFLIGHT:-1 2}; do
-  gaussdca.jl_amd/gdca_cli --batch $D/in --out $D/out --gpus 1 --inflight $k 2>&1 | tail -2
+  ${CLI:-gaussdca.jl_amd/gdca_cli} --batch $D/in --out $D/out --gpus 1 --inflight $k 2>&1 | tail -3
 done
 ls $D/out | wc -l
