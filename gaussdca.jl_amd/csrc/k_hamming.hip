@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[r][c] = 0;
+    bool all_beyond = false;  // the main loop ended early: every pair of the tile is at or beyond the threshold
 
     const uint32_t *Ag = Zb + (size_t)I * NPLANES * NW * GDCA_HTILE;
     const uint32_t *Bg = Zb + (size_t)J * NPLANES * NW * GDCA_HTILE;
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
             for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
-            if (__syncthreads_or((int)mn < thresh) == 0) break;
+            if (__syncthreads_or((int)mn < thresh) == 0) {
+                all_beyond = true;  // (uniform over the workgroup)
+                break;
+            }
         }
     }
 
@@ -216,19 +220,28 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         if (tid == 0 && rc[0]) atomicAdd(&sc->ham_cand, rc[0]);
         return;
     }
+    if (all_beyond) return;  // nothing of this tile counts (the usual end of a tile of unrelated sequences): no list, no atomics
     unsigned long long cand = 0ull;  // bit 8 r + c: pair (r, c) of this thread's micro-tile is a candidate (bound below the threshold)
     if constexpr (NP < NPLANES) {
         // candidates -> the tile's list in LDS (the bound can only be too small, so nothing else can be a neighbour); they are
         // counted by the refinement below and skipped by their owner's own count.  A tile with more candidates than the list
         // holds (a dense corner of a sparse family) takes several passes.
+        // (most threads hold no candidate at all: 32 three-way minima decide that, instead of 64 x 7 instructions of index tests)
+        uint32_t mn = acc[0][0];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
-                const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
-                if ((int)acc[r][c] < thresh && gr < M && gc < M && gr != gc) cand |= 1ull << (8 * r + c);
-            }
+            for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
+        if ((int)mn < thresh) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                    const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
+                    if ((int)acc[r][c] < thresh && gr < M && gc < M && gr != gc) cand |= 1ull << (8 * r + c);
+                }
+        }
         unsigned long long todo = cand;
         for (;;) {
             while (todo) {
@@ -272,34 +285,40 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         }
     }
 
-    // threshold, count (strict '<'), reduce over the workgroup
-    int rowc[8], colc[8];
+    // The exact form: threshold, count (strict '<'), reduce over the workgroup.  (The bound form has nothing left to count: every
+    // in-range pair whose bound is below the threshold went to the refinement above, which did the counting -- and as long as this
+    // block was compiled for it too, its never-true `acc < thresh && !candidate` kept the 64 accumulators alive across the
+    // refinement loop: 78 scratch stores and 74 loads per lane and tile, found with tools/kernel_resources.py.)
+    if constexpr (NP == NPLANES) {
+        int rowc[8], colc[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) rowc[r] = 0;
+        for (int r = 0; r < 8; ++r) rowc[r] = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) colc[c] = 0;
+        for (int c = 0; c < 8; ++c) colc[c] = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int gr = I * GDCA_HTILE + ty * 8 + r;
+        for (int r = 0; r < 8; ++r) {
+            const int gr = I * GDCA_HTILE + ty * 8 + r;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
-            const int gc = J * GDCA_HTILE + lc;
-            const bool ok = (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh) && !((cand >> (8 * r + c)) & 1ull);
-            rowc[r] += ok ? 1 : 0;
-            colc[c] += ok ? 1 : 0;
+            for (int c = 0; c < 8; ++c) {
+                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                const int gc = J * GDCA_HTILE + lc;
+                const bool ok = (gr < M) && (gc < M) && (gr != gc) && ((int)acc[r][c] < thresh);
+                rowc[r] += ok ? 1 : 0;
+                colc[c] += ok ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (rowc[r]) atomicAdd(&rc[ty * 8 + r], rowc[r]);
+        if (!diag) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                if (colc[c]) atomicAdd(&cc[lc], colc[c]);
+            }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-        if (rowc[r]) atomicAdd(&rc[ty * 8 + r], rowc[r]);
-    if (!diag) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
-            if (colc[c]) atomicAdd(&cc[lc], colc[c]);
-        }
-    }
+    (void)cand;
     __syncthreads();
     if (tid < GDCA_HTILE) {
         const int v = rc[tid];
