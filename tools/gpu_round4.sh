@@ -40,12 +40,17 @@ timeout 600 python tools/stress_merged.py --rounds 40 --seed 11 > $out/stress_me
 timeout 600 python tools/stress_inverse.py > $out/stress_inverse.log 2>&1 < /dev/null; tail -1 $out/stress_inverse.log
 # conditioning (sweep alone / default path / LAPACK against refined columns)
 timeout 1200 python -m pytest tests/test_gpu_conditioning.py -m gpu -q -s -p no:cacheprovider > $out/conditioning.log 2>&1 < /dev/null; grep "cond(C)\|passed\|failed" $out/conditioning.log | cut -c1-400
+# the blocked Cholesky fallback against LAPACK (every inverse through it), status parity at tiny pseudocounts
+PYTHONPATH=tests timeout 600 python tools/chol_probe.py --families > $out/chol_probe.txt 2>&1 < /dev/null; tail -1 $out/chol_probe.txt
 # end to end, host feed, vmcnt ordering micro-benchmark
 timeout 200 python tools/e2e_profile.py C 5 > $out/e2e_profile_C.log 2>&1 < /dev/null
 timeout 200 python tools/e2e_profile.py D 3 > $out/e2e_profile_D.log 2>&1 < /dev/null
 ( cat /sys/fs/cgroup/cpu.max; nproc ) > $out/host_cpus.log 2>&1
 PASSES=6 timeout 900 bash tools/parse_bench.sh 128 /tmp/gdca_pb "1 8 16 32 64" > $out/parse_bench.log 2>&1 < /dev/null
-INFLIGHT="1 2" timeout 600 bash tools/cli_batch_bench.sh 128 /tmp/gdca_cb > $out/cli_batch.log 2>&1 < /dev/null
+GDCA_FASTA_ZLIB=1 PASSES=6 timeout 600 bash tools/parse_bench.sh 128 /tmp/gdca_pb "1 16" > $out/parse_bench_zlib.log 2>&1 < /dev/null
+timeout 300 bash tools/experiments/inflate/ab.sh > $out/inflate_ab.log 2>&1 < /dev/null
+INFLIGHT="1 2 3" timeout 600 bash tools/cli_batch_bench.sh 128 /tmp/gdca_cb > $out/cli_batch.log 2>&1 < /dev/null
+timeout 600 python bench.py --config E --families 128 --no-cpu-baseline > $out/bench_E128.json 2> $out/bench_E128.err < /dev/null   # the device-resident rate the CLI is compared with
 [ -x tools/_bin/rank_time ] && ( tools/_bin/rank_time 500; tools/_bin/rank_time 1000 ) > $out/rank_time.log 2>&1 < /dev/null
 [ -x tools/_bin/ubench_vmcnt_order ] && timeout 120 tools/_bin/ubench_vmcnt_order 1000 > $out/ubench_vmcnt_order.log 2>&1 < /dev/null
 # kernel-trace + stats of the driver's hot path (profiled timings are not compared with un-profiled ones), both scores
