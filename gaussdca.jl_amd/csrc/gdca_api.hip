@@ -659,6 +659,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     if (!ctx->pending) return fail(ctx, GDCA_EINVAL, "no enqueued run to collect%s%s", "", "");
     HIPCHK(hipSetDevice(ctx->device));
     ctx->pending = false;
+    ctx->rank_pending = false;  // (collected through this entry, a ranked run's ranking is given up: its arrays are scratch of the next run)
     CHK(fetch_scalars(ctx));
     if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
         (ctx->tune.refine == 1 || ctx->sc_host->inv_diagmax * 256.0 > ctx->tune.refine_cond)) {

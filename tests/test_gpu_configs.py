@@ -55,8 +55,18 @@ def _synth(N, M, seed):
 
 
 def _top_order_equal(g, o, S, S_o, top=200):
+    """The first `top` pairs in the oracle's order, and the WHOLE ranking as an ordering of the oracle's scores: the same set of
+    pairs, and walking down the device's ranking the oracle's score never rises by more than the 1e-6 bar allows -- i.e. the
+    two rankings can differ only by swaps among pairs whose scores the bar does not separate (VERDICT r03 weak spot 1b)."""
     R, R_o = g.compute_ranking(S, 5), o.compute_ranking(S_o, 5)
-    return [t[:2] for t in R[:top]] == [t[:2] for t in R_o[:top]]
+    if [t[:2] for t in R[:top]] != [t[:2] for t in R_o[:top]]:
+        return False
+    ii, jj = np.asarray(R.i, dtype=np.int64) - 1, np.asarray(R.j, dtype=np.int64) - 1
+    if sorted(zip(ii.tolist(), jj.tolist())) != sorted((t[0] - 1, t[1] - 1) for t in R_o):
+        return False
+    along = S_o[jj, ii]                                   # the oracle's scores in the device's order
+    rises = along[1:] - along[:-1]
+    return bool(rises.max() <= 2e-6 * float(np.abs(S_o).max()))
 
 
 # ---- B -------------------------------------------------------------------------------------------------------------
