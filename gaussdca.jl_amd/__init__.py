@@ -5,7 +5,7 @@ DCAUtils-named operators are in :mod:`dcautils`.  All hot-path arithmetic runs i
 library ``libgdca.so`` (C-ABI: include/gdca.h); importing this package never falls back to a
 CPU implementation -- calling any operator without the built library or without a GPU raises.
 """
-from ._lib import run_dev_phased, spd_inverse_batch_dev  # noqa: F401
+from ._lib import run_dev_phased, run_ranked_phased_async, spd_inverse_batch_dev  # noqa: F401
 from ._lib import (ArgumentError, Context, ConvergenceError, DeviceBuffer, GdcaError, PosDefException,  # noqa: F401
                    default_context, load)
 from .dcautils import (add_pseudocount, compute_C, compute_DI_gauss, compute_FN, compute_ranking,  # noqa: F401

@@ -128,6 +128,7 @@ SYMBOLS = {
     "gdca_ranking": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_ranking_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_run_ranked_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "gdca_run_ranked_phased_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "gdca_run_ranked_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdca_run_ranked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -326,6 +327,20 @@ def run_dev_phased(ctxs, Z_ptrs, Ns, Ms, qs, pseudocount: float, theta: float, s
     i32 = lambda v: (C.c_int32 * K)(*[int(x) for x in v])  # noqa: E731
     # (the library copies a failing member's message to the leader: ctxs[0]'s last_error names the member)
     ctxs[0].check(ctxs[0].lib.gdca_run_dev_phased(hs, K, zp, i32(Ns), i32(Ms), i32(qs), C.byref(prm), sp))
+
+
+def run_ranked_phased_async(ctxs, Z_ptrs, Ns, Ms, qs, pseudocount: float, theta: float, score: int, min_separation: int, apc: bool = True):
+    """K families (HOST matrices given by address) through gdca_run_ranked_phased_async: uploads, the phase-batched hot path with
+    the small inverses merged, every member's ranking; nothing waited for.  run_ranked_collect() each context afterwards."""
+    K = len(ctxs)
+    assert K >= 1 and len(Z_ptrs) == len(Ns) == len(Ms) == len(qs) == K
+    prm = Params(float(pseudocount), float(theta), int(score), 1 if apc else 0)
+    hs = (_ctx * K)(*[c.h for c in ctxs])
+    zp = (C.c_void_p * K)(*[C.c_void_p(int(z)) for z in Z_ptrs])
+    i32 = lambda v: (C.c_int32 * K)(*[int(x) for x in v])  # noqa: E731
+    ctxs[0].check(ctxs[0].lib.gdca_run_ranked_phased_async(hs, K, zp, i32(Ns), i32(Ms), i32(qs), C.byref(prm), int(min_separation)))
+    for c, n in zip(ctxs, Ns):
+        c._ranked = (int(n), int(min_separation))
 
 
 def spd_inverse_batch_dev(ctxs, A_ptrs, ns):

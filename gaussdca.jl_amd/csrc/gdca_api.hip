@@ -1108,6 +1108,55 @@ gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z_host, int32_t N
     return GDCA_OK;
 }
 
+gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_host, const int32_t *N, const int32_t *M,
+                                         const int32_t *q, const gdca_params *p, int32_t min_separation)
+{
+    if (!ctxs || K < 1 || K > 64 || !Z_host || !N || !M || !q || !p) return GDCA_EINVAL;
+    gdca_ctx *lead = ctxs[0];
+    if (!lead) return GDCA_EINVAL;
+    gdca_ctx *ctx = lead;  // (the error macros' context)
+    if (min_separation < 1) return fail(lead, GDCA_EINVAL, "min_separation < 1%s%s", "", "");
+    const int8_t *Zd[64];
+    double *Sd[64];
+    for (int k = 0; k < K; ++k) {
+        gdca_ctx *m = ctxs[k];
+        if (!m || !Z_host[k]) return fail(lead, GDCA_EINVAL, "null context or alignment in the batch%s%s", "", "");
+        gdca_status vs = validate(m, N[k], M[k], q[k]);
+        if (vs == GDCA_OK) vs = not_pending(m);
+        if (vs != GDCA_OK) {
+            if (k > 0) {
+                char msg[sizeof(lead->err)];
+                snprintf(msg, sizeof(msg), "member %d: %.400s", k, m->err);
+                memcpy(lead->err, msg, sizeof(msg));
+            }
+            return vs;
+        }
+    }
+    HIPCHK(hipSetDevice(lead->device));
+    for (int k = 0; k < K; ++k) {
+        gdca_ctx *m = ctxs[k];
+        gdca_status es = ensure(m, m->scratch[0], (size_t)N[k] * M[k]);
+        if (es == GDCA_OK) es = ensure(m, m->scratch[1], (size_t)N[k] * N[k] * sizeof(double));
+        if (es != GDCA_OK) return es;
+        // (each member's upload goes to its own stream; gdca_run_dev_phased waits for the members' streams before it enqueues
+        // anything, and the leader's upload sits on the very stream the batch is enqueued on)
+        if (hipMemcpyAsync(m->scratch[0].p, Z_host[k], (size_t)N[k] * M[k], hipMemcpyHostToDevice, m->stream) != hipSuccess)
+            return fail(lead, GDCA_EHIP, "upload of a member's alignment%s%s", "", "");
+        Zd[k] = (const int8_t *)m->scratch[0].p;
+        Sd[k] = (double *)m->scratch[1].p;
+    }
+    CHK(gdca_run_dev_phased(ctxs, K, Zd, N, M, q, p, Sd));
+    // every member's ranking behind its scores, on the member's own stream (which now waits for the batch)
+    for (int k = 0; k < K; ++k) {
+        gdca_ctx *m = ctxs[k];
+        m->rank_len = gdca_ranking_length(N[k], min_separation);
+        m->rank_sep = min_separation;
+        m->rank_status = m->rank_len > 0 ? ranking_stage(m, Sd[k], N[k], min_separation, m->rank_len, &m->rank_i, &m->rank_j, &m->rank_s) : GDCA_OK;
+        m->rank_pending = true;
+    }
+    return GDCA_OK;
+}
+
 gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
 {
     if (!ctx) return GDCA_EINVAL;

@@ -39,7 +39,7 @@ struct Options {
     int score = GDCA_SCORE_FROB, min_separation = 5;
     bool remove_dups = false;
     std::string batch_dir, out_dir;
-    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1;
+    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1, merge = 1 /* small families per merged batch (--merge K, up to 8); 1 = off: see the worker */, merge_blocks = 24 /* largest covariance of a "small" family, in 128-blocks */;
     bool parse_only = false;
     std::vector<std::string> positional;
 };
@@ -461,9 +461,55 @@ int run_batch(const Options &o)
             }
             cv_out.notify_one();
         };
+        // Small families (covariance of at most --merge-blocks 128-blocks: chain-bound inverses that leave most of the chip idle) do
+        // not go through the slots one by one but up to --merge at a time through gdca_run_ranked_phased_async: one phase-batched
+        // run whose SPD inverses share launches of the sweep kernel.  Two sets of contexts take turns, so that the next batch is
+        // uploaded and enqueued while the previous one computes; they are created when the first small family shows up -- as peers
+        // of the pipeline's leader: ONE gate orders every SPD inverse of this GPU, single or merged (two persistent sweep launches
+        // that become resident side by side can wait for each other's workgroups until the watchdog ends them).
+        // OFF by default (--merge 1).  Measured on one MI355X (profiles/r04_cli_merge.log): 96 families of config B's size run at
+        // 630-650 families/s in steady state through the slots' pipeline and at 650-660 through merged batches of eight -- the
+        // worker thread's uploads, ~60 launches per family and collects bound both -- while creating the sixteen extra contexts
+        // costs 0.25 s; on the mixed batch of configuration E merged batches lose 2-4 % (the phase-batched front ends are slower
+        // than pipelined ones).  The merged sweep pays where the caller keeps data on the device
+        // (gdca_run_dev_phased: 1.55 -> 1.19 ms per family at config B); here it is an option for batches of tiny families
+        // on hosts with faster cores.
+        const int SMALL_BLOCKS = o.merge_blocks;
+        struct Set {
+            std::vector<Slot> mem;
+            int used = 0;
+        };
+        Set sets[2];
+        int cur_set = 0;
+        bool sets_ok = true;
+        auto is_small = [&](const Family &f) { return o.merge > 1 && ((long long)f.N * (f.q - 1) + 127) / 128 <= SMALL_BLOCKS; };
+        auto finish_set = [&](Set &st) {
+            for (int m = 0; m < st.used; ++m)
+                if (st.mem[(size_t)m].busy) finish(st.mem[(size_t)m]);
+            st.used = 0;
+        };
+        auto drain = [&](size_t k) {
+            for (int j = 0; j < K; ++j) {
+                Slot &t = slots[(k + (size_t)j) % (size_t)K];
+                if (t.busy) finish(t);
+            }
+            finish_set(sets[cur_set]);
+            finish_set(sets[cur_set ^ 1]);
+        };
+        auto fill_slot = [&](Slot &sl, const Family &f, double t) {
+            const int64_t len = std::max<int64_t>(gdca_ranking_length(f.N, o.min_separation), 0);
+            sl.res = Result();
+            sl.res.name = f.name;
+            sl.res.R.i.resize((size_t)len);
+            sl.res.R.j.resize((size_t)len);
+            sl.res.R.s.resize((size_t)len);
+            sl.N = f.N;
+            sl.M = f.M;
+            sl.q = f.q;
+            sl.parse_s = f.parse_s;
+            sl.t_start = t;
+        };
         for (size_t k = 0;; ++k) {
-            Slot &sl = slots[k % (size_t)K];
-            if (sl.busy) finish(sl);  // (round robin: the slot needed next holds the oldest run)
             Family f;
             bool got = false;
             {
@@ -475,11 +521,8 @@ int run_batch(const Options &o)
                 }
             }
             if (!got) {
-                // nothing parsed right now: hand over what has been computed (oldest first) before waiting for the parsers
-                for (int j = 1; j < K; ++j) {
-                    Slot &t = slots[(k + (size_t)j) % (size_t)K];
-                    if (t.busy) finish(t);
-                }
+                // nothing parsed right now: hand over what has been computed before waiting for the parsers
+                drain(k);
                 std::unique_lock<std::mutex> lk(mu);
                 cv_ready.wait(lk, [&] { return !ready.empty() || parsed_done >= jobs.size(); });
                 if (ready.empty()) break;
@@ -493,18 +536,76 @@ int run_batch(const Options &o)
                 --k;  // the slot stays free
                 continue;
             }
+            if (sets_ok && is_small(f)) {
+                // a batch: this family and whatever small ones the parsers have ready behind it
+                std::vector<Family> grp;
+                grp.push_back(std::move(f));
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    while ((int)grp.size() < o.merge && !ready.empty() && ready.front().error.empty() && is_small(ready.front())) {
+                        grp.push_back(std::move(ready.front()));
+                        ready.pop_front();
+                    }
+                }
+                cv_space.notify_all();
+                Set &st = sets[cur_set];
+                finish_set(st);  // (its previous batch; the other set's keeps computing meanwhile)
+                const double t = now();
+                while (sets_ok && st.mem.size() < grp.size()) {
+                    Slot sl;
+                    if (gdca_ctx_create_peer(slots[0].ctx, &sl.ctx) != GDCA_OK) sets_ok = false;
+                    else st.mem.push_back(std::move(sl));
+                }
+                bool started = false;
+                if (sets_ok) {
+                    const int G2 = (int)grp.size();
+                    std::vector<gdca_ctx *> cs((size_t)G2);
+                    std::vector<const int8_t *> zs((size_t)G2);
+                    std::vector<int32_t> ns((size_t)G2), ms((size_t)G2), qs((size_t)G2);
+                    for (int m = 0; m < G2; ++m) {
+                        fill_slot(st.mem[(size_t)m], grp[(size_t)m], t);
+                        cs[(size_t)m] = st.mem[(size_t)m].ctx;
+                        zs[(size_t)m] = grp[(size_t)m].Z();
+                        ns[(size_t)m] = grp[(size_t)m].N;
+                        ms[(size_t)m] = grp[(size_t)m].M;
+                        qs[(size_t)m] = grp[(size_t)m].q;
+                    }
+                    gdca_params p{o.pseudocount, o.theta, o.score, 1};
+                    const gdca_status rc = gdca_run_ranked_phased_async(cs.data(), G2, zs.data(), ns.data(), ms.data(), qs.data(), &p, o.min_separation);
+                    busy_s += now() - t;
+                    if (rc == GDCA_OK) {
+                        for (int m = 0; m < G2; ++m) st.mem[(size_t)m].busy = true;
+                        st.used = G2;
+                        cur_set ^= 1;
+                        started = true;
+                    } else {
+                        fprintf(stderr, "WARNING: merged batch of %d families could not be enqueued (%s): running them one by one\n", G2,
+                                gdca_last_error(cs[0]));
+                    }
+                }
+                if (!started) {
+                    // (no contexts for the sets, or the batch was refused: each family through the ordinary slots, synchronously)
+                    for (Family &fm : grp) {
+                        Slot &sl = slots[0];
+                        if (sl.busy) finish(sl);
+                        fill_slot(sl, fm, now());
+                        gdca_params p{o.pseudocount, o.theta, o.score, 1};
+                        if (gdca_run_ranked_async(sl.ctx, fm.Z(), fm.N, fm.M, fm.q, &p, o.min_separation) != GDCA_OK) {
+                            fprintf(stderr, "ERROR: %s: gdca_run failed: %s\n", fm.name.c_str(), gdca_last_error(sl.ctx));
+                            ++failures;
+                            continue;
+                        }
+                        sl.busy = true;
+                        finish(sl);
+                    }
+                }
+                --k;  // (the big families' slots were not touched)
+                continue;
+            }
+            Slot &sl = slots[k % (size_t)K];
+            if (sl.busy) finish(sl);  // (round robin: the slot needed next holds the oldest run)
             const double t = now();
-            const int64_t len = std::max<int64_t>(gdca_ranking_length(f.N, o.min_separation), 0);
-            sl.res = Result();
-            sl.res.name = f.name;
-            sl.res.R.i.resize((size_t)len);
-            sl.res.R.j.resize((size_t)len);
-            sl.res.R.s.resize((size_t)len);
-            sl.N = f.N;
-            sl.M = f.M;
-            sl.q = f.q;
-            sl.parse_s = f.parse_s;
-            sl.t_start = t;
+            fill_slot(sl, f, t);
             gdca_params p{o.pseudocount, o.theta, o.score, 1};
             const gdca_status rc = gdca_run_ranked_async(sl.ctx, f.Z(), f.N, f.M, f.q, &p, o.min_separation);
             busy_s += now() - t;
@@ -516,14 +617,14 @@ int run_batch(const Options &o)
             }
             sl.busy = true;  // (the family's host matrix is no longer needed: it goes back to the reader's pool here)
         }
-        for (size_t j = 0; j < (size_t)K; ++j) {  // (the loop left at position k: oldest first from there -- order does not matter for files)
-            if (slots[j].busy) finish(slots[j]);
-        }
+        drain(0);
         {
             std::lock_guard<std::mutex> lk(omu);
             busy[(size_t)g] += busy_s;
             count[(size_t)g] += done;
         }
+        for (Set &st : sets)
+            for (int m = (int)st.mem.size() - 1; m >= 0; --m) gdca_ctx_destroy(st.mem[(size_t)m].ctx);  // (peers before their leader)
         for (int k = K - 1; k >= 0; --k) gdca_ctx_destroy(slots[(size_t)k].ctx);
     };
     std::vector<std::thread> threads, writers;
@@ -578,6 +679,8 @@ int main(int argc, char **argv)
         else if (s == "--gpus") o.gpus = atoi(val());
         else if (s == "--parsers") o.parsers = atoi(val());
         else if (s == "--inflight") o.inflight = atoi(val());
+        else if (s == "--merge") o.merge = std::min(8, std::max(1, atoi(val())));
+        else if (s == "--merge-blocks") o.merge_blocks = std::min(57, std::max(1, atoi(val())));
         else if (s == "--parse-only") o.parse_only = true;
         else if (s == "--passes") o.passes = atoi(val());
         else if (s == "--synth") {
@@ -591,7 +694,7 @@ int main(int argc, char **argv)
         } else if (s == "-h" || s == "--help") {
             printf("usage: gdca_cli [--pseudocount X] [--theta auto|X] [--max_gap_fraction X] [--score frob|DI]\n"
                    "                [--min_separation K] [--remove_dups] alignment.fasta[.gz] [ranking.txt]\n"
-                   "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K]\n"
+                   "       gdca_cli [options] --batch DIR --out OUTDIR [--gpus G] [--parsers P] [--inflight K] [--merge K] [--merge-blocks B]\n"
                    "       gdca_cli [options] --batch DIR --parse-only [--parsers P] [--passes R]\n"
                    "       gdca_cli --synth N M SEED out.fasta[.gz]\n");
             return 0;

@@ -282,6 +282,12 @@ gdca_status gdca_run_ranked(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int3
 gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z_host, int32_t N, int32_t M, int32_t q, const gdca_params *p,
                                   int32_t min_separation);
 gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st);
+/* K families at once on K contexts of one device (K <= 64; ctxs[0] leads: its options decide the merging, its last_error carries a
+ * member's message): uploads, gdca_run_dev_phased -- K front ends, the SPD inverses with the small ones sharing launches of the
+ * sweep kernel (options MERGE, MERGE_BLOCKS, ...), K score stages -- and every member's ranking, nothing waited for.  Each member
+ * is then collected by itself with gdca_run_ranked_collect, in any order.  What `gdca_cli --batch` runs its small families through. */
+gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_host, const int32_t *N,
+                                         const int32_t *M, const int32_t *q, const gdca_params *p, int32_t min_separation);
 /* printrank(filename, R) (:67-74): one "%i %i %e" line per entry */
 gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len);
 

@@ -131,6 +131,22 @@ gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z, int32_t N, int
     return GDCA_OK;
 }
 
+gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z, const int32_t *N, const int32_t *M,
+                                         const int32_t *q, const gdca_params *p, int32_t min_separation)
+{
+    if (!ctxs || K < 1 || K > 64 || !Z || !N || !M || !q || !p) return GDCA_EINVAL;
+    for (int32_t k = 0; k < K; ++k)
+        if (!ctxs[k] || ctxs[k]->pending) return GDCA_EINVAL;
+    for (int32_t k = 0; k < K; ++k) {
+        const gdca_status rc = gdca_run_ranked_async(ctxs[k], Z[k], N[k], M[k], q[k], p, min_separation);
+        if (rc != GDCA_OK) {  // (as in the product: nobody is left half-enqueued)
+            for (int32_t j = 0; j < k; ++j) ctxs[j]->pending = false;
+            return rc;
+        }
+    }
+    return GDCA_OK;
+}
+
 gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_out, double *score_out, gdca_stats *st)
 {
     if (!ctx || !ctx->pending) return GDCA_EINVAL;

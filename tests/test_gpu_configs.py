@@ -280,7 +280,9 @@ def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
     for f in fams:
         N, M = sizes[f]
         synth.write_fasta(str(indir / ("fam%03d.fasta" % f)), synth.synth_family(N, M, 21, 0xE000 + f))
-    r = subprocess.run([CLI, "--batch", str(indir), "--out", str(outdir), "--parsers", "4"], capture_output=True,
+    # (every family through a launch of its own -- the driver's default -- which is what the single-family path below runs; merged
+    # batches of small families are compared in test_batch_driver_merges_small_families)
+    r = subprocess.run([CLI, "--batch", str(indir), "--out", str(outdir), "--parsers", "4", "--merge", "1"], capture_output=True,
                        text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "16 families" in r.stderr and "(0 failed)" in r.stderr
@@ -293,6 +295,51 @@ def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
         g.printrank(str(want), R)
         got = (outdir / ("fam%03d.rank.txt" % f)).read_bytes()
         assert got == want.read_bytes(), f
+
+
+def _read_rank(path):
+    ii, jj, ss = [], [], []
+    with open(path) as fh:
+        for line in fh:
+            a, b, c = line.split()
+            ii.append(int(a))
+            jj.append(int(b))
+            ss.append(float(c))
+    return np.array(ii), np.array(jj), np.array(ss)
+
+
+def test_batch_driver_merges_small_families(g, ctx, tmp_path):
+    """`gdca_cli --batch --merge 8 --merge-blocks 57` sends families with a covariance of at most 57 blocks through
+    gdca_run_ranked_phased_async, up to eight at a time, their SPD inverses sharing launches of the sweep kernel.  20 small families (1 to 45 blocks, ragged sizes) and two big
+    ones in one directory: (a) with GDCA_MERGE_GROUP=1 (single-block groups: the schedule a launch of its own runs up to 48 blocks)
+    every ranking file is byte-identical to the unmerged driver's (`--merge 1`); (b) with the default grouping the same pairs come
+    out with scores equal to the file's seven digits or one unit of the last one."""
+    from gaussdca.jl_amd import synth
+
+    rng = np.random.default_rng(8)
+    indir = tmp_path / "in"
+    indir.mkdir()
+    sizes = [(int(n), int(m)) for n, m in zip(rng.integers(6, 288, size=20), rng.integers(300, 4000, size=20))] + [(420, 3000), (380, 2500)]
+    for f, (N, M) in enumerate(sizes):
+        synth.write_fasta(str(indir / ("fam%03d.fasta" % f)), synth.synth_family(N, M, 21, 0xABC0 + f))
+    outs = {}
+    wide = ["--merge", "8", "--merge-blocks", "57"]    # (merged batches are an option of the driver, off by default; 24 blocks by default)
+    for name, args, env in (("unmerged", ["--merge", "1"], {}), ("merged_g1", wide, {"GDCA_MERGE_GROUP": "1"}), ("merged", wide, {})):
+        out = tmp_path / name
+        r = subprocess.run([CLI, "--batch", str(indir), "--out", str(out), "--parsers", "4", *args], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0 and "22 families" in r.stderr and "(0 failed)" in r.stderr, r.stderr[-3000:]
+        outs[name] = out
+    for f in range(len(sizes)):
+        fn = "fam%03d.rank.txt" % f
+        ref = (outs["unmerged"] / fn).read_bytes()
+        assert (outs["merged_g1"] / fn).read_bytes() == ref, (f, sizes[f])
+        i0, j0, s0 = _read_rank(outs["unmerged"] / fn)
+        i1, j1, s1 = _read_rank(outs["merged"] / fn)
+        assert len(i0) == len(i1) and sorted(zip(i0.tolist(), j0.tolist())) == sorted(zip(i1.tolist(), j1.tolist()))
+        a = {(x, y): v for x, y, v in zip(i0.tolist(), j0.tolist(), s0.tolist())}
+        dev = max(abs(a[(x, y)] - v) / max(abs(v), 1e-30) for x, y, v in zip(i1.tolist(), j1.tolist(), s1.tolist()))
+        assert dev <= 2e-6, (f, sizes[f], dev)          # (%e keeps seven digits: one unit of the last is 1e-6 relative)
 
 
 @pytest.mark.parametrize("which", ["smallest", "largest", "mid_a", "mid_b"])

@@ -111,6 +111,12 @@ def test_batch_queues(bins, tmp_path, san):
     assert r.returncode == 1 and "gpu 1:" in r.stderr and "gpu 0:" not in r.stderr
     for nm in os.listdir(outdir):
         assert (outdir / nm).read_bytes() == (outdir2 / nm).read_bytes(), nm
+    # ... and with the small families in merged batches of up to four (two sets of contexts taking turns beside the slots' pipeline)
+    outdir3 = tmp_path / "out3"
+    r = run(exe, "--batch", indir, "--out", outdir3, "--parsers", 3, "--inflight", 2, "--merge", 4, "--merge-blocks", 6, env=env)
+    assert r.returncode == 1 and "16 families" in r.stderr and "(1 failed)" in r.stderr, r.stderr[-2000:]
+    for nm in os.listdir(outdir):
+        assert (outdir / nm).read_bytes() == (outdir3 / nm).read_bytes(), nm
     # parse-only (the host feed rate benchmark) and the start-up failure paths
     r = run(exe, "--batch", indir, "--parse-only", "--parsers", 4, env=env)
     assert r.returncode == 1 and "parse-only: 16 families" in r.stderr
