@@ -212,6 +212,52 @@ struct Bits {
     }
 };
 
+// the header of a dynamic block (RFC 1951 3.2.7), the block-type bits already consumed: both tables built.  false: not a
+// valid header (the parallel decoder's search for block starts relies on how much has to be right for `true`)
+bool read_dynamic_header(Bits &b, uint32_t *lit, uint32_t *dist)
+{
+    b.refill();
+    const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t pl[19] = {0};
+    b.refill();
+    for (int i = 0; i < hclen; ++i) {
+        if (b.cnt < 3) b.refill();
+        pl[order[i]] = (uint8_t)b.take(3);
+    }
+    uint32_t PT[PRE_CAP];
+    if (!build_table(PRECODE, pl, 19, PRE_BITS, PT, PRE_CAP)) return false;
+    uint8_t lens[288 + 32 + 140];
+    int i = 0;
+    const int total = hlit + hdist;
+    while (i < total) {
+        if (b.p > b.lim) return false;
+        b.refill();
+        const uint32_t e = PT[b.buf & (PRE_CAP - 1)];
+        if (e_kind(e) != K_LIT) return false;
+        b.take((int)e_total(e));
+        const int sym = (int)(e >> 16);
+        if (sym < 16) {
+            lens[i++] = (uint8_t)sym;
+        } else if (sym == 16) {
+            if (i == 0) return false;
+            const int rep = 3 + (int)b.take(2);
+            memset(lens + i, lens[i - 1], (size_t)rep);
+            i += rep;
+        } else {
+            const int rep = sym == 17 ? 3 + (int)b.take(3) : 11 + (int)b.take(7);
+            memset(lens + i, 0, (size_t)rep);
+            i += rep;
+        }
+    }
+    if (i != total || lens[256] == 0) return false;
+    uint8_t ll[288] = {0}, dl[32] = {0};
+    memcpy(ll, lens, (size_t)hlit);
+    memcpy(dl, lens + hlit, (size_t)hdist);
+    return build_table(LITLEN, ll, 288, LIT_BITS, lit, LIT_CAP) && build_table(DIST, dl, 32, DIST_BITS, dist, DIST_CAP);
+}
+
 }  // namespace
 
 static uint32_t crc32_tables(uint32_t c, const uint8_t *p, size_t n)  // c: the running (inverted) state
@@ -363,45 +409,7 @@ bool gdca_gunzip_fast(const uint8_t *in, size_t n, std::string &outbuf, size_t *
                 LT = fixed.lit;
                 DT = fixed.dist;
             } else if (type == 2) {
-                const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
-                if (hlit > 286 || hdist > 30) return false;
-                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                uint8_t pl[19] = {0};
-                b.refill();
-                for (int i = 0; i < hclen; ++i) {
-                    if (b.cnt < 3) b.refill();
-                    pl[order[i]] = (uint8_t)b.take(3);
-                }
-                uint32_t PT[PRE_CAP];
-                if (!build_table(PRECODE, pl, 19, PRE_BITS, PT, PRE_CAP)) return false;
-                uint8_t lens[288 + 32 + 140];
-                int i = 0;
-                const int total = hlit + hdist;
-                while (i < total) {
-                    if (b.p > b.lim) return false;
-                    b.refill();
-                    const uint32_t e = PT[b.buf & (PRE_CAP - 1)];
-                    if (e_kind(e) != K_LIT) return false;
-                    b.take((int)e_total(e));
-                    const int sym = (int)(e >> 16);
-                    if (sym < 16) {
-                        lens[i++] = (uint8_t)sym;
-                    } else if (sym == 16) {
-                        if (i == 0) return false;
-                        const int rep = 3 + (int)b.take(2);
-                        memset(lens + i, lens[i - 1], (size_t)rep);
-                        i += rep;
-                    } else {
-                        const int rep = sym == 17 ? 3 + (int)b.take(3) : 11 + (int)b.take(7);
-                        memset(lens + i, 0, (size_t)rep);
-                        i += rep;
-                    }
-                }
-                if (i != total || lens[256] == 0) return false;
-                uint8_t ll[288] = {0}, dl[32] = {0};
-                memcpy(ll, lens, (size_t)hlit);
-                memcpy(dl, lens + hlit, (size_t)hdist);
-                if (!build_table(LITLEN, ll, 288, LIT_BITS, dyn_lit, LIT_CAP) || !build_table(DIST, dl, 32, DIST_BITS, dyn_dist, DIST_CAP)) return false;
+                if (!read_dynamic_header(b, dyn_lit, dyn_dist)) return false;
                 add_literal_pairs(dyn_lit);
                 LT = dyn_lit;
                 DT = dyn_dist;
