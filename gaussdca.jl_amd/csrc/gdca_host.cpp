@@ -266,6 +266,15 @@ bool slurp(const char *path, FileText &out)
         static const bool zlib_only = getenv("GDCA_FASTA_ZLIB") != nullptr;
         memset(&zin[fsz], 0, GDCA_INFLATE_PAD);
         size_t len = 0;
+        // (a big single-member file read by a caller that gives this file several threads -- one gDCA(filename) call, not the batch
+        // driver's one-thread-per-file parsers -- is decoded on those threads: speculative block starts, see gdca_inflate.cpp)
+        static const bool no_parallel = getenv("GDCA_FASTA_SERIAL_INFLATE") != nullptr;
+        const int T = fasta_threads();
+        if (!zlib_only && !no_parallel && T > 1 && fsz >= ((size_t)4 << 20) &&
+            gdca_gunzip_parallel((const uint8_t *)zin.data(), fsz, buf, &len, hint, T)) {
+            out.text = std::string_view(buf.data(), len);
+            return true;
+        }
         if (!zlib_only && gdca_gunzip_fast((const uint8_t *)zin.data(), fsz, buf, &len, hint)) {
             out.text = std::string_view(buf.data(), len);
             return true;

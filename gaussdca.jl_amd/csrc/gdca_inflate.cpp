@@ -3,6 +3,11 @@
 
 #include <algorithm>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -508,5 +513,307 @@ bool gdca_gunzip_fast(const uint8_t *in, size_t n, std::string &outbuf, size_t *
         if (q == in_end) break;
     }
     *len_out = (size_t)(out - base);
+    return true;
+}
+
+// =====================================================================================================================
+// One gzip member on several threads
+// =====================================================================================================================
+// A DEFLATE stream has no index, and a block can only be decoded knowing the 32 KB before it -- so a single .gz file is a serial
+// job (43 ms for the 25 MB of config C's alignment at 600 MB/s: more than the GPU needs for the whole hot path), unless one
+// speculates (the scheme of pugz, Kerbiriou & Chikhi 2019, restated for this reader):
+//   1. split the compressed bytes into T pieces; in every piece but the first SEARCH the first position where a complete, valid
+//      header of a non-final dynamic block parses (precode, both code-length sets: random bits pass with negligible probability);
+//   2. decode every piece from its block start to the next piece's, all at once, NOT knowing the window: output symbols are 16 bits
+//      wide, 0..255 a byte, 256 + k "the byte at position k of the 32 KB before this piece" (the output buffer starts with those
+//      32 768 placeholders, so that a match is a plain copy whatever it points at).  Piece t must end EXACTLY at the block start
+//      piece t + 1 was decoded from -- that is what validates the search;
+//   3. resolve: piece 0 is bytes already; the last 32 KB of every piece are resolved one piece after the other (each needs only
+//      the previous tail), then all bodies at once;
+//   4. CRC-32 and ISIZE of the member over the assembled text, as always.
+// Anything that does not fit -- no header found, a piece that does not land on the next start, a second member, a checksum mismatch
+// -- returns false and the caller decodes the file the ordinary way.
+
+namespace {
+
+inline void seek_bit(Bits &b, const uint8_t *in, const uint8_t *in_end, size_t bit)
+{
+    b.p = in + (bit >> 3);
+    b.lim = in_end + 8;
+    b.buf = 0;
+    b.cnt = 0;
+    b.refill();
+    const int d = (int)(bit & 7);
+    b.buf >>= d;
+    b.cnt -= d;
+}
+
+inline size_t tell_bit(const Bits &b, const uint8_t *in)
+{
+    return (size_t)(b.p - in) * 8 - (size_t)b.cnt;
+}
+
+// first bit position in [from, limit) where the header of a non-final dynamic block parses completely; SIZE_MAX: none
+size_t find_block_start(const uint8_t *in, const uint8_t *in_end, size_t from, size_t limit, uint32_t *lit, uint32_t *dist)
+{
+    for (size_t bit = from; bit < limit; ++bit) {
+        const uint64_t w = load64(in + (bit >> 3)) >> (bit & 7);  // 57+ bits from `bit` on
+        if ((w & 7) != 4) continue;                                 // BFINAL = 0, BTYPE = 10b
+        if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;  // HLIT, HDIST
+        // the code-length code must be complete (Kraft sum = 1): 13 of its (up to 19) lengths are in this word already
+        const int hclen = (int)((w >> 13) & 15) + 4;
+        int kraft = 0;
+        const int here = hclen < 13 ? hclen : 13;
+        for (int i = 0; i < here; ++i) {
+            const int l = (int)((w >> (17 + 3 * i)) & 7);
+            if (l) kraft += 128 >> l;
+        }
+        if (kraft > 128 || (hclen <= 13 && kraft != 128)) continue;
+        Bits b;
+        seek_bit(b, in, in_end, bit);
+        b.take(3);
+        if (read_dynamic_header(b, lit, dist)) return bit;
+    }
+    return SIZE_MAX;
+}
+
+// decode blocks from `start_bit` until a block would start at `stop_bit` (SIZE_MAX: until the final block has ended); Out = uint8_t
+// (no window before the piece: the beginning of the member) or uint16_t (unknown window: `out` begins with 32 768 placeholders)
+template <class Out>
+bool decode_piece(const uint8_t *in, const uint8_t *in_end, size_t start_bit, size_t stop_bit, std::vector<Out> &out, size_t prefix, size_t *produced,
+                  const uint8_t **after_final)
+{
+    static const FixedTables fixed;
+    if (!fixed.ok) return false;
+    static thread_local uint32_t dyn_lit[LIT_CAP], dyn_dist[DIST_CAP];
+    constexpr size_t SLACK = 320;
+    constexpr uint32_t LMASK = (1u << LIT_BITS) - 1;
+    size_t pos = prefix;  // next element of `out`
+    auto room = [&](size_t want) {
+        if (out.size() - pos >= want) return true;
+        size_t size = out.size();
+        while (size - pos < want) size *= 2;
+        if (size > ((size_t)1 << 33)) return false;
+        out.resize(size);
+        return true;
+    };
+    Bits b;
+    seek_bit(b, in, in_end, start_bit);
+    *after_final = nullptr;
+    for (;;) {
+        const size_t at = tell_bit(b, in);
+        if (at == stop_bit) break;
+        if (at > stop_bit || b.p > b.lim) return false;
+        b.refill();
+        const uint32_t final = b.take(1), type = b.take(2);
+        const uint32_t *LT, *DT;
+        if (type == 0) {
+            const uint8_t *s = b.byte_align();
+            if (in_end - s < 4) return false;
+            const size_t L = (size_t)s[0] | ((size_t)s[1] << 8), NL = (size_t)s[2] | ((size_t)s[3] << 8);
+            if ((L ^ NL) != 0xffff) return false;
+            s += 4;
+            if ((size_t)(in_end - s) < L || !room(L + SLACK)) return false;
+            for (size_t k = 0; k < L; ++k) out[pos + k] = (Out)s[k];
+            pos += L;
+            seek_bit(b, in, in_end, (size_t)(s + L - in) * 8);
+        } else {
+            if (type == 1) {
+                LT = fixed.lit;
+                DT = fixed.dist;
+            } else if (type == 2) {
+                if (!read_dynamic_header(b, dyn_lit, dyn_dist)) return false;
+                add_literal_pairs(dyn_lit);
+                LT = dyn_lit;
+                DT = dyn_dist;
+            } else {
+                return false;
+            }
+            for (;;) {
+                if (!room(SLACK) || b.p > b.lim) return false;
+                Out *o = out.data() + pos;
+                b.refill();
+                uint32_t e = LT[b.buf & LMASK];
+                if ((e & KIND_MASK) == (K_SUB << 5)) {
+                    b.buf >>= LIT_BITS;
+                    b.cnt -= LIT_BITS;
+                    e = LT[(e >> 16) + (b.buf & ((1u << e_extra(e)) - 1))];
+                }
+                const uint64_t saved = b.buf;
+                b.buf >>= e_total(e);
+                b.cnt -= (int)e_total(e);
+                const uint32_t kind = e_kind(e);
+                if (kind <= K_LIT2) {
+                    o[0] = (Out)((e >> 16) & 0xff);
+                    o[1] = (Out)(e >> 24);
+                    pos += 1 + kind;
+                    // one more look-up out of the bits at hand (41+) where it is a literal again
+                    e = LT[b.buf & LMASK];
+                    if ((e & KIND_MASK) <= (K_LIT2 << 5)) {
+                        b.buf >>= e_total(e);
+                        b.cnt -= (int)e_total(e);
+                        o = out.data() + pos;
+                        o[0] = (Out)((e >> 16) & 0xff);
+                        o[1] = (Out)(e >> 24);
+                        pos += 1 + e_kind(e);
+                    }
+                    continue;
+                }
+                if (kind == K_EOB) break;
+                if (kind != K_BASE) return false;
+                const size_t mlen = (e >> 16) + (size_t)((saved >> e_cbits(e)) & ((1u << e_extra(e)) - 1));
+                uint32_t d = DT[b.buf & ((1u << DIST_BITS) - 1)];
+                if ((d & KIND_MASK) == (K_SUB << 5)) {
+                    b.buf >>= DIST_BITS;
+                    b.cnt -= DIST_BITS;
+                    d = DT[(d >> 16) + (b.buf & ((1u << e_extra(d)) - 1))];
+                }
+                const uint64_t saved_d = b.buf;
+                b.buf >>= e_total(d);
+                b.cnt -= (int)e_total(d);
+                if (e_kind(d) != K_BASE) return false;
+                const size_t dist = (d >> 16) + (size_t)((saved_d >> e_cbits(d)) & ((1u << e_extra(d)) - 1));
+                if (dist > pos) return false;  // (before the placeholders / before the member's first byte)
+                const Out *src = o - dist;
+                if (dist >= 8) {
+                    // 8 elements at a time, two chunks unconditionally (most matches of alignment text are shorter than 16)
+                    memcpy(o, src, 8 * sizeof(Out));
+                    memcpy(o + 8, src + 8, 8 * sizeof(Out));
+                    for (size_t k = 16; k < mlen; k += 8) memcpy(o + k, src + k, 8 * sizeof(Out));
+                } else {
+                    for (size_t k = 0; k < mlen; ++k) o[k] = src[k];
+                }
+                pos += mlen;
+            }
+        }
+        if (final) {
+            *after_final = b.byte_align();
+            break;
+        }
+    }
+    *produced = pos - prefix;
+    // a piece that was to stop at a block start must not have met the final block, and the other way round
+    return (stop_bit == SIZE_MAX) == (*after_final != nullptr);
+}
+
+}  // namespace
+
+bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size_t *len_out, size_t hint, int threads)
+{
+    constexpr size_t WIN = 32768, MIN_PIECE = (size_t)512 << 10;
+    const uint8_t *const in_end = in + n;
+    // ---- header of the (single) member ----
+    const uint8_t *q = in;
+    if (n < 18 + 2 * MIN_PIECE || q[0] != 0x1f || q[1] != 0x8b || q[2] != 8) return false;
+    const uint8_t flg = q[3];
+    if (flg & 0xe0) return false;
+    q += 10;
+    if (flg & 4) {
+        if (in_end - q < 2) return false;
+        const size_t xlen = (size_t)q[0] | ((size_t)q[1] << 8);
+        q += 2;
+        if ((size_t)(in_end - q) < xlen) return false;
+        q += xlen;
+    }
+    for (int f = 8; f <= 16; f <<= 1)
+        if (flg & f) {
+            const uint8_t *z = (const uint8_t *)memchr(q, 0, (size_t)(in_end - q));
+            if (!z) return false;
+            q = z + 1;
+        }
+    if (flg & 2) {
+        if (in_end - q < 2) return false;
+        q += 2;
+    }
+    if (in_end - q < (ptrdiff_t)(8 + 2 * MIN_PIECE)) return false;
+    const size_t first_bit = (size_t)(q - in) * 8, last_bit = (size_t)(in_end - 8 - in) * 8;
+    int T = (int)std::min<size_t>((size_t)std::max(threads, 1), (last_bit - first_bit) / 8 / MIN_PIECE);
+    if (T < 2) return false;
+    static const bool trace = getenv("GDCA_INFLATE_TRACE") != nullptr;
+    auto tick = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = trace ? tick() : 0.0;
+    // ---- 1. block starts ----
+    std::vector<size_t> start((size_t)T + 1, SIZE_MAX);
+    start[0] = first_bit;
+    start[(size_t)T] = SIZE_MAX;
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t)
+            th.emplace_back([&, t] {
+                static thread_local uint32_t lit[LIT_CAP], dist[DIST_CAP];
+                const size_t from = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)t;
+                const size_t limit = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)(t + 1);
+                start[(size_t)t] = find_block_start(in, in_end, from, limit, lit, dist);
+            });
+        for (auto &x : th) x.join();
+    }
+    for (int t = 1; t < T; ++t)
+        if (start[(size_t)t] == SIZE_MAX) return false;
+    const double t_1 = trace ? tick() : 0.0;
+    // ---- 2. every piece, window unknown ----
+    std::vector<uint8_t> first;
+    std::vector<std::vector<uint16_t>> piece((size_t)T);
+    std::vector<size_t> produced((size_t)T, 0);
+    std::vector<char> ok((size_t)T, 0);
+    const uint8_t *after_final = nullptr;
+    const size_t guess = std::max<size_t>((hint ? hint : 4 * n) / (size_t)T * 5 / 4, (size_t)1 << 20);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                const uint8_t *af = nullptr;
+                if (t == 0) {
+                    first.resize(guess);
+                    ok[0] = decode_piece<uint8_t>(in, in_end, start[0], start[1], first, 0, &produced[0], &af);
+                } else {
+                    std::vector<uint16_t> &v = piece[(size_t)t];
+                    v.resize(WIN + guess);
+                    for (size_t k = 0; k < WIN; ++k) v[k] = (uint16_t)(256 + k);
+                    ok[(size_t)t] = decode_piece<uint16_t>(in, in_end, start[(size_t)t], start[(size_t)t + 1], v, WIN, &produced[(size_t)t], &af);
+                }
+                if (t == T - 1) after_final = af;
+            });
+        for (auto &x : th) x.join();
+    }
+    const double t_2 = trace ? tick() : 0.0;
+    size_t total = 0;
+    for (int t = 0; t < T; ++t) {
+        if (!ok[(size_t)t] || produced[(size_t)t] < WIN) return false;
+        total += produced[(size_t)t];
+    }
+    // the member must end here: trailer, end of file
+    if (!after_final || after_final != in_end - 8) return false;
+    const uint8_t *tr = after_final;
+    const uint32_t want_crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+    const uint32_t want_len = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+    if ((uint32_t)total != want_len) return false;
+    // ---- 3. resolve ----
+    if (outbuf.size() < total + 64) outbuf.resize(total + 64);
+    uint8_t *base = (uint8_t *)&outbuf[0];
+    std::vector<size_t> off((size_t)T + 1, 0);
+    for (int t = 0; t < T; ++t) off[(size_t)t + 1] = off[(size_t)t] + produced[(size_t)t];
+    memcpy(base, first.data(), produced[0]);
+    auto resolve = [&](int t, size_t a, size_t b) {  // elements [a, b) of piece t
+        const uint16_t *src = piece[(size_t)t].data() + WIN;
+        const uint8_t *win = base + off[(size_t)t] - WIN;
+        uint8_t *dst = base + off[(size_t)t];
+        for (size_t k = a; k < b; ++k) {
+            const uint16_t v = src[k];
+            dst[k] = v < 256 ? (uint8_t)v : win[v - 256];
+        }
+    };
+    for (int t = 1; t < T; ++t) resolve(t, produced[(size_t)t] - WIN, produced[(size_t)t]);  // the tails, one after the other
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back([&, t] { resolve(t, 0, produced[(size_t)t] - WIN); });
+        for (auto &x : th) x.join();
+    }
+    const double t_3 = trace ? tick() : 0.0;
+    // ---- 4. checksum ----
+    if (gdca_crc32(0, base, total) != want_crc) return false;
+    if (trace)
+        fprintf(stderr, "inflate-trace %d threads: block starts %.2f ms, pieces %.2f ms, resolve %.2f ms, crc %.2f ms\n", T, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3,
+                (t_3 - t_2) * 1e3, (tick() - t_3) * 1e3);
+    *len_out = total;
     return true;
 }

@@ -16,5 +16,8 @@
 // out: resized as needed (never shrunk), *len = bytes produced.  hint: expected size (0 = unknown).
 #define GDCA_INFLATE_PAD 16
 bool gdca_gunzip_fast(const uint8_t *in, size_t n, std::string &out, size_t *len, size_t hint);
+// One single-member file on `threads` threads (speculative block starts, 16-bit symbols for the unknown windows, resolved afterwards:
+// see gdca_inflate.cpp); same contract as gdca_gunzip_fast, false also for small files, several members, or a failed speculation.
+bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &out, size_t *len, size_t hint, int threads);
 // CRC-32 (IEEE 802.3, as in gzip trailers): carry-less-multiply folding where the CPU has PCLMULQDQ, slicing-by-16 tables otherwise
 uint32_t gdca_crc32(uint32_t crc, const uint8_t *p, size_t n);

@@ -104,6 +104,25 @@ int main(int argc, char **argv)
                 verdicts += ok2;
                 if (ok2 && (!fok || l2 != flen || memcmp(fresh.data(), fo.data(), l2) != 0)) verdicts = -100;
             }
+            // the multi-threaded decoder on the same bytes: it may decline (small files, several members, a speculation that failed),
+            // but whatever it accepts must be zlib's output
+            {
+                std::vector<uint8_t> padded(in.size() + GDCA_INFLATE_PAD, 0);
+                if (!in.empty()) memcpy(padded.data(), in.data(), in.size());
+                for (int threads : {2, 5, 16}) {
+                    std::string po;
+                    size_t pl = 0;
+                    double t0 = now();
+                    const bool pok = gdca_gunzip_parallel(padded.data(), in.size(), po, &pl, 0, threads);
+                    const double tp = now() - t0;
+                    if (pok && (!zok || pl != zo.size() || memcmp(po.data(), zo.data(), pl) != 0)) {
+                        printf("%s: the parallel decoder (%d threads) accepted the file and decoded it differently  MISMATCH\n", argv[a], threads);
+                        ++bad;
+                    }
+                    if (pok) printf("   parallel x%d: ok, %.0f MB/s\n", threads, pl / tp / 1e6);
+                    else if (in.size() > (4u << 20)) printf("   parallel x%d: declined\n", threads);
+                }
+            }
             if (verdicts != 0 && verdicts != 6) {
                 printf("%s: the fast decoder's verdict or output depends on the state of its output buffer  MISMATCH\n", argv[a]);
                 ++bad;
@@ -119,7 +138,7 @@ int main(int argc, char **argv)
         const int rounds = atoi(argv[3]);
         const std::vector<uint8_t> orig = read_file(argv[4]);
         std::mt19937 rng(seed);
-        int accepted = 0, declined = 0;
+        int accepted = 0, declined = 0, paccepted = 0;
         std::string zo, fo;
         for (int r = 0; r < rounds; ++r) {
             std::vector<uint8_t> in = orig;
@@ -139,6 +158,19 @@ int main(int argc, char **argv)
             }
             size_t flen = 0;
             if (!fo.empty()) memset(&fo[0], 0x5a, fo.size());
+            {   // the multi-threaded decoder must survive the same input, and agree with zlib whenever it accepts it
+                std::vector<uint8_t> padded(in.size() + GDCA_INFLATE_PAD, 0);
+                if (!in.empty()) memcpy(padded.data(), in.data(), in.size());
+                std::string po;
+                size_t pl = 0;
+                if (gdca_gunzip_parallel(padded.data(), in.size(), po, &pl, 0, 3)) {
+                    ++paccepted;
+                    if (!zlib_gunzip(in, zo) || zo.size() != pl || memcmp(zo.data(), po.data(), pl) != 0) {
+                        printf("round %d kind %d: the parallel decoder accepted an input zlib rejects or decodes differently\n", r, kind);
+                        ++bad;
+                    }
+                }
+            }
             const bool fok = fast_gunzip(in, fo, &flen);
             if (fok) {
                 ++accepted;
@@ -151,7 +183,7 @@ int main(int argc, char **argv)
                 ++declined;
             }
         }
-        printf("fuzz: %d rounds, %d accepted (all equal to zlib: %s), %d declined\n", rounds, accepted, bad ? "NO" : "yes", declined);
+        printf("fuzz: %d rounds, %d accepted (all equal to zlib: %s), %d declined; parallel decoder accepted %d\n", rounds, accepted, bad ? "NO" : "yes", declined, paccepted);
     } else if (mode == "crc") {
         std::mt19937 rng(7);
         std::vector<uint8_t> v(1 << 20);

@@ -26,17 +26,18 @@ def bins():
         pytest.skip("no g++")
     os.makedirs(BUILD, exist_ok=True)
     src = [os.path.join(ROOT, "tests", "sanitize", "inflate_check.cpp"), os.path.join(CSRC, "gdca_inflate.cpp")]
-    out = {"plain": os.path.join(BUILD, "inflate_check"), "asan": os.path.join(BUILD, "inflate_check_asan")}
+    out = {"plain": os.path.join(BUILD, "inflate_check"), "asan": os.path.join(BUILD, "inflate_check_asan"), "tsan": os.path.join(BUILD, "inflate_check_tsan")}
     for kind, flags in (("plain", ["-O2"]),
-                        ("asan", ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])):
-        r = subprocess.run(["g++", *flags, "-std=c++17", "-Wall", "-I" + CSRC, *src, "-o", out[kind], "-lz"], capture_output=True, text=True,
+                        ("asan", ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]),
+                        ("tsan", ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread"])):
+        r = subprocess.run(["g++", *flags, "-std=c++17", "-Wall", "-pthread", "-I" + CSRC, *src, "-o", out[kind], "-lz"], capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
     return out
 
 
 def run(exe, *args, timeout=900):
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=0")
     r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout, env=env)
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     return r
@@ -127,6 +128,37 @@ def test_damaged_streams_are_left_to_zlib(bins, tmp_path):
         p.write_bytes(blob)
         r = run(bins["asan"], "files", p)
         assert r.returncode == 0 and "fast declines" in r.stdout, (name, r.stdout)
+
+
+def test_one_member_on_several_threads(bins, tmp_path):
+    """gdca_gunzip_parallel (speculative block starts, 16-bit symbols for the unknown windows, resolved afterwards) on files big enough
+    for it: accepted and equal to zlib at 2, 5 and 16 threads for level 1 / 6 / 9 streams and a stream that mixes in stored and
+    fixed-Huffman blocks; declined (never wrong) for two members; under ASan + UBSan and under TSan; and 25 random corruptions of a
+    big file under ASan -- whatever the parallel decoder accepts must be zlib's output."""
+    rng = np.random.default_rng(21)
+    text = alignment_text(rng, 300, 40000)                      # 12.6 MB
+    noise = rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()
+    mixed = b"".join(text[k:k + 400000] + noise[:150000] for k in range(0, len(text), 400000))   # incompressible stretches: stored blocks
+    cases = {"big_l1": gz_member(text, 1), "big_l6": gz_member(text, 6), "big_l9": gz_member(text, 9), "big_mixed": gz_member(mixed, 6),
+             "big_two_members": gz_member(text[:len(text) // 2], 6) + gz_member(text[len(text) // 2:], 6)}
+    paths = {}
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        paths[name] = str(p)
+    for kind in ("plain", "asan", "tsan"):
+        # (under ThreadSanitizer the decoders run at a few MB/s: two files are enough for the thread structure)
+        r = run(bins[kind], "files", *(paths.values() if kind != "tsan" else [paths["big_l6"], paths["big_mixed"]]))
+        print(r.stdout)
+        assert r.returncode == 0 and "MISMATCH" not in r.stdout and "FAILS" not in r.stdout, r.stdout + r.stderr[-3000:]
+        blocks = r.stdout.split("\n/")          # (the parallel lines of a file are printed before its own line)
+        for name in (("big_l1", "big_l6", "big_l9", "big_mixed") if kind != "tsan" else ("big_l6", "big_mixed")):
+            mine = [b for b in r.stdout.split(".gz: zlib") if name in b.splitlines()[-1]]
+            assert mine and mine[0].count("parallel x") >= 1 and "ok," in mine[0], (kind, name, r.stdout)
+        assert len(blocks) >= 1
+    r = run(bins["asan"], "fuzz", 77, 25, paths["big_l6"])
+    print(r.stdout.strip())
+    assert r.returncode == 0 and "all equal to zlib: yes" in r.stdout, r.stdout + r.stderr[-2000:]
 
 
 def test_reader_gives_the_same_matrix_for_gz_and_plain(tmp_path):
