@@ -185,3 +185,17 @@ def test_reader_gives_the_same_matrix_for_gz_and_plain(tmp_path):
         assert len(lines) == 3 and lines[0] == lines[1] == lines[2], r.stdout
         outs.append(lines[0])
     assert outs[0] == outs[1] and outs[0].startswith("(97, 3000)")
+    # a file big enough for the multi-threaded decoder (>= 4 MB compressed, several reader threads): the reader's default against
+    # the serial decoder (GDCA_FASTA_SERIAL_INFLATE=1) and zlib, on the synthetic generator's text
+    cli = os.path.join(ROOT, "gaussdca.jl_amd", "gdca_cli")
+    big = str(tmp_path / "big.fasta.gz")
+    subprocess.run([cli, "--synth", "300", "40000", "4660", big], check=True, stdout=subprocess.DEVNULL)
+    assert os.path.getsize(big) > (4 << 20)
+    seen = set()
+    for env in ({"GDCA_FASTA_THREADS": "6"}, {"GDCA_FASTA_THREADS": "6", "GDCA_FASTA_SERIAL_INFLATE": "1"}, {"GDCA_FASTA_ZLIB": "1"}):
+        r = subprocess.run([sys.executable, "-c", code, big], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, GDCA_INFLATE_TRACE="1", **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("inflate-trace" in r.stderr) == (len(env) == 1 and "GDCA_FASTA_THREADS" in env), (env, r.stderr[-500:])   # the path really taken
+        seen.add(r.stdout.strip())
+    assert len(seen) == 1 and next(iter(seen)).startswith("(300, 40000)"), seen
