@@ -1,5 +1,5 @@
 """Where the wall time of gDCA(filename) goes at config C / D (FASTA file -> ranking): parse, copies, upload + hot path + download,
-ranking.   python tools/e2e_profile.py [C|D] [reps]"""
+ranking.   python tools/e2e_profile.py [C|D] [reps] [gz]      (gz: the same family as a .fasta.gz, gDCA() only)"""
 import os
 import sys
 import tempfile
@@ -13,6 +13,7 @@ from gaussdca.jl_amd import dcautils, synth
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+as_gz = len(sys.argv) > 3 and sys.argv[3] == "gz"
 N, M, seed = (500, 50000, 0xC500) if cfg == "C" else (1000, 100000, 0xD1000)
 Zh = synth.synth_family(N, M, 21, seed)
 letters = np.frombuffer(b"?ACDEFGHIKLMNPQRSTVWY-", dtype=np.uint8)
@@ -23,6 +24,22 @@ with tempfile.NamedTemporaryFile("wb", suffix=".fasta", delete=False) as f:
         f.write(letters[Zh[k]].tobytes())
         f.write(b"\n")
 ctx = g.Context(0)
+if as_gz:
+    import gzip
+    import shutil
+
+    gz = path + ".gz"
+    with open(path, "rb") as fi, gzip.open(gz, "wb", compresslevel=6) as fo:
+        shutil.copyfileobj(fi, fo)
+    try:
+        for r in range(reps):
+            t0 = time.perf_counter()
+            R = g.gDCA(gz, ctx=ctx)
+            print("rep %d: gDCA(%s.fasta.gz, %d MB compressed) %.1f ms" % (r, cfg, os.path.getsize(gz) >> 20, (time.perf_counter() - t0) * 1e3), flush=True)
+    finally:
+        os.unlink(gz)
+        os.unlink(path)
+    sys.exit(0)
 try:
     for r in range(reps):
         t0 = time.perf_counter()
