@@ -580,8 +580,8 @@ size_t find_block_start(const uint8_t *in, const uint8_t *in_end, size_t from, s
 // decode blocks from `start_bit` until a block would start at `stop_bit` (SIZE_MAX: until the final block has ended); Out = uint8_t
 // (no window before the piece: the beginning of the member) or uint16_t (unknown window: `out` begins with 32 768 placeholders)
 template <class Out>
-bool decode_piece(const uint8_t *in, const uint8_t *in_end, size_t start_bit, size_t stop_bit, std::vector<Out> &out, size_t prefix, size_t *produced,
-                  const uint8_t **after_final)
+bool decode_piece(const uint8_t *in, const uint8_t *in_end, size_t start_bit, size_t stop_bit, std::vector<Out> &out, size_t prefix, size_t max_elems,
+                  size_t *produced, const uint8_t **after_final)
 {
     static const FixedTables fixed;
     if (!fixed.ok) return false;
@@ -593,7 +593,7 @@ bool decode_piece(const uint8_t *in, const uint8_t *in_end, size_t start_bit, si
         if (out.size() - pos >= want) return true;
         size_t size = out.size();
         while (size - pos < want) size *= 2;
-        if (size > ((size_t)1 << 33)) return false;
+        if (size > max_elems) return false;  // (DEFLATE cannot expand by more than 1032 : 1: a piece that wants more is not what it seems)
         out.resize(size);
         return true;
     };
@@ -704,7 +704,8 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
     const uint8_t *const in_end = in + n;
     // ---- header of the (single) member ----
     const uint8_t *q = in;
-    if (n < 18 + 2 * MIN_PIECE || q[0] != 0x1f || q[1] != 0x8b || q[2] != 8) return false;
+    // (files beyond 1 GiB compressed stay with the serial decoder: the pieces' 16-bit images would take twice the text's size on top of it)
+    if (n < 18 + 2 * MIN_PIECE || n > ((size_t)1 << 30) || q[0] != 0x1f || q[1] != 0x8b || q[2] != 8) return false;
     const uint8_t flg = q[3];
     if (flg & 0xe0) return false;
     q += 10;
@@ -756,20 +757,25 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
     std::vector<size_t> produced((size_t)T, 0);
     std::vector<char> ok((size_t)T, 0);
     const uint8_t *after_final = nullptr;
+    // (the size hint is the trailer's ISIZE, untrusted: alignment text deflates 2-10 x; a file that claims more than 16 x is left to the
+    // serial decoder instead of sizing sixteen 16-bit buffers after it)
+    if (hint > 16 * n) return false;
     const size_t guess = std::max<size_t>((hint ? hint : 4 * n) / (size_t)T * 5 / 4, (size_t)1 << 20);
     {
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
             th.emplace_back([&, t] {
                 const uint8_t *af = nullptr;
+                const size_t piece_bytes = ((t + 1 < T ? start[(size_t)t + 1] : last_bit) - start[(size_t)t]) / 8 + 16;
+                const size_t cap = 2 * (WIN + 1040 * piece_bytes + ((size_t)1 << 20));   // (x 2: the buffer grows by doubling)
                 if (t == 0) {
-                    first.resize(guess);
-                    ok[0] = decode_piece<uint8_t>(in, in_end, start[0], start[1], first, 0, &produced[0], &af);
+                    first.resize(std::min(guess, cap));
+                    ok[0] = decode_piece<uint8_t>(in, in_end, start[0], start[1], first, 0, cap, &produced[0], &af);
                 } else {
                     std::vector<uint16_t> &v = piece[(size_t)t];
-                    v.resize(WIN + guess);
+                    v.resize(WIN + std::min(guess, cap));
                     for (size_t k = 0; k < WIN; ++k) v[k] = (uint16_t)(256 + k);
-                    ok[(size_t)t] = decode_piece<uint16_t>(in, in_end, start[(size_t)t], start[(size_t)t + 1], v, WIN, &produced[(size_t)t], &af);
+                    ok[(size_t)t] = decode_piece<uint16_t>(in, in_end, start[(size_t)t], start[(size_t)t + 1], v, WIN, cap, &produced[(size_t)t], &af);
                 }
                 if (t == T - 1) after_final = af;
             });
