@@ -331,6 +331,47 @@ __attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_clmul(uint32_t c,
 }
 #endif
 
+// CRC-32 of A || B from those of A and B and the length of B: crc(A) is multiplied by x^(8 len B) modulo the polynomial (bit-reflected:
+// bit 31 is x^0), the power by square-and-multiply over a table of x^(2^k)
+namespace {
+inline uint32_t mulmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+struct X2nTable {
+    uint32_t t[32];
+    X2nTable()
+    {
+        uint32_t p = 1u << 30;  // x^1
+        t[0] = p;
+        for (int k = 1; k < 32; ++k) t[k] = p = mulmodp(p, p);
+    }
+};
+}  // namespace
+
+uint32_t gdca_crc32_combine(uint32_t crc_a, uint32_t crc_b, size_t len_b)
+{
+    static const X2nTable X;
+    uint32_t p = 1u << 31;  // x^0
+    size_t n = len_b;
+    unsigned k = 3;         // x^(2^3) = one byte
+    while (n) {
+        if (n & 1) p = mulmodp(X.t[k & 31], p);
+        n >>= 1;
+        ++k;
+    }
+    return mulmodp(p, crc_a) ^ crc_b;
+}
+
 uint32_t gdca_crc32(uint32_t crc, const uint8_t *p, size_t n)
 {
 #if defined(__x86_64__)
@@ -809,16 +850,23 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
         }
     };
     for (int t = 1; t < T; ++t) resolve(t, produced[(size_t)t] - WIN, produced[(size_t)t]);  // the tails, one after the other
+    // ---- 4. checksum: every piece's CRC-32 by the thread that resolved it, combined in order ----
+    std::vector<uint32_t> crc((size_t)T, 0);
     {
         std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back([&, t] { resolve(t, 0, produced[(size_t)t] - WIN); });
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                if (t > 0) resolve(t, 0, produced[(size_t)t] - WIN);
+                crc[(size_t)t] = gdca_crc32(0, base + off[(size_t)t], produced[(size_t)t]);
+            });
         for (auto &x : th) x.join();
     }
     const double t_3 = trace ? tick() : 0.0;
-    // ---- 4. checksum ----
-    if (gdca_crc32(0, base, total) != want_crc) return false;
+    uint32_t whole = crc[0];
+    for (int t = 1; t < T; ++t) whole = gdca_crc32_combine(whole, crc[(size_t)t], produced[(size_t)t]);
+    if (whole != want_crc) return false;
     if (trace)
-        fprintf(stderr, "inflate-trace %d threads: block starts %.2f ms, pieces %.2f ms, resolve %.2f ms, crc %.2f ms\n", T, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3,
+        fprintf(stderr, "inflate-trace %d threads: block starts %.2f ms, pieces %.2f ms, resolve + crc %.2f ms, combine %.2f ms\n", T, (t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3,
                 (t_3 - t_2) * 1e3, (tick() - t_3) * 1e3);
     *len_out = total;
     return true;

@@ -21,3 +21,5 @@ bool gdca_gunzip_fast(const uint8_t *in, size_t n, std::string &out, size_t *len
 bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &out, size_t *len, size_t hint, int threads);
 // CRC-32 (IEEE 802.3, as in gzip trailers): carry-less-multiply folding where the CPU has PCLMULQDQ, slicing-by-16 tables otherwise
 uint32_t gdca_crc32(uint32_t crc, const uint8_t *p, size_t n);
+// CRC-32 of the concatenation A || B from crc(A), crc(B) and the length of B
+uint32_t gdca_crc32_combine(uint32_t crc_a, uint32_t crc_b, size_t len_b);

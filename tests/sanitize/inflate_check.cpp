@@ -193,6 +193,8 @@ int main(int argc, char **argv)
             const uint32_t want = (uint32_t)crc32(0, v.data() + a, (uInt)n);
             const uint32_t got = gdca_crc32(gdca_crc32(0, v.data() + a, cut), v.data() + a + cut, n - cut);
             if (want != got) { ++bad; printf("crc mismatch at a=%zu n=%zu\n", a, n); }
+            const uint32_t comb = gdca_crc32_combine(gdca_crc32(0, v.data() + a, cut), gdca_crc32(0, v.data() + a + cut, n - cut), n - cut);
+            if (comb != want) { ++bad; printf("crc combine mismatch at a=%zu n=%zu cut=%zu\n", a, n, cut); }
         }
         double t0 = now();
         uint32_t c = 0;
