@@ -739,8 +739,37 @@ bool decode_piece(const uint8_t *in, const uint8_t *in_end, size_t start_bit, si
 
 }  // namespace
 
-bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size_t *len_out, size_t hint, int threads)
+namespace {
+// fn(t) for t = first .. T-1 on threads of their own; false if a thread could not be started or one of them threw (out of memory
+// while a piece's buffer grew): nothing escapes into the caller's thread, which then takes the serial path
+template <class F>
+bool on_threads(int first, int T, F fn)
 {
+    std::vector<std::thread> th;
+    std::vector<char> failed((size_t)T, 0);
+    bool started = true;
+    try {
+        for (int t = first; t < T; ++t)
+            th.emplace_back([&, t] {
+                try {
+                    fn(t);
+                } catch (...) {
+                    failed[(size_t)t] = 1;
+                }
+            });
+    } catch (...) {
+        started = false;
+    }
+    for (auto &x : th) x.join();
+    if (!started) return false;
+    for (char f : failed)
+        if (f) return false;
+    return true;
+}
+}  // namespace
+
+bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size_t *len_out, size_t hint, int threads)
+try {
     constexpr size_t WIN = 32768, MIN_PIECE = (size_t)512 << 10;
     const uint8_t *const in_end = in + n;
     // ---- header of the (single) member ----
@@ -778,17 +807,13 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
     std::vector<size_t> start((size_t)T + 1, SIZE_MAX);
     start[0] = first_bit;
     start[(size_t)T] = SIZE_MAX;
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t)
-            th.emplace_back([&, t] {
-                static thread_local uint32_t lit[LIT_CAP], dist[DIST_CAP];
-                const size_t from = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)t;
-                const size_t limit = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)(t + 1);
-                start[(size_t)t] = find_block_start(in, in_end, from, limit, lit, dist);
-            });
-        for (auto &x : th) x.join();
-    }
+    if (!on_threads(1, T, [&](int t) {
+            static thread_local uint32_t lit[LIT_CAP], dist[DIST_CAP];
+            const size_t from = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)t;
+            const size_t limit = first_bit + (last_bit - first_bit) / (size_t)T * (size_t)(t + 1);
+            start[(size_t)t] = find_block_start(in, in_end, from, limit, lit, dist);
+        }))
+        return false;
     for (int t = 1; t < T; ++t)
         if (start[(size_t)t] == SIZE_MAX) return false;
     const double t_1 = trace ? tick() : 0.0;
@@ -802,10 +827,7 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
     // serial decoder instead of sizing sixteen 16-bit buffers after it)
     if (hint > 16 * n) return false;
     const size_t guess = std::max<size_t>((hint ? hint : 4 * n) / (size_t)T * 5 / 4, (size_t)1 << 20);
-    {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t] {
+    if (!on_threads(0, T, [&](int t) {
                 const uint8_t *af = nullptr;
                 const size_t piece_bytes = ((t + 1 < T ? start[(size_t)t + 1] : last_bit) - start[(size_t)t]) / 8 + 16;
                 const size_t cap = 2 * (WIN + 1040 * piece_bytes + ((size_t)1 << 20));   // (x 2: the buffer grows by doubling)
@@ -819,9 +841,8 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
                     ok[(size_t)t] = decode_piece<uint16_t>(in, in_end, start[(size_t)t], start[(size_t)t + 1], v, WIN, cap, &produced[(size_t)t], &af);
                 }
                 if (t == T - 1) after_final = af;
-            });
-        for (auto &x : th) x.join();
-    }
+        }))
+        return false;
     const double t_2 = trace ? tick() : 0.0;
     size_t total = 0;
     for (int t = 0; t < T; ++t) {
@@ -852,15 +873,11 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
     for (int t = 1; t < T; ++t) resolve(t, produced[(size_t)t] - WIN, produced[(size_t)t]);  // the tails, one after the other
     // ---- 4. checksum: every piece's CRC-32 by the thread that resolved it, combined in order ----
     std::vector<uint32_t> crc((size_t)T, 0);
-    {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t] {
-                if (t > 0) resolve(t, 0, produced[(size_t)t] - WIN);
-                crc[(size_t)t] = gdca_crc32(0, base + off[(size_t)t], produced[(size_t)t]);
-            });
-        for (auto &x : th) x.join();
-    }
+    if (!on_threads(0, T, [&](int t) {
+            if (t > 0) resolve(t, 0, produced[(size_t)t] - WIN);
+            crc[(size_t)t] = gdca_crc32(0, base + off[(size_t)t], produced[(size_t)t]);
+        }))
+        return false;
     const double t_3 = trace ? tick() : 0.0;
     uint32_t whole = crc[0];
     for (int t = 1; t < T; ++t) whole = gdca_crc32_combine(whole, crc[(size_t)t], produced[(size_t)t]);
@@ -870,4 +887,6 @@ bool gdca_gunzip_parallel(const uint8_t *in, size_t n, std::string &outbuf, size
                 (t_3 - t_2) * 1e3, (tick() - t_3) * 1e3);
     *len_out = total;
     return true;
+} catch (...) {
+    return false;  // (out of memory sizing a buffer: the serial decoder needs a fraction of it)
 }
