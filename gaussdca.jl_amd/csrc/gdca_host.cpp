@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -408,11 +409,26 @@ void parallel(int T, F fn)
         fn(0);
         return;
     }
+    // (nothing may leave a worker thread -- that would end the process -- and nothing is lost: what a thread threw, or a thread that
+    // could not be started, comes out of this function as std::bad_alloc in the caller's thread, after every started thread has ended)
     std::vector<std::thread> th;
-    th.reserve((size_t)T - 1);
-    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
-    fn(0);
+    std::atomic<bool> failed{false};
+    auto guarded = [&](int t) {
+        try {
+            fn(t);
+        } catch (...) {
+            failed = true;
+        }
+    };
+    try {
+        th.reserve((size_t)T - 1);
+        for (int t = 1; t < T; ++t) th.emplace_back(guarded, t);
+        guarded(0);
+    } catch (...) {
+        failed = true;
+    }
     for (auto &x : th) x.join();
+    if (failed) throw std::bad_alloc();
 }
 
 // the stripped non-empty lines of text[a, b), concatenated (what the reference's reader hands back as one
@@ -452,7 +468,7 @@ int32_t gdca_host_cpus(void)
 }
 
 gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fasta **out, int32_t *N, int32_t *M)
-{
+try {
     if (!path || !out || !N || !M) return GDCA_EINVAL;
     *out = nullptr;
     // GDCA_FASTA_TRACE=1: per-file phase times on stderr (debug aid for the feed-rate benchmark, tools/parse_bench.sh)
@@ -506,12 +522,13 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     const int32_t n = (int32_t)cols.size();
     if (n <= 0) return GDCA_EINVAL;
 
-    gdca_fasta *h = new (std::nothrow) gdca_fasta();
+    std::unique_ptr<gdca_fasta> hold(new (std::nothrow) gdca_fasta());  // (freed on every way out but the last line, exceptions included)
+    gdca_fasta *h = hold.get();
     if (!h) return GDCA_ENOMEM;
     h->N = n;
     h->Z = matbuf_get((size_t)n * R);
     if (!h->Z.p) {
-        delete h;
+        hold.reset();
         return GDCA_ENOMEM;
     }
     std::vector<uint8_t> keep(R, 0);
@@ -576,7 +593,7 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     });
     const double t_p2 = trace ? tick() : 0.0;
     if (misaligned) {
-        delete h;
+        hold.reset();
         return GDCA_EINVAL;
     }
     // pass 3: drop the filtered rows, order preserved
@@ -591,10 +608,14 @@ gdca_status gdca_fasta_open(const char *path, double max_gap_fraction, gdca_fast
     if (trace)
         fprintf(stderr, "fasta-trace %s bytes %zu threads %d read/inflate %.2f ms parse %.2f ms (headers %.2f, first record + buffers %.2f, records %.2f, compaction %.2f)\n",
                 path, L, T, t_read - t_open, tick() - t_read, t_p1 - t_read, t_alloc - t_p1, t_p2 - t_alloc, tick() - t_p2);
-    *out = h;
+    *out = hold.release();
     *N = h->N;
     *M = h->M;
     return GDCA_OK;
+} catch (const std::bad_alloc &) {
+    return GDCA_ENOMEM;  // (never an exception across the C boundary)
+} catch (...) {
+    return GDCA_EINVAL;
 }
 
 gdca_status gdca_fasta_copy(const gdca_fasta *h, int8_t *Z)
@@ -622,7 +643,7 @@ gdca_status gdca_fasta_close(gdca_fasta *h)
 
 gdca_status gdca_remove_duplicates(const int8_t *Z, int32_t N, int32_t M, int8_t *Z_out, int32_t *keep_idx,
                                    int32_t *M_out)
-{
+try {
     if (!Z || !Z_out || !M_out || N < 1 || M < 0) return GDCA_EINVAL;
     // The set's keys are views of the DESTINATION rows: row k is first copied to slot m of Z_out (m <= k, so with
     // Z_out == Z only a row that has already been examined is overwritten), then a view of that slot is inserted and
@@ -642,6 +663,10 @@ gdca_status gdca_remove_duplicates(const int8_t *Z, int32_t N, int32_t M, int8_t
     }
     *M_out = m;
     return GDCA_OK;
+} catch (const std::bad_alloc &) {
+    return GDCA_ENOMEM;  // (never an exception across the C boundary)
+} catch (...) {
+    return GDCA_EINVAL;
 }
 
 int64_t gdca_ranking_length(int32_t N, int32_t min_separation)
@@ -653,7 +678,7 @@ int64_t gdca_ranking_length(int32_t N, int32_t min_separation)
 
 gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int32_t *i_out, int32_t *j_out,
                          double *score_out)
-{
+try {
     if (!S || N < 1 || min_separation < 1) return GDCA_EINVAL;
     const int64_t len = gdca_ranking_length(N, min_separation);
     if (len == 0) return GDCA_OK;
@@ -728,16 +753,24 @@ gdca_status gdca_ranking(const double *S, int32_t N, int32_t min_separation, int
         score_out[e] = S[(size_t)(gj[g] - 1) + (size_t)(gi[g] - 1) * N];
     }
     return GDCA_OK;
+} catch (const std::bad_alloc &) {
+    return GDCA_ENOMEM;  // (never an exception across the C boundary)
+} catch (...) {
+    return GDCA_EINVAL;
 }
 
 gdca_status gdca_write_rank(const char *path, const int32_t *i, const int32_t *j, const double *score, int64_t len)
-{
+try {
     if (!path || (len > 0 && (!i || !j || !score))) return GDCA_EINVAL;
     FILE *f = fopen(path, "w");
     if (!f) return GDCA_EINVAL;
     for (int64_t t = 0; t < len; ++t) fprintf(f, "%i %i %e\n", i[t], j[t], score[t]);
     fclose(f);
     return GDCA_OK;
+} catch (const std::bad_alloc &) {
+    return GDCA_ENOMEM;  // (never an exception across the C boundary)
+} catch (...) {
+    return GDCA_EINVAL;
 }
 
 // ---- synthetic families ----------------------------------------------------------------------
@@ -797,7 +830,7 @@ gdca_status gdca_synth_family(int32_t N, int32_t M, int32_t q, uint64_t seed, in
 }
 
 gdca_status gdca_write_fasta(const char *path, const int8_t *Z, int32_t N, int32_t M)
-{
+try {
     if (!path || !Z || N < 1 || M < 0) return GDCA_EINVAL;
     static const char L[] = "?ACDEFGHIKLMNPQRSTVWY-";
     std::string out;
@@ -831,6 +864,10 @@ gdca_status gdca_write_fasta(const char *path, const int8_t *Z, int32_t N, int32
     if (!f) return GDCA_EINVAL;
     const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
     return (fclose(f) == 0 && ok) ? GDCA_OK : GDCA_EINVAL;
+} catch (const std::bad_alloc &) {
+    return GDCA_ENOMEM;  // (never an exception across the C boundary)
+} catch (...) {
+    return GDCA_EINVAL;
 }
 
 }  // extern "C"
