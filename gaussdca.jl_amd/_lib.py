@@ -53,7 +53,7 @@ class Stats(C.Structure):
         ("ms_total", C.c_double), ("ms_theta", C.c_double), ("ms_weights", C.c_double),
         ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
         ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
-        ("sweep_ghz", C.c_double), ("inverse_norm1", C.c_double),
+        ("sweep_ghz", C.c_double), ("inverse_norm1", C.c_double), ("matrix_norm1", C.c_double), ("cond_bound", C.c_double),
     ]
 
     def as_dict(self):

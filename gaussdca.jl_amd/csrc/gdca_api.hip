@@ -57,7 +57,7 @@ struct gdca_ctx {
     int n_ev;
     // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
     bool meff_pending;  // k_meff enqueued on the side stream, not yet joined
-    hipEvent_t ev_weights, ev_meff, ev_batch;
+    hipEvent_t ev_weights, ev_meff, ev_batch, ev_upload;
     bool pending;
     bool pend_timed;
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
@@ -66,7 +66,7 @@ struct gdca_ctx {
     double *pend_S;
     gdca_params pend_p;
     int pend_refined;
-    hipEvent_t pend_upd_ev[2]; // the two events around that launch (a merged launch's are its first member's)
+    hipEvent_t pend_upd_ev[2]; // the two events around that launch (this context's own, also for a merged launch)
     double pend_upd_flops;
 };
 
@@ -260,7 +260,8 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     }
     if (hipEventCreateWithFlags(&ctx->ev_weights, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
         gdca_ctx_destroy(ctx);
         return GDCA_EHIP;
     }
@@ -331,6 +332,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->ev_weights) (void)hipEventDestroy(ctx->ev_weights);
     if (ctx->ev_meff) (void)hipEventDestroy(ctx->ev_meff);
     if (ctx->ev_batch) (void)hipEventDestroy(ctx->ev_batch);
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
@@ -378,6 +380,27 @@ static gdca_status need_events(gdca_ctx *ctx, int n)
         HIPCHK(hipEventCreate(&ctx->ev[ctx->n_ev]));
         ++ctx->n_ev;
     }
+    return GDCA_OK;
+}
+
+// a member's failure as the LEADER's last error (the caller of a batch entry reads the leader's)
+static gdca_status member_error(gdca_ctx *lead, gdca_ctx *m, int k, gdca_status st)
+{
+    if (k > 0 && m != lead && m->err[0]) {
+        char msg[sizeof(lead->err)];
+        snprintf(msg, sizeof(msg), "member %d: %.400s", k, m->err);
+        memcpy(lead->err, msg, sizeof(msg));
+    }
+    return st;
+}
+
+// The host buffer of an upload just enqueued on ctx->stream may be reused by the caller: true at once for pageable memory (the copy
+// is staged before hipMemcpyAsync returns), a DMA still in flight for pinned or registered memory -- wait for it (an event right
+// behind the copy; the stream of a context that is not pending holds nothing else)
+static gdca_status upload_done(gdca_ctx *ctx)
+{
+    HIPCHK(hipEventRecord(ctx->ev_upload, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev_upload));
     return GDCA_OK;
 }
 
@@ -438,8 +461,9 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
 }
 
 // stage 3: Pi, pair tallies.  mode 0 -> Pij_true (ld) ; mode 1 -> covariance (ld)
+// want_norm1 (mode 1): the covariance build also leaves ||C||_1 in sc->mat_norm1 (a reduction inside its epilogue)
 static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, int q, const double *Meff_dev, double pc,
-                               int mode, double *Pi_true_out, double *out, size_t ld)
+                               int mode, double *Pi_true_out, double *out, size_t ld, bool want_norm1 = false)
 {
     hipStream_t s = ctx->stream;
     const int sdim = q - 1, n = N * sdim;
@@ -449,6 +473,7 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     CHK(ensure(ctx, ctx->Zp, (size_t)round_up(N, 64) * M + 64));
     CHK(ensure(ctx, ctx->Pifix, (size_t)N * 32 * sizeof(unsigned long long)));
     CHK(ensure(ctx, ctx->Pipc, (size_t)n * sizeof(double)));
+    if (want_norm1) CHK(ensure(ctx, ctx->normws, (size_t)round_up(n, GDCA_TILE) * sizeof(double)));  // (the ||X||_1 pass uses it later)
     gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
     gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
@@ -462,7 +487,8 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
                             (double *)ctx->Pipc.p);
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
                            (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
-                           (const double *)ctx->Pipc.p, mode, out, ld, TJ);
+                           (const double *)ctx->Pipc.p, mode, out, ld, TJ, want_norm1 ? (unsigned long long *)ctx->normws.p : nullptr,
+                           want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->mat_norm1 : nullptr);
     return check_launch(ctx, "tally");
 }
 
@@ -599,22 +625,26 @@ static gdca_status inverse_norm_stage(gdca_ctx *ctx, int n, int n_pad)
     return check_launch(ctx, "inverse_norm1");
 }
 
-// The screen every fused run pays for (n diagonal entries): max_i X(i, i) <= ||X||_1 <= n max_i X(i, i) for the SPD inverse.  Only
-// where it comes within a factor 256 of the threshold does the collect spend a pass over the triangle on ||X||_1 itself.
-static gdca_status inverse_screen_stage(gdca_ctx *ctx, int n, int n_pad)
+// The screen of the fused path costs no pass over anything: the covariance with pseudocount pc is that of a MIXTURE -- weight 1 - pc
+// on the reweighted alignment, weight pc on independent uniform columns -- so  C >= pc Cov_uniform  in the positive-definite order, and
+// Cov_uniform = blockdiag(I / q - 1 1^T / q^2) (q - 1 states a column) has smallest eigenvalue 1 / q^2:
+//       lambda_min(C) >= pc / q^2,     cond_2(C) <= ||C||_1 q^2 / pc
+// (attained on every alignment tried: a column without gaps makes the bound sharp).  ||C||_1 comes out of the covariance build's
+// epilogue (sc->mat_norm1, no extra pass; on the reference's `large` data 64 .. 94), so at the pseudocounts gDCA is used with the
+// bound is 1e4 .. 1e5 and the run pays nothing; beyond the threshold the collect measures ||X||_1 itself (one pass over the lower
+// triangle) and decides on kappa_1 = ||C||_1 ||X||_1 like the operator-level entry.  Returns +inf where there is no bound (pc = 0).
+static double cond_bound(const gdca_dev_scalars &h, double pc, int q)
 {
-    if (ctx->tune.refine == 0) return GDCA_OK;
-    gdca_launch_inverse_diagmax(ctx->stream, (const double *)ctx->A.p, n_pad, n, &((gdca_dev_scalars *)ctx->sc.p)->inv_diagmax);
-    return check_launch(ctx, "inverse_diagmax");
+    if (!(h.mat_norm1 > 0.0) || !(pc > 0.0)) return HUGE_VAL;
+    return h.mat_norm1 * (double)q * (double)q / pc;
 }
 
 static bool wants_refinement(const gdca_ctx *ctx, const gdca_dev_scalars &h)
 {
     if (h.info != 0 || ctx->tune.refine == 0) return false;
     if (ctx->tune.refine == 1) return true;
-    if (!(h.inv_norm1 > 0.0)) return false;  // the screen (max diagonal entry) stayed far below the threshold
-    // kappa_1 = ||C||_1 ||X||_1 where ||C||_1 was at hand (operator-level entry); in the fused path ||X||_1 alone: the covariance of
-    // indicator variables has entries <= 1/4 and ||C||_1 of order one
+    if (!(h.inv_norm1 > 0.0)) return false;  // not measured: the a-priori bound on cond(C) was below the threshold
+    // kappa_1 = ||C||_1 ||X||_1 (||C||_1: the covariance build's, or the caller's matrix at the operator-level entry)
     return h.inv_norm1 * (h.mat_norm1 > 0.0 ? h.mat_norm1 : 1.0) > ctx->tune.refine_cond;
 }
 
@@ -662,8 +692,8 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     ctx->rank_pending = false;  // (collected through this entry, a ranked run's ranking is given up: its arrays are scratch of the next run)
     CHK(fetch_scalars(ctx));
     if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
-        (ctx->tune.refine == 1 || ctx->sc_host->inv_diagmax * 256.0 > ctx->tune.refine_cond)) {
-        CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));   // the screen says "maybe": ||X||_1 itself
+        (ctx->tune.refine == 1 || cond_bound(*ctx->sc_host, ctx->pend_p.pseudocount, ctx->pend_q) > ctx->tune.refine_cond)) {
+        CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));   // cond(C) may be beyond the threshold: ||X||_1 itself
         CHK(fetch_scalars(ctx));
     }
     if (wants_refinement(ctx, *ctx->sc_host) && !ctx->sc_host->bad_symbol) {
@@ -722,7 +752,9 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->update_launches = ctx->pend_nupd;
         st->inverse_batch = ctx->pend_batch;
         st->refined = ctx->pend_refined;
-        st->inverse_norm1 = h.inv_norm1 > 0.0 ? h.inv_norm1 : h.inv_diagmax;
+        st->inverse_norm1 = h.inv_norm1;
+        st->matrix_norm1 = h.mat_norm1;
+        st->cond_bound = ctx->tune.refine != 0 ? cond_bound(h, ctx->pend_p.pseudocount, ctx->pend_q) : 0.0;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
@@ -790,7 +822,7 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
     if (timed) HIPCHK(hipEventRecord(ev[2], s));
 
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
-    CHK(tally_stage(ctx, Z_dev, N, M, q, &sc->Meff, p->pseudocount, 1, nullptr, (double *)ctx->A.p, (size_t)n_pad));
+    CHK(tally_stage(ctx, Z_dev, N, M, q, &sc->Meff, p->pseudocount, 1, nullptr, (double *)ctx->A.p, (size_t)n_pad, ctx->tune.refine != 0));
     gdca_launch_pad_identity(s, (double *)ctx->A.p, n, n_pad);
     if (p->score == GDCA_SCORE_DI) {
         CHK(ensure(ctx, ctx->Dblk, (size_t)N * sdim * sdim * sizeof(double)));
@@ -841,8 +873,7 @@ static gdca_status run_inverse(gdca_ctx *ctx)
 }
 
 // The inverses of K members of a phase batch as ONE merged launch on the batch's stream (k_sweep_merged: small matrices, which
-// leave most of the chip idle when they run alone).  Every member keeps its own workspace, flags and scalars; the events around
-// the launch are the first member's.
+// leave most of the chip idle when they run alone).  Every member keeps its own workspace, flags, scalars and events.
 static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int K)
 {
     gdca_ctx *ctx = mem[0];
@@ -865,13 +896,17 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
         jobs[k].tune = &tun[k];
         if (lead->tune.sweep_debug & 16) CHK(poison_inverse_ws(mem[k], s));
     }
-    hipEvent_t *uev = nullptr;
-    if (timed) {
-        CHK(need_events(ctx, 18));
-        uev = ctx->ev + 16;
-    }
-    gdca_launch_spd_inverse_merged(s, jobs, K, uev, timed ? 2 : 0, flops);
+    // every timed member brackets the launch with events of ITS OWN: members may be collected, enqueued again or destroyed in any
+    // order, and a collect must never read another context's events
+    if (timed)
+        for (int k = 0; k < K; ++k) {
+            CHK(need_events(mem[k], 18));
+            HIPCHK(hipEventRecord(mem[k]->ev[16], s));
+        }
+    gdca_launch_spd_inverse_merged(s, jobs, K, nullptr, 0, flops);
     CHK(check_launch(ctx, "spd_inverse_merged"));
+    if (timed)
+        for (int k = 0; k < K; ++k) HIPCHK(hipEventRecord(mem[k]->ev[17], s));
     for (int k = 0; k < K; ++k) {
         gdca_ctx *m = mem[k];
         if (m->pend_timed) HIPCHK(hipEventRecord(m->ev[4], s));
@@ -888,8 +923,8 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
         // (a member without timing of its own still gets valid events to read: the launch's, or none -- collect reads them only if timed)
         m->pend_timed = m->pend_timed && timed;
         if (timed) {
-            m->pend_upd_ev[0] = uev[0];
-            m->pend_upd_ev[1] = uev[1];
+            m->pend_upd_ev[0] = m->ev[16];
+            m->pend_upd_ev[1] = m->ev[17];
         }
     }
     return GDCA_OK;
@@ -898,7 +933,6 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
 static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
     ctx->pend_S = S_dev;
-    CHK(inverse_screen_stage(ctx, ctx->pend_n, ctx->pend_npad));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;
@@ -1098,6 +1132,7 @@ gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z_host, int32_t N
     // (from pageable memory this copy holds the calling thread until the last byte is staged -- and overlaps whatever another
     // context of the same device is computing meanwhile: the pipelined batch driver's upload of the NEXT family)
     HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, Z_host, (size_t)N * M, hipMemcpyHostToDevice, ctx->stream));
+    CHK(upload_done(ctx));  // Z_host is the caller's again when this call returns (gdca.h), pinned or not
     double *S_dev = (double *)ctx->scratch[1].p;
     CHK(gdca_run_dev_async(ctx, (const int8_t *)ctx->scratch[0].p, N, M, q, p, S_dev));
     // the ranking is enqueued behind the scores before anybody waits: one synchronisation for the whole run
@@ -1137,7 +1172,7 @@ gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const
         gdca_ctx *m = ctxs[k];
         gdca_status es = ensure(m, m->scratch[0], (size_t)N[k] * M[k]);
         if (es == GDCA_OK) es = ensure(m, m->scratch[1], (size_t)N[k] * N[k] * sizeof(double));
-        if (es != GDCA_OK) return es;
+        if (es != GDCA_OK) return member_error(lead, m, k, es);
         // (each member's upload goes to its own stream; gdca_run_dev_phased waits for the members' streams before it enqueues
         // anything, and the leader's upload sits on the very stream the batch is enqueued on)
         if (hipMemcpyAsync(m->scratch[0].p, Z_host[k], (size_t)N[k] * M[k], hipMemcpyHostToDevice, m->stream) != hipSuccess)
@@ -1145,6 +1180,10 @@ gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const
         Zd[k] = (const int8_t *)m->scratch[0].p;
         Sd[k] = (double *)m->scratch[1].p;
     }
+    // Z_host may be released when this call returns (gdca.h): from pageable memory the copies above are complete by now, from
+    // pinned or registered memory they are true DMAs still in flight -- wait for the leader's here (the members' streams are
+    // synchronised by gdca_run_dev_phased before anything is enqueued)
+    CHK(upload_done(lead));
     CHK(gdca_run_dev_phased(ctxs, K, Zd, N, M, q, p, Sd));
     // every member's ranking behind its scores, on the member's own stream (which now waits for the batch)
     for (int k = 0; k < K; ++k) {
@@ -1434,7 +1473,10 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
         const int n_pad = round_up(n[k], GDCA_TILE);
         st = begin(m);
         if (st == GDCA_OK) st = ensure(m, m->A, (size_t)n_pad * n_pad * sizeof(double));
-        if (st != GDCA_OK) break;
+        if (st != GDCA_OK) {
+            member_error(lead, m, k, st);
+            break;
+        }
         gdca_launch_copy_in(lead->stream, A_dev[k], n[k], (double *)m->A.p, n_pad);
         m->pend_n = n[k];
         m->pend_npad = n_pad;
@@ -1443,8 +1485,8 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
     if (st == GDCA_OK) st = run_inverses(lead, ctxs, K);
     // kappa_1 and, where it is beyond the threshold, the Newton-Schulz step: member by member, as gdca_spd_inverse_dev does (the
     // caller's matrices are still intact; each member's switches are its own context's)
-    for (int k = 0; k < K && st == GDCA_OK; ++k) st = operator_norms_and_refine(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad);
-    for (int k = 0; k < K && st == GDCA_OK; ++k) st = operator_fallback(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad);
+    for (int k = 0; k < K && st == GDCA_OK; ++k) st = member_error(lead, ctxs[k], k, operator_norms_and_refine(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad));
+    for (int k = 0; k < K && st == GDCA_OK; ++k) st = member_error(lead, ctxs[k], k, operator_fallback(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad));
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
         gdca_launch_copy_out_neg_sym(lead->stream, (const double *)ctxs[k]->A.p, ctxs[k]->pend_npad, A_dev[k], n[k]);
         st = check_launch(lead, "copy_out");

@@ -25,7 +25,7 @@ struct gdca_dev_scalars {
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
     double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
     double ns_resid;     // max |I - X0 C| seen by the Newton-Schulz step (0: no step)
-    double mat_norm1;  // ||C||_1 where the caller's matrix was at hand (operator-level inverse), else 0
+    double mat_norm1;  // ||C||_1: from the covariance build's epilogue (fused path) or the caller's matrix (operator-level inverse); 0: not measured
 };
 
 // Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
@@ -104,7 +104,9 @@ int gdca_tally_tj(int q, int tj_wanted);
 void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ);
 void gdca_launch_pair_tally(hipStream_t s, const int8_t *Zc, const int8_t *Zt, const unsigned long long *Wfix,
                             int N, int M, int q, int fix_shift, const double *Meff_dev, double pc,
-                            const double *Pi_pc, int mode, double *out, size_t ld, int TJ);
+                            const double *Pi_pc, int mode, double *out, size_t ld, int TJ,
+                            unsigned long long *colabs_fix = nullptr, double *norm1_out = nullptr);
+// (mode 1, colabs_fix != nullptr: [N (q-1)] scratch; the kernel also leaves ||C||_1 of the covariance it writes in *norm1_out)
 
 // ---- k_elementwise.hip ---------------------------------------------------------------------
 void gdca_launch_add_pseudocount(hipStream_t s, const double *Pi_true, const double *Pij_true, int N, int q,

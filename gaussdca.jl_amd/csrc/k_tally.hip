@@ -155,7 +155,7 @@ template <int TJ>
 __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
     const int8_t *__restrict__ Zc, const int8_t *__restrict__ Zt, const u64 *__restrict__ Wfix, int N, int M,
     int q, int fix_shift, const double *__restrict__ Meff_dev, double pc, const double *__restrict__ Pi_pc, int mode,
-    double *__restrict__ out, size_t ld)
+    double *__restrict__ out, size_t ld, u64 *__restrict__ colabs_fix)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = q - 1;
@@ -248,24 +248,49 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
             pi_j[e] = (jj < N) ? Pi_pc[jj * s + (e % s)] : 0.0;
         }
     }
+    // ||C||_1 on the way (colabs_fix != nullptr): the column sums of |C| in 2^-46 fixed point -- integer sums: exact and independent
+    // of the order of the atomics, like the tallies themselves -- of this workgroup's elements, first in LDS: [s] for the columns
+    // (i, a), [TJ s] for the mirror columns (j, b).  The decision on a refinement of the inverse needs cond(C) (gdca_run_collect).
+    u64 *colacc = reinterpret_cast<u64 *>(zs);
+    if (colabs_fix)
+        for (int e = tid; e < s + TJ * s; e += TALLY_THREADS) colacc[e] = 0ull;
     __syncthreads();
     const double Meff = *Meff_dev;
     const double pcq = pc / (double)q;
     const double off_add = pcq / (double)q;
     const int total = s * s * TJ;
     // pass 1: element (row j*s+b, col i*s+a): contiguous over (j, b) for fixed a
-    for (int e = tid; e < total; e += TALLY_THREADS) {
+    for (int e0 = 0; e0 < total; e0 += TALLY_THREADS) {
+        const int e = e0 + tid;
         const int a = e / (TJ * s), rem = e - a * (TJ * s);
         const int l = rem / s, b = rem - l * s;
         const int jj = j0 + l;
-        if (jj >= N || jj < i) continue;
-        const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
-        double v = pt;
-        if (mode == 1) {
-            const double pij = (jj != i) ? ((1.0 - pc) * pt + off_add) : ((1.0 - pc) * pt + ((a == b) ? pcq : 0.0));
-            v = pij - pi_i[a] * pi_j[rem];
+        const bool live = e < total && jj < N && jj >= i;
+        double v = 0.0;
+        if (live) {
+            const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
+            v = pt;
+            if (mode == 1) {
+                const double pij = (jj != i) ? ((1.0 - pc) * pt + off_add) : ((1.0 - pc) * pt + ((a == b) ? pcq : 0.0));
+                v = pij - pi_i[a] * pi_j[rem];
+            }
+            out[(size_t)(jj * s + b) + (size_t)(i * s + a) * ld] = v;
         }
-        out[(size_t)(jj * s + b) + (size_t)(i * s + a) * ld] = v;
+        if (colabs_fix) {  // (uniform)
+            const u64 fx = live ? (u64)(fabs(v) * 0x1p46) : 0ull;
+            // column (i, a): with s = 20 and 16 or 32 columns per block a wave's 64 elements share one a -- one butterfly, one atomic;
+            // otherwise lane by lane
+            const int a0 = __builtin_amdgcn_readfirstlane(a);
+            if (__all(a == a0)) {
+                u64 t = fx;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                if (lane == 0 && t != 0ull && a0 < s) atomicAdd(&colacc[a0], t);
+            } else if (live)
+                atomicAdd(&colacc[a], fx);
+            // the mirror element lies in column (jj, b) (a diagonal block is written in full by this pass: no mirror)
+            if (live && jj > i) atomicAdd(&colacc[s + rem], fx);
+        }
     }
     // pass 2: the mirror element (row i*s+a, col j*s+b): contiguous over a for fixed (j, b)
     for (int e = tid; e < total; e += TALLY_THREADS) {
@@ -281,6 +306,30 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
         }
         out[(size_t)(i * s + a) + (size_t)(jj * s + b) * ld] = v;
     }
+    if (colabs_fix) {
+        __syncthreads();
+        for (int e = tid; e < s + TJ * s; e += TALLY_THREADS) {
+            const u64 t = colacc[e];
+            if (t == 0ull) continue;
+            const int col = e < s ? i * s + e : (j0 + (e - s) / s) * s + (e - s) % s;
+            atomicAdd(&colabs_fix[col], t);
+        }
+    }
+}
+
+// *out = max_c colabs_fix[c] 2^-46 = ||C||_1 of the matrix k_pair_tally has just written
+__global__ __launch_bounds__(256) void k_colabs_fix_max(const u64 *__restrict__ colabs_fix, int n, double *__restrict__ out)
+{
+    __shared__ u64 red[256];
+    u64 a = 0ull;
+    for (int k = threadIdx.x; k < n; k += 256) a = max(a, colabs_fix[k]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (double)red[0] * 0x1p-46;
 }
 
 static size_t tally_lds_bytes(int s, int TJ)
@@ -299,18 +348,21 @@ int gdca_tally_tj(int q, int tj_wanted)
 
 void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,
                             int fix_shift, const double *Meff_dev, double pc, const double *Pi_pc, int mode,
-                            double *out, size_t ld, int TJ)
+                            double *out, size_t ld, int TJ, unsigned long long *colabs_fix, double *norm1_out)
 {
     const int s = q - 1;
+    if (mode != 1) colabs_fix = nullptr;
+    if (colabs_fix) (void)hipMemsetAsync(colabs_fix, 0, (size_t)N * s * sizeof(u64), st);
     if (TJ == 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld, colabs_fix);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_pair_tally<16>, dim3((N + 15) / 16, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 16), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld, colabs_fix);
     }
+    if (colabs_fix && norm1_out) hipLaunchKernelGGL(k_colabs_fix_max, dim3(1), dim3(256), 0, st, colabs_fix, N * s, norm1_out);
 }

@@ -80,7 +80,7 @@ typedef struct gdca_stats {
     int32_t update_launches;    /* launches of the dominant kernel this run accounts for (a merged launch: its first member) */
     int32_t inverse_batch;      /* families that shared this run's SPD-inverse launch (gdca_run_dev_phased merges the small ones;
                                    1 = a launch of its own).  ms_inverse and ms_inverse_update are the launch's time divided by it */
-    int32_t refined;            /* 1: the inverse looked ill-conditioned (inverse_norm1 beyond REFINE_COND) and got a Newton-Schulz
+    int32_t refined;            /* 1: the covariance is ill-conditioned (kappa_1 = matrix_norm1 * inverse_norm1 beyond REFINE_COND) and the inverse got a Newton-Schulz
                                    step, the scores were computed again from it (the ms_* are those of the first pass);
                                    -1: the step was taken but cannot have converged (residual |I - X C| >= 1: cond(C) beyond ~1e10,
                                    where the sweep's own error is of order one) and option CHOLESKY is 0 -- the scores are not
@@ -100,9 +100,16 @@ typedef struct gdca_stats {
     double update_flops;        /* flops executed by all launches of the dominant kernel    */
     double sweep_ghz;           /* shader clock during the SPD-inverse kernel, measured by the kernel itself
                                    (s_memtime cycles / 100 MHz wall-clock ticks, summed over its workgroups); 0 if no inverse ran */
-    double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it -- with ||C||_1 of order one (a covariance of indicator variables)
-                                   an estimate of cond(C) -- where it was needed to decide on a refinement; else its lower bound
-                                   max_i inv(C)(i, i), the screen every run computes; 0 with option REFINE=0 */
+    double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it, measured (one pass over the inverse) only where cond_bound is
+                                   beyond REFINE_COND: the decision on a refinement is kappa_1 = matrix_norm1 * inverse_norm1 >
+                                   REFINE_COND.  0: not measured (the bound settled it, or option REFINE=0) */
+    double matrix_norm1;        /* ||C||_1 of the covariance (src/GaussDCA.jl:32), from the epilogue of its build: 64 .. 94 on the
+                                   reference's test/data/large.fasta.gz, not "of order one"; 0 with option REFINE=0 */
+    double cond_bound;          /* a-priori bound of cond_2(C): matrix_norm1 * q^2 / pseudocount.  The covariance with pseudocount pc is
+                                   that of a mixture with weight pc on independent uniform columns, hence lambda_min(C) >= pc / q^2
+                                   (sharp whenever some column has no gap).  Every run whose bound is below REFINE_COND is
+                                   KNOWN to be well enough conditioned for the sweep and pays nothing for the screen; +inf at
+                                   pseudocount 0; 0 with option REFINE=0 */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */

@@ -37,7 +37,7 @@ mutable struct GdcaStats
     ms_total::Cdouble; ms_theta::Cdouble; ms_weights::Cdouble; ms_covariance::Cdouble
     ms_inverse::Cdouble; ms_inverse_update::Cdouble; ms_score::Cdouble
     inverse_flops::Cdouble; update_flops::Cdouble
-    sweep_ghz::Cdouble; inverse_norm1::Cdouble
+    sweep_ghz::Cdouble; inverse_norm1::Cdouble; matrix_norm1::Cdouble; cond_bound::Cdouble
     GdcaStats() = new()
 end
 
@@ -112,7 +112,10 @@ function gDCA(filename::AbstractString; pseudocount::Real = 0.8, θ = :auto, max
     end
     q = Int(maximum(Z))
     q ≥ 32 && error("parameter q=$q is too big (max 31 is allowed)")
-    R, _ = hot_path_ranked(Z, q, pseudocount, θ, score, min_separation)
+    R, st = hot_path_ranked(Z, q, pseudocount, θ, score, min_separation)
+    # (gdca.h, gdca_stats.refined: -1 = the refinement of an ill-conditioned inverse cannot have converged and the Cholesky
+    # fallback is switched off -- the Python mirror warns in the same case)
+    st.refined < 0 && @warn "covariance too ill-conditioned for the refinement step and option CHOLESKY=0: scores are unreliable" pseudocount kappa_1 = st.matrix_norm1 * st.inverse_norm1
     return R
 end
 

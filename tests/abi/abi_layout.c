@@ -40,6 +40,8 @@ int main(void)
     F(gdca_stats, update_flops);
     F(gdca_stats, sweep_ghz);
     F(gdca_stats, inverse_norm1);
+    F(gdca_stats, matrix_norm1);
+    F(gdca_stats, cond_bound);
     printf("status GDCA_OK %d 0\nstatus GDCA_EINVAL %d 0\nstatus GDCA_ENOTPD %d 0\nstatus GDCA_EHIP %d 0\n"
            "status GDCA_ENOMEM %d 0\nstatus GDCA_ENOCONV %d 0\n",
            GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV);
