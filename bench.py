@@ -34,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0  # HBM3E peak bandwidth (MI355X_MICROARCH.md)
 SPEC_SHADER_GHZ = 2.4  # the clock the spec peak is quoted at; the clock of the timed launches is measured by k_sweep itself
 PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_update_traffic.json")
 
@@ -485,6 +486,7 @@ def main():
                     others[key]["roofline"] = {k: o2["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                                                              "launches_per_step", "measured_shader_ghz",
                                                                              "frac_of_attainable_at_measured_clock")}
+                    others[key]["roofline_hbm"] = o2.get("roofline_hbm", [])
                 except Exception as e:  # noqa: BLE001
                     others[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["other_configs"] = others
@@ -610,6 +612,29 @@ def measure(args, config, score_name, steps, warmup, rank, world, local, dev, di
                 stats=stats, dt=dt, steps=steps, warm=warm, P=P, phased=phased)
 
 
+def hbm_records(stats, q):
+    """`roofline` objects (bound "hbm") of the HBM-bound kernels of the timed runs: FN and the covariance write."""
+    import numpy as np
+
+    out = []
+    s_dim = q - 1
+    fn = [(8.0 * st["n"] * (st["n"] - s_dim) / 2.0, st["ms_fn"]) for st in stats if st.get("ms_fn", 0.0) > 0.0]
+    if fn:
+        by, ms = float(np.sum([b for b, _ in fn])), float(np.sum([m for _, m in fn]))
+        ach = by / (ms * 1e-3) / 1e9
+        out.append({"kernel": "k_fn (compute_FN: one pass over the lower block triangle of the inverse)", "bound": "hbm", "achieved": ach,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "bytes_per_launch": by / len(fn),
+                    "avg_launch_ms": ms / len(fn), "traffic": None})
+    pt = [(8.0 * st["n"] * st["n"], st["ms_pair_tally"]) for st in stats if st.get("ms_pair_tally", 0.0) > 0.0]
+    if pt:
+        by, ms = float(np.sum([b for b, _ in pt])), float(np.sum([m for _, m in pt]))
+        ach = by / (ms * 1e-3) / 1e9
+        out.append({"kernel": "k_pair_tally (pair tallies + pseudocount + covariance epilogue: C written once, 8 n^2 bytes; the kernel is "
+                              "bound by its LDS atomics)", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "bytes_per_launch": by / len(pt), "avg_launch_ms": ms / len(pt), "traffic": None})
+    return out
+
+
 def summarize(args, meas, world, dist, comm_fallback):
     """Rank 0's JSON object of one measurement (all ranks take part in the reductions)."""
     import numpy as np
@@ -701,6 +726,11 @@ def summarize(args, meas, world, dist, comm_fallback):
             "attainable_at_measured_clock": PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ,
             "frac_of_attainable_at_measured_clock": (achieved / (PEAK_F64_MFMA_TFLOPS * ghz / SPEC_SHADER_GHZ)) if ghz > 0 else None,
         },
+        # the HBM-bound stages: algorithmic bytes / the kernel's own duration (HIP events around that kernel on its
+        # stream, gdca_stats.ms_fn / ms_pair_tally) against the 8 TB/s HBM3E peak.  FN: one pass over the lower block triangle of
+        # the inverse, 8 n (n - s) / 2 bytes.  The covariance build's compulsory write (8 n^2 bytes) is listed against the pair-tally
+        # kernel that contains it -- a kernel bound by its LDS atomics, not by that write: the fraction says how far from HBM it is.
+        "roofline_hbm": hbm_records(stats, q),
         "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                  "data_path_collectives": 0, "fallback_reason": comm_fallback},
     }

@@ -54,6 +54,7 @@ class Stats(C.Structure):
         ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
         ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
         ("sweep_ghz", C.c_double), ("inverse_norm1", C.c_double), ("matrix_norm1", C.c_double), ("cond_bound", C.c_double),
+        ("ms_fn", C.c_double), ("ms_pair_tally", C.c_double),   # (new fields go to the END: an older build of the library fills a prefix)
     ]
 
     def as_dict(self):

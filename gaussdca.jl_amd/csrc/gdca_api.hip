@@ -39,6 +39,7 @@ struct gdca_ctx {
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
     gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
     gdca_buf Wd;                  // Cholesky fallback: the inverses of the diagonal tiles of the factor
+    gdca_buf hcand;               // reweighting, bound form: the list of candidate pairs
     gdca_buf rankws;              // device ranking: keys, values, histograms, the three output arrays
     // an enqueued ranked run (gdca_run_ranked_async): where its ranking will be, and whether enqueueing it worked
     bool rank_pending = false;
@@ -60,6 +61,7 @@ struct gdca_ctx {
     hipEvent_t ev_weights, ev_meff, ev_batch, ev_upload;
     bool pending;
     bool pend_timed;
+    bool pend_fn_timed, pend_tally_timed;  // events 7 / 8 around k_fn, 9 / 10 around k_pair_tally were recorded by this run
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
     int pend_batch;            // families that shared this run's SPD-inverse launch (1: a launch of its own)
     const int8_t *pend_Z;      // what a refinement at collect time needs to build C again and to score again
@@ -318,7 +320,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
-                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd, &ctx->rankws};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd, &ctx->rankws, &ctx->hcand};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -437,6 +439,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE;
     CHK(ensure(ctx, ctx->Zb, gdca_bitplane_bytes(N, M)));
     CHK(ensure(ctx, ctx->hcnt, (size_t)Mt * GDCA_HTILE * sizeof(int32_t)));
+    if (!ctx->tune.force_fallback && ctx->tune.hamming_mode != 0) CHK(ensure(ctx, ctx->hcand, gdca_hamming_cand_cap(M) * 8));
     CHK(ensure(ctx, ctx->nk, (size_t)M * sizeof(int32_t)));
     CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
@@ -447,7 +450,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     if (ctx->tune.force_fallback)
         gdca_launch_hamming_fallback(s, Zd, (int32_t *)ctx->hcnt.p, N, M, sc);
     else
-        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode);
+        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, Zd, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode, ctx->hcand.p);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
     // Meff is one long dependent chain on a single CU: run it on the side stream, next to the kernels that
@@ -485,10 +488,13 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     }
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
                             (double *)ctx->Pipc.p);
+    const bool tm = want_norm1 && ctx->timing && ctx->n_ev >= 18;  // (the fused path's first build: its own device time, gdca_stats.ms_pair_tally)
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[9], s));
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
                            (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
                            (const double *)ctx->Pipc.p, mode, out, ld, TJ, want_norm1 ? (unsigned long long *)ctx->normws.p : nullptr,
                            want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->mat_norm1 : nullptr);
+    if (tm) HIPCHK(hipEventRecord(ctx->ev[10], s));
     return check_launch(ctx, "tally");
 }
 
@@ -569,7 +575,7 @@ static gdca_status inverse_stage(gdca_ctx *ctx, int n, int n_pad, bool timed, in
     return check_launch(ctx, "spd_inverse");
 }
 
-static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int score, int apc, double *S_dev)
+static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int score, int apc, double *S_dev, bool time_fn = false)
 {
     hipStream_t s = ctx->stream;
     if (score == GDCA_SCORE_DI) {
@@ -577,7 +583,11 @@ static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int sc
         gdca_launch_di(s, (const double *)ctx->A.p, (size_t)n_pad, (const double *)ctx->Ld.p, N, sdim, S_dev,
                        (double *)ctx->Tws.p, (gdca_dev_scalars *)ctx->sc.p);
     } else {
+        const bool tm = time_fn && ctx->n_ev >= 18;  // (a timed fused run: gdca_stats.ms_fn)
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[7], s));
         gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev);
+        if (tm) HIPCHK(hipEventRecord(ctx->ev[8], s));
+        if (time_fn) ctx->pend_fn_timed = tm;
     }
     if (apc) {
         CHK(ensure(ctx, ctx->colsum, (size_t)N * sizeof(double)));
@@ -777,6 +787,14 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
             st->ms_score = ms;
             HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
             st->ms_inverse_update = ms * share;
+            if (ctx->pend_fn_timed && ctx->pend_refined == 0) {
+                HIPCHK(hipEventElapsedTime(&ms, ev[7], ev[8]));
+                st->ms_fn = ms;
+            }
+            if (ctx->pend_tally_timed && ctx->pend_refined == 0) {
+                HIPCHK(hipEventElapsedTime(&ms, ev[9], ev[10]));
+                st->ms_pair_tally = ms;
+            }
         }
     }
     if (h.bad_symbol) return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
@@ -833,6 +851,8 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
     CHK(check_launch(ctx, "covariance"));
     if (timed) HIPCHK(hipEventRecord(ev[3], s));
     ctx->pend_timed = timed;
+    ctx->pend_tally_timed = timed && ctx->tune.refine != 0;
+    ctx->pend_fn_timed = false;
     ctx->pend_Z = Z_dev;
     ctx->pend_p = *p;
     ctx->pend_refined = 0;
@@ -933,7 +953,7 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
 static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
     ctx->pend_S = S_dev;
-    CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev));
+    CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev, ctx->pend_timed));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;
     return GDCA_OK;

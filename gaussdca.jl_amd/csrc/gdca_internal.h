@@ -21,6 +21,7 @@ struct gdca_dev_scalars {
     int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
     int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement
     int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
+    unsigned ham_ncand;  // pairs the bound form has put (or tried to put) into its candidate list: beyond the list's capacity the exact form counts
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
     double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
@@ -77,7 +78,9 @@ void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int
                                gdca_dev_scalars *sc);
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
 // force: -1 = decide per family from a sample of tiles, 0 = the exact form, 1 = the lower bound with refinement
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force);
+size_t gdca_hamming_cand_cap(int M);  // pairs the bound form's candidate list holds (8 bytes each)
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force,
+                         void *cand_list);
 // the same counts by an independent plain byte-compare kernel straight from Z (GDCA_FORCE_FALLBACK; overwrites cnt[0..M-1])
 void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc);
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)

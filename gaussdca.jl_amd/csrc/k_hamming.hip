@@ -113,19 +113,95 @@ __device__ __forceinline__ void tri_decode(int t, int Mt, int &I, int &J)
 #define HAM_BOUND_PLANES 3
 #define HAM_CAND_CAP 1024  // candidate pairs of one tile per pass of the refinement
 
+// "does any thread of the (one-dimensional, 256-thread) workgroup say yes?" with ONE barrier: call number k (the same in every thread, counted
+// from 0) collects into slot k % 3 and clears slot (k + 1) % 3 for the next call before its barrier -- the readers of that slot (call
+// k - 2) are all past the barrier of call k - 1.  hm_any[0 .. 1] are zeroed at the start of the kernel.  (__syncthreads_or builds a
+// three-dimensional thread index for its own LDS slot: its y and z parts were hoisted out of the chunk loop and kept in scratch.)
+__shared__ int hm_any[3];
+__device__ __forceinline__ bool wg_any(bool pred, int &k)
+{
+    const int s = k % 3, n = (k + 1) % 3;
+    ++k;
+    if (threadIdx.x == 0) hm_any[n] = 0;
+    if (__any(pred) && (threadIdx.x & 63) == 0) atomicOr(&hm_any[s], 1);
+    __syncthreads();
+    return hm_any[s] != 0;
+}
+
+// ---- the bound form's candidates ----------------------------------------------------------------------------------------------
+// k_hamming<3, false> does not count anything: every in-range pair of a tile whose three-plane distance is below the threshold goes,
+// as (k, l), k != l, into ONE list in HBM (a slot range per thread off a device-wide counter, sc->ham_ncand), and k_hamming_refine
+// counts the listed pairs exactly from the alignment's bytes -- 16 lanes per pair, 64 contiguous bytes of either sequence per
+// trip -- with one integer atomic per end of a neighbour pair.  (Round 3 refined inside the tile's workgroup, from the five bit
+// planes: 16 scattered dwords per lane and plane, and the refinement's loops shared the main loop's registers -- 36 of them parked
+// in scratch on EVERY tile, 2.2 GB written per launch at N = 500, M = 50 000 for 200 KB of results.)  The list holds HAM_CAND_PER_TILE
+// pairs per tile on average -- sixteen times the density at which the bound form is chosen at all; a family that overflows it
+// anyway (clustered where the sampled tiles were not) is counted by the exact form instead: nothing is ever dropped.
+#define HAM_CAND_PER_TILE 16
+
+size_t gdca_hamming_cand_cap(int M)
+{
+    const long long Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE;
+    return (size_t)(Mt * (Mt + 1) / 2 * HAM_CAND_PER_TILE + 4096);
+}
+
+__global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict__ Z, const int2 *__restrict__ list, unsigned cap, int N,
+                                                         int32_t *__restrict__ cnt, const gdca_dev_scalars *__restrict__ sc)
+{
+    if (sc->ham_mode != 1) return;
+    const unsigned total = sc->ham_ncand;
+    if (total > cap) return;  // the list overflowed: the exact form counts this family
+    const int thresh = sc->thresh;
+    const int tid = threadIdx.x, sub = tid & 15, grp = (tid & 63) >> 4;
+    const unsigned wave = blockIdx.x * 4u + (unsigned)(tid >> 6), nwave = gridDim.x * 4u;
+    for (unsigned eb = wave * 4u; eb < total; eb += nwave * 4u) {  // (a wave's trip count is uniform: the shuffles need all lanes)
+        const unsigned e = eb + (unsigned)grp;
+        uint32_t d = 0;
+        int k = 0, l = 0;
+        if (e < total) {
+            const int2 pr = list[e];
+            k = pr.x;
+            l = pr.y;
+            const int8_t *zk = Z + (size_t)k * N, *zl = Z + (size_t)l * N;
+            if ((N & 3) == 0) {
+                const uint32_t *a = reinterpret_cast<const uint32_t *>(zk), *b = reinterpret_cast<const uint32_t *>(zl);
+                for (int w = sub; w < (N >> 2); w += 16) {
+                    uint32_t x = a[w] ^ b[w];  // bytes that differ -> one bit each
+                    x |= x >> 4;
+                    x |= x >> 2;
+                    x |= x >> 1;
+                    d += __builtin_popcount(x & 0x01010101u);
+                }
+            } else {
+                for (int i = sub; i < N; i += 16) d += zk[i] != zl[i];
+            }
+        }
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        d += __shfl_xor(d, 4);
+        d += __shfl_xor(d, 8);
+        if (e < total && sub == 0 && (int)d < thresh) {
+            atomicAdd(&cnt[k], 1);
+            atomicAdd(&cnt[l], 1);
+        }
+    }
+}
+
 template <int NP, bool PROBE>
 __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
-                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc)
+                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc, int2 *__restrict__ cand_list, unsigned cand_cap)
 {
     const int thresh = sc->thresh;
     if (thresh <= 0) return;  // theta == 0 (or floor(theta N) == 0): every n_k = 1
-    if (!PROBE && sc->ham_mode != (NP == NPLANES ? 0 : 1)) return;  // the other form was chosen for this family
+    if constexpr (!PROBE) {
+        // the other form was chosen for this family -- unless the bound form's candidate list overflowed: then the exact form counts
+        const bool mine = NP == NPLANES ? (sc->ham_mode == 0 || sc->ham_ncand > cand_cap) : sc->ham_mode == 1;
+        if (!mine) return;
+    }
 
     __shared__ __attribute__((aligned(16))) uint32_t As[NP][WCHUNK][GDCA_HTILE];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[NP][WCHUNK][GDCA_HTILE];
     __shared__ int rc[GDCA_HTILE], cc[GDCA_HTILE];
-    __shared__ int ncand;
-    __shared__ unsigned short cand_list[(NP < NPLANES && !PROBE) ? HAM_CAND_CAP : 1];
 
     int I, J;
     // (PROBE: gridDim.x tiles spread evenly over the upper triangle's Mt (Mt + 1) / 2)
@@ -135,7 +211,11 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         rc[tid] = 0;
         cc[tid] = 0;
     }
-    if (tid == 0) ncand = 0;
+    if (tid == 0) {
+        hm_any[0] = 0;
+        hm_any[1] = 0;
+    }
+    int any_calls = 0;  // (wg_any: calls so far)
 
     uint32_t acc[8][8];
 #pragma unroll
@@ -196,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
             for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
-            if (__syncthreads_or((int)mn < thresh) == 0) {
+            if (!wg_any((int)mn < thresh, any_calls)) {
                 all_beyond = true;  // (uniform over the workgroup)
                 break;
             }
@@ -221,68 +301,34 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         return;
     }
     if (all_beyond) return;  // nothing of this tile counts (the usual end of a tile of unrelated sequences): no list, no atomics
-    unsigned long long cand = 0ull;  // bit 8 r + c: pair (r, c) of this thread's micro-tile is a candidate (bound below the threshold)
     if constexpr (NP < NPLANES) {
-        // candidates -> the tile's list in LDS (the bound can only be too small, so nothing else can be a neighbour); they are
-        // counted by the refinement below and skipped by their owner's own count.  A tile with more candidates than the list
-        // holds (a dense corner of a sparse family) takes several passes.
-        // (most threads hold no candidate at all: 32 three-way minima decide that, instead of 64 x 7 instructions of index tests)
+        // candidates -> the list (the bound can only be too small, so nothing else can be a neighbour).  A diagonal tile holds every
+        // pair twice: its upper half is listed.  (Most threads hold no candidate at all: 63 minima decide that.)
         uint32_t mn = acc[0][0];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
             for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
-        if ((int)mn < thresh) {
+        if ((int)mn >= thresh) return;
+        unsigned long long cand = 0ull;  // bit 8 r + c: pair (r, c) of this thread's micro-tile
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
-                    const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
-                    if ((int)acc[r][c] < thresh && gr < M && gc < M && gr != gc) cand |= 1ull << (8 * r + c);
-                }
-        }
-        unsigned long long todo = cand;
-        for (;;) {
-            while (todo) {
-                const int e = __builtin_ctzll(todo), r = e >> 3, c = e & 7;
-                const int slot = atomicAdd(&ncand, 1);
-                if (slot >= HAM_CAND_CAP) break;  // next pass
-                cand_list[slot] = (unsigned short)(((ty * 8 + r) << 8) | ((c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4))));
-                todo &= todo - 1;
+            for (int c = 0; c < 8; ++c) {
+                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
+                if ((int)acc[r][c] < thresh && gr < M && gc < M && (diag ? gr < gc : true)) cand |= 1ull << (8 * r + c);
             }
-            __syncthreads();
-            const int total = ncand, nc = min(total, HAM_CAND_CAP), sub = tid & 15;
-            // exact distances of the listed pairs: 16 lanes per pair, lane <-> dword of 32 positions (dwords 16.. in further trips)
-            for (int e = tid >> 4; e < ((nc + 15) & ~15); e += 16) {  // (trip count uniform per wave: the shuffles need all lanes)
-                uint32_t d = 0;
-                int ka = 0, kb = 0;
-                if (e < nc) {
-                    const unsigned pr = cand_list[e];
-                    ka = (int)(pr >> 8);
-                    kb = (int)(pr & 255u);
-                    for (int w = sub; w < NW; w += 16) {
-                        uint32_t x = 0;
-#pragma unroll
-                        for (int p = 0; p < NPLANES; ++p)
-                            x |= Ag[((size_t)p * NW + w) * GDCA_HTILE + ka] ^ Bg[((size_t)p * NW + w) * GDCA_HTILE + kb];
-                        d += __builtin_popcount(x);
-                    }
-                }
-                d += __shfl_xor(d, 1);
-                d += __shfl_xor(d, 2);
-                d += __shfl_xor(d, 4);
-                d += __shfl_xor(d, 8);
-                if (e < nc && sub == 0 && (int)d < thresh) {
-                    atomicAdd(&rc[ka], 1);
-                    if (I != J) atomicAdd(&cc[kb], 1);
-                }
-            }
-            if (total <= HAM_CAND_CAP) break;
-            __syncthreads();  // everybody has read the count and the list
-            if (tid == 0) ncand = 0;
-            __syncthreads();
+        if (cand == 0ull) return;
+        unsigned slot = atomicAdd(&sc->ham_ncand, (unsigned)__builtin_popcountll(cand));
+        while (cand) {
+            const int e = __builtin_ctzll(cand), r = e >> 3, c = e & 7;
+            const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+            if (slot < cand_cap) cand_list[slot] = make_int2(I * GDCA_HTILE + ty * 8 + r, J * GDCA_HTILE + lc);
+            ++slot;
+            cand &= cand - 1;
         }
+        return;
     }
 
     // The exact form: threshold, count (strict '<'), reduce over the workgroup.  (The bound form has nothing left to count: every
@@ -318,7 +364,6 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
             }
         }
     }
-    (void)cand;
     __syncthreads();
     if (tid < GDCA_HTILE) {
         const int v = rc[tid];
@@ -333,31 +378,38 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
 // that the refinement costs more than the two instructions per word the bound saves
 __global__ void k_hamming_decide(gdca_dev_scalars *sc, long long sampled_pairs, int force)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         sc->ham_mode = force >= 0 ? force : ((double)sc->ham_cand < 1e-3 * (double)sampled_pairs ? 1 : 0);
+        sc->ham_ncand = 0u;
+    }
 }
 
-void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force)
+// Z: the alignment's bytes ([M][N], what the bit planes were packed from); cand_list: gdca_hamming_cand_cap(M) pairs of scratch
+void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force,
+                         void *cand_list)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
     const long long ntile = (long long)Mt * (Mt + 1) / 2;
+    int2 *list = (int2 *)cand_list;
+    const unsigned cap = (unsigned)gdca_hamming_cand_cap(M);
     // the context option GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a
     // sample of tiles
     const int nprobe = (int)std::min<long long>(ntile, 192);
     if (force < 0 && ntile >= 64) {
-        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1);
     } else {
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, 1ll, force < 0 ? 0 : force);  // tiny families: the exact form
     }
-    // both forms are launched only where the device decides between them (the one not chosen exits on sc->ham_mode: Mt (Mt + 1) / 2
-    // empty workgroups); a forced form, and a family too small to sample, launch the one they run
+    // both forms are launched wherever the bound form may run: where the device decides between them, and behind a forced bound form,
+    // whose list may overflow (the form that has nothing to do exits on sc->ham_mode / sc->ham_ncand: Mt (Mt + 1) / 2 empty workgroups)
     const bool decided = !(force < 0 && ntile >= 64);
     const int form = decided ? (force < 0 ? 0 : force) : -1;
-    if (form != 0)
-        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
-    if (form != 1)
-        hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc);
+    if (form != 0) {
+        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
+        hipLaunchKernelGGL(k_hamming_refine, dim3(1024), dim3(256), 0, s, Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc);
+    }
+    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
 }
 
 // ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------

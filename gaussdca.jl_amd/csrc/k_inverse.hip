@@ -21,6 +21,7 @@
 // [k][row] with a 128-byte pad per k-row, which puts the four k-rows a ds_read_b64 touches on
 // disjoint bank halves (conflict-free).
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <vector>
 
@@ -532,19 +533,38 @@ __device__ __forceinline__ void tile_product(double4_t (&acc)[TM][4], const doub
 // then stream in underneath the MFMAs instead of as one blocking burst in front of them (every workgroup of a
 // launch runs in lockstep, so that burst was 64 MB at once: measured 6 of the 39 us a tile takes).
 // Piece ci = accumulators (tm = ci / 2, tn = 2 (ci % 2) + {0, 1}, reg 0..3): 8 doubles per lane.
+// Addresses of a thread's accumulator elements inside a 128 x 128 tile of a column-major matrix: element (tm, tn, reg) of the wave
+// at (wr, wc) is row wr 64 + 16 tn + l15, column wc 64 + 16 tm + lq + 4 reg.  Kept as FOUR 32-bit byte offsets (one per reg; tm
+// moves a wave-uniform base, tn is an immediate): the C pieces' loads and the tile's final stores take the scalar-base form, and
+// what has to survive the chunk loop is four registers -- as 64-bit addresses these were sixteen register pairs, twelve of
+// which hipcc parked in scratch across the loop.
+struct TileOff {
+    unsigned o[4];
+};
+__device__ __forceinline__ TileOff tile_off(size_t ld, int wr, int wc, int l15, int lq)
+{
+    TileOff t;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) t.o[reg] = ((unsigned)(wr * 64 + l15) + (unsigned)(wc * 64 + lq + 4 * reg) * (unsigned)ld) * 8u;
+    return t;
+}
+// the 16-column strip tm of the tile at At (wave-uniform)
+__device__ __forceinline__ const char *tile_strip(const double *At, size_t ld, int tm)
+{
+    return reinterpret_cast<const char *>(At + (size_t)(16 * tm) * ld);
+}
+
 template <int CI>
-__device__ __forceinline__ void cpiece_load(double (&cp)[8], const double *__restrict__ At, size_t ld, int wr, int wc,
-                                            int l15, int lq)
+__device__ __forceinline__ void cpiece_load(double (&cp)[8], const double *__restrict__ At, size_t ld, const TileOff &to)
 {
     constexpr int tm = CI / 2;
+    const char *base = tile_strip(At, ld, tm);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int tn = 2 * (CI % 2) + h;
-            const int r = wr * 64 + tn * 16 + l15;
-            const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-            cp[h * 4 + reg] = At[(size_t)r + (size_t)c * ld];
+            constexpr int tn0 = 2 * (CI % 2);
+            cp[h * 4 + reg] = reinterpret_cast<const double *>(base + to.o[reg])[16 * (tn0 + h)];
         }
 }
 
@@ -605,19 +625,24 @@ __device__ __forceinline__ ChunkIO chunk_io(size_t gld, size_t hld, int tid, siz
 #define GT_LD 18
 static_assert(T * GT_LD <= KC * LDS_LD, "transposed G image fits the chunk buffer");
 
+typedef const volatile double __attribute__((address_space(3))) *lds_cvd_t;  // (an LDS address, said so: a volatile access through a generic pointer is a flat one)
+
 template <bool GT>
 __device__ __forceinline__ void frag_read(Frag &f, const double (*Gs)[LDS_LD], const double (*Hs)[LDS_LD], int k4, int wr, int wc,
                                           int l15, int lq)
 {
+    // (volatile: single ds_read_b64 with 16-bit immediate offsets off ONE address register per operand.  Left to itself hipcc pairs
+    // them into ds_read2_b64, whose 8-bit offsets reach 2 KB: it then keeps an address register per LDS buffer and k4 step -- a dozen
+    // registers of a kernel that has none to spare -- and parks staging registers in scratch inside the chunk loop instead)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f.a[t] = Hs[k4 + lq][wc * 64 + t * 16 + l15];
+    for (int t = 0; t < 4; ++t) f.a[t] = *(lds_cvd_t)&Hs[k4 + lq][wc * 64 + t * 16 + l15];
     if constexpr (GT) {
         const double *Gt = &Gs[0][0];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) f.b[t] = Gt[(wr * 64 + t * 16 + l15) * GT_LD + k4 + lq];
+        for (int t = 0; t < 4; ++t) f.b[t] = *(lds_cvd_t)&Gt[(wr * 64 + t * 16 + l15) * GT_LD + k4 + lq];
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) f.b[t] = Gs[k4 + lq][wr * 64 + t * 16 + l15];
+        for (int t = 0; t < 4; ++t) f.b[t] = *(lds_cvd_t)&Gs[k4 + lq][wr * 64 + t * 16 + l15];
     }
 }
 
@@ -744,7 +769,8 @@ template <bool STORE, bool LOAD, bool NEXT, int CI, bool GT = false>
 __device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, StageRegs<4> &R, double (&cp)[8], double (*Gc)[LDS_LD],
                                            double (*Hc)[LDS_LD], double (*Gn)[LDS_LD], double (*Hn)[LDS_LD],
                                            const double *__restrict__ g, const double *__restrict__ h, const ChunkIO &io,
-                                           const double *__restrict__ At, size_t ld, int tid, double *__restrict__ gc = nullptr)
+                                           const double *__restrict__ At, size_t ld, int tid, double *__restrict__ gc = nullptr,
+                                           const TileOff &to = TileOff{})
 {
     const int lane = tid & 63, wv = tid >> 6, wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
     Frag f1;
@@ -753,7 +779,7 @@ __device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, Stag
     mma_all<TM0>(acc, f);  // k4 = 0
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (CI >= 0) cpiece_add<(CI >= 0 ? CI : 0)>(acc, cp);
-    if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, wr, wc, l15, lq);
+    if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, to);
     frag_read<GT>(f, Gc, Hc, 8, wr, wc, l15, lq);
     __builtin_amdgcn_sched_barrier(0);
     stage_unit<0, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);  // k4 = 4, two MFMAs per unit
@@ -922,6 +948,52 @@ struct SweepDesc {
     unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
     unsigned long long *dbg_main;  // optional: [0] ticks tile items waited, [1] panel items waited, [2..] ticks / counts by kind
 };
+
+// LDS of the sweep kernels, at file scope so that the out-of-line item functions (below) address it as LDS without having it
+// handed to them as generic pointers: the staging buffers of the tile paths -- ONE array: the pivot's images (pivot_chain) span
+// both staging buffers off one base -- and the few words a workgroup's threads share about its current and next item
+__shared__ __attribute__((aligned(16))) double sw_lds[4][KC][LDS_LD];
+__shared__ int sw_item, sw_next, sw_ready, sw_fam, sw_live, sw_fnext, sw_pnext;
+__shared__ unsigned long long sw_probe[2];  // the workgroup's start: shader clock, wall clock (the launch's clock measurement)
+__shared__ unsigned long long sw_stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
+
+// The descriptor of family f of the running launch, read where it lies: in the kernel-argument segment (constant address space:
+// scalar loads).  k_sweep's argument is one SweepDesc (f = 0), k_sweep_merged's a SweepBatch, whose first member is fam[].
+// launch_desc_k: inside the kernels themselves.  launch_desc: anywhere -- the out-of-line item functions take the family's index,
+// not a reference to its descriptor, and `llvm.amdgcn.kernarg.segment.ptr` is NULL outside a kernel: the kernels leave the
+// segment's address in LDS (sw_kbase, thread 0, before their first barrier).
+__shared__ unsigned long long sw_kbase;
+typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
+
+__device__ __forceinline__ const SweepDesc &launch_desc_k(int f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr())[f];
+#else
+    (void)f;
+    static const SweepDesc host_pass_dummy{};  // (host pass: never executed)
+    return host_pass_dummy;
+#endif
+}
+
+__device__ __forceinline__ void launch_desc_init()  // thread 0 of a kernel, before the workgroup's first barrier
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sw_kbase = (unsigned long long)(const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+}
+
+__device__ __forceinline__ const SweepDesc &launch_desc(int f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long b = sw_kbase;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    // (the generic address of the segment, back in the constant address space: the loads stay scalar)
+    return ((const SweepDesc *)(kernarg_desc_t)(((unsigned long long)hi << 32) | lo))[f];
+#else
+    return launch_desc_k(f);
+#endif
+}
 
 __device__ __forceinline__ int g_start(const SweepDesc &D, int p)
 {
@@ -1485,16 +1557,30 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
                                   Hs[0], gcopy0 ? gcopy0 + (size_t)v * D.pstride : nullptr, ld);
     }
     double *Hw = H0 + (size_t)w * D.pstride + (size_t)i * T;
+    if constexpr (TM == 4) {
+        // (as in the tile item: four 32-bit offsets, computed after the chunk loop from a fresh thread index)
+        const int t2 = opaque_tid(), lane2 = t2 & 63, wv2 = t2 >> 6;
+        const TileOff to = tile_off(ld, wv2 & 1, wv2 >> 1, lane2 & 15, lane2 >> 4);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < 4; ++tm) {
+            char *base = const_cast<char *>(tile_strip(Hw, ld, tm));
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = ch * 64 + wc * (16 * TM) + tm * 16 + lq + 4 * reg;
-                Hw[(size_t)r + (size_t)c * ld] = -acc[tm][tn][reg];
-            }
+                for (int reg = 0; reg < 4; ++reg) (reinterpret_cast<double *>(base + to.o[reg]))[16 * tn] = -acc[tm][tn][reg];
+        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = wr * 64 + tn * 16 + l15;
+                    const int c = ch * 64 + wc * (16 * TM) + tm * 16 + lq + 4 * reg;
+                    Hw[(size_t)r + (size_t)c * ld] = -acc[tm][tn][reg];
+                }
+    }
     publish_begin();
     if (tid == 0) __hip_atomic_fetch_add(D.rb + (size_t)p * D.nblk + i, (unsigned)(TM / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1674,28 +1760,28 @@ __device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I,
     return acquire_end(ok);
 }
 
-// The workgroup's NEXT take (thread 0's values; nullptr s_next: none, an M-list caller): item number `nxt`, in flight as an atomic
-// since the start of this item, and where it goes.  A merged launch (k_sweep_merged) takes the next item from another family: Dn =
-// that family's descriptor, pn = the group its last item there belonged to, fn = its index (-> *s_fam).
+// The workgroup's NEXT take: item number `nxt` (thread 0's value, in flight as an atomic since the start of this item) and where
+// it goes.  main = 0: none (an M-list caller).  merged: the launch is k_sweep_merged, which takes the next item from another family
+// -- that family's index and the group this workgroup's last item there belonged to wait in LDS (sw_fnext, sw_pnext: known when the
+// atomic is issued; as registers of thread 0 they were live, and spilled, across the item).
 struct NextTake {
     int nxt;
-    int *s_next, *s_ready;
-    const SweepDesc *Dn;
-    int pn, fn;
-    int *s_fam;
+    int main;
+    int merged;
 };
 
 // after the tile's (write-through) stores have been issued: look the next item up while they drain, then publish
 __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int I, int J, const NextTake &nt)
 {
     const int tid = opaque_tid();
-    if (nt.s_next && tid == 0) {
-        *nt.s_next = nt.nxt;
-        if (nt.s_fam) *nt.s_fam = nt.fn;
-        const SweepDesc &Dn = nt.Dn ? *nt.Dn : D;
+    if (nt.main && tid == 0) {
+        sw_next = nt.nxt;
+        const int fn = nt.merged ? sw_fnext : 0;
+        if (nt.merged) sw_fam = fn;
+        const SweepDesc &Dn = nt.merged ? launch_desc(fn) : D;
         int r = 0;
         if (nt.nxt < Dn.total) {
-            int ph = nt.Dn ? nt.pn : p;
+            int ph = nt.merged ? sw_pnext : p;
             const MainItem ni = main_decode(Dn, ph, nt.nxt);
             if (ni.kind == 1 || ni.kind == 4) {
                 const int nsz2 = g_size(Dn, ni.p);
@@ -1704,7 +1790,7 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
                 r = (f1 >= 2u * (unsigned)nsz2) & (f2 >= 2u * (unsigned)nsz2) & (f3 >= (unsigned)ni.p);
             }
         }
-        *nt.s_ready = r;
+        sw_ready = r;
     }
     publish_wt_begin();
     if (tid == 0) {
@@ -1715,7 +1801,7 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
 
 template <bool MULTI>
 __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I, int J, double (*Gs)[KC][LDS_LD],
-                                                double (*Hs)[KC][LDS_LD], int ready = 0, const NextTake &nt = NextTake{}, bool inplace = false)
+                                                double (*Hs)[KC][LDS_LD], int ready = 0, const NextTake &nt = NextTake{0, 0, 0}, bool inplace = false)
 {
     const int tid = opaque_tid(), lane = tid & 63, wv = tid >> 6;
     const int wr = wv & 1, wc = wv >> 1, l15 = lane & 15, lq = lane >> 4;
@@ -1734,33 +1820,34 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
         StageRegs<4> R;
         double cp[8];
         Frag f;
+        const TileOff to = tile_off(ld, wr, wc, l15, lq);
         const size_t go = (size_t)I * T, ho = (size_t)J * T;
         const ChunkIO io = chunk_io<false>(pld, pld, tid);
         const size_t cs = (size_t)KC * pld;  // one chunk further along k
         const double *g = Gp + go, *h = Hp + ho;
+        // nch = chunks of the whole item (even, >= 10): 8 per pivot block, fewer for the block that holds the ragged end of the
+        // matrix (its padding columns are zero in G and H: g_chunks).  Looked up here: no control flow between the first eight chunks
+        const int nch = MULTI ? g_chunks(D, p) : 8;
         stage_load<false, 4>(R, g, pld, h, pld, 0, tid);
-        cpiece_load<0>(cp, At, ld, wr, wc, l15, lq);
+        cpiece_load<0>(cp, At, ld, to);
         stage_store<false, 4>(R, Gs[0], Hs[0], tid);
         stage_load<false, 4>(R, g, pld, h, pld, KC, tid);
         __syncthreads();
         frag_read<false>(f, Gs[0], Hs[0], 0, wr, wc, l15, lq);
         // chunk c multiplies LDS buffer c & 1, stores chunk c+1 into the other one and loads chunk c+2; the first eight chunks
         // (the group's first pivot block) also bring the C tile in
-        tile_chunk<true, true, true, 0>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 2 * cs, h + 2 * cs, io, At, ld, tid);
-        tile_chunk<true, true, true, 1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 3 * cs, h + 3 * cs, io, At, ld, tid);
-        tile_chunk<true, true, true, 2>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 4 * cs, h + 4 * cs, io, At, ld, tid);
-        tile_chunk<true, true, true, 3>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 5 * cs, h + 5 * cs, io, At, ld, tid);
-        tile_chunk<true, true, true, 4>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 6 * cs, h + 6 * cs, io, At, ld, tid);
-        tile_chunk<true, true, true, 5>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 7 * cs, h + 7 * cs, io, At, ld, tid);
+        tile_chunk<true, true, true, 0>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 2 * cs, h + 2 * cs, io, At, ld, tid, nullptr, to);
+        tile_chunk<true, true, true, 1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 3 * cs, h + 3 * cs, io, At, ld, tid, nullptr, to);
+        tile_chunk<true, true, true, 2>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 4 * cs, h + 4 * cs, io, At, ld, tid, nullptr, to);
+        tile_chunk<true, true, true, 3>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 5 * cs, h + 5 * cs, io, At, ld, tid, nullptr, to);
+        tile_chunk<true, true, true, 4>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g + 6 * cs, h + 6 * cs, io, At, ld, tid, nullptr, to);
+        tile_chunk<true, true, true, 5>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + 7 * cs, h + 7 * cs, io, At, ld, tid, nullptr, to);
         if constexpr (MULTI) {
-            // the other pivot blocks of the group: operand pair w at Gp / Hp + w * pstride.  nch = chunks of the whole item (even,
-            // >= 10): 8 per pivot block, fewer for the block that holds the ragged end of the matrix (its padding columns are
-            // zero in G and H: g_chunks)
-            const int nch = g_chunks(D, p);
+            // the other pivot blocks of the group: operand pair w at Gp / Hp + w * pstride
             g += D.pstride;
             h += D.pstride;
-            tile_chunk<true, true, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
-            tile_chunk<true, true, true, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + cs, h + cs, io, At, ld, tid);
+            tile_chunk<true, true, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid, nullptr, to);
+            tile_chunk<true, true, true, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g + cs, h + cs, io, At, ld, tid, nullptr, to);
 #pragma unroll 1
             for (int c = 8; c < nch - 2; c += 2) {
                 // loads chunks c + 2 and c + 3 (the same operand pair: c is even and a pair holds 8 chunks)
@@ -1772,20 +1859,24 @@ __device__ __forceinline__ void sweep_tile_item(const SweepDesc &D, int p, int I
             tile_chunk<true, false, true, -1>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
             tile_chunk<false, false, false, -1>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, io, At, ld, tid);
         } else {
-            tile_chunk<true, false, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid);
-            tile_chunk<false, false, false, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, io, At, ld, tid);
+            tile_chunk<true, false, true, 6>(acc, f, R, cp, Gs[0], Hs[0], Gs[1], Hs[1], g, h, io, At, ld, tid, nullptr, to);
+            tile_chunk<false, false, false, 7>(acc, f, R, cp, Gs[1], Hs[1], Gs[0], Hs[0], g, h, io, At, ld, tid, nullptr, to);
         }
     }
+    {
+        // (the offsets are computed again, from a thread index the compiler cannot connect with the one above: nothing of the
+        // addressing stays live across the chunk loop)
+        const int t2 = opaque_tid(), lane2 = t2 & 63, wv2 = t2 >> 6;
+        const TileOff to = tile_off(ld, wv2 & 1, wv2 >> 1, lane2 & 15, lane2 >> 4);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < 4; ++tm) {
+            char *base = const_cast<char *>(tile_strip(At, ld, tm));
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = wr * 64 + tn * 16 + l15;
-                const int c = wc * 64 + tm * 16 + lq + 4 * reg;
-                store_wt(&At[(size_t)r + (size_t)c * ld], acc[tm][tn][reg]);
-            }
+                for (int reg = 0; reg < 4; ++reg) store_wt(reinterpret_cast<double *>(base + to.o[reg]) + 16 * tn, acc[tm][tn][reg]);
+        }
+    }
     tile_item_finish(D, p, I, J, nt);
 }
 
@@ -1878,14 +1969,195 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
     }
 }
 
+// ---- item functions kept OUT OF LINE ---------------------------------------------------------------------------------------------
+// The persistent loops below hold the hot items inline -- the tile item on the hand-scheduled chunk loop and the panel item that
+// shares it -- and nothing else: every other kind of item is a function of its own, with registers of its own.  Inlined into one
+// 256-VGPR kernel, the cold kinds' address arithmetic, descriptors and loop state were live (or spilled) across the chunk loops:
+// 132 spilled VGPRs, scratch loads and stores inside the 512-MFMA blocks, and a kernel whose spill placement changed with every edit
+// (a wrong-result incident that moved with it).  Arguments are the family's index in the launch and plain item
+// numbers (made uniform again on entry: arguments arrive in vector registers); the callee finds the descriptor and the LDS itself.
+// A call costs the callee's saves of the registers it uses (~1 us for a 100-register item): the items behind calls take 25 us and more.
+// (GDCA_EXP_LATE_NEXT, experiments only: tile items leave the publication of the next take to the caller, behind the item -- the
+// form of the merged loop that gave wrong inverses in round 4; tools/build_variant.sh late -DGDCA_EXP_LATE_NEXT)
+#ifdef GDCA_EXP_LATE_NEXT
+#define SWEEP_TILE_PUBLISHES 0
+#else
+#define SWEEP_TILE_PUBLISHES 1
+#endif
+#define SWEEP_OUTLINE __device__ __attribute__((noinline))
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+
+// the M list of family f (the serial chain), run by the workgroups of the compute units elected for it: ONE call per workgroup
+// (the 16-step micro-sweep of the pivot and the slab items stay inline in here, next to each other -- the chain's latency is theirs)
 template <bool MULTI>
-__device__ __forceinline__ void sweep_one_family(const SweepDesc &D)
+SWEEP_OUTLINE void sweep_chain_worker(int f_in)
 {
-    // ONE array: the pivot's images (pivot_chain) span both staging buffers off one base
-    __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
-    double(*const Gs)[KC][LDS_LD] = GHs;
-    double(*const Hs)[KC][LDS_LD] = GHs + 2;
-    __shared__ int s_item;
+    const SweepDesc &D = launch_desc(UNI(f_in));
+    double(*const Gs)[KC][LDS_LD] = sw_lds;
+    double(*const Hs)[KC][LDS_LD] = sw_lds + 2;
+    int q = 0;
+    for (;;) {
+        if (threadIdx.x == 0) sw_item = (int)__hip_atomic_fetch_add(D.next_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int item = sw_item;
+        __syncthreads();
+        if (item >= D.total_m || *abort_lds()) break;
+        while (item >= D.mitem0[q + 1]) ++q;
+        int e = item - D.mitem0[q];
+        if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
+        const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
+        const int nm = m_items(sz);
+        if (e < nm) {
+            sweep_m_item(D, q, e, Gs, Hs, D.dbg ? D.dbg + 2 * item : nullptr);
+            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+            continue;
+        }
+        e -= nm;
+        if (D.slab) {
+            if (e < SLAB_ITEMS)
+                sweep_slab_item(D, q, e, 1, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
+            else if (e < 2 * SLAB_ITEMS)
+                sweep_xslab_item(D, q, e - SLAB_ITEMS, D.dbg ? D.dbg + 2 * item : nullptr);
+            else
+                sweep_slab_item(D, q, e - 2 * SLAB_ITEMS, 2, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
+            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+            continue;
+        }
+        // the next group's rows, one after the other: the 2 sz panel items of row rr, then the tiles (rr, 0 .. rr) of its
+        // diagonal super-block -- its FIRST diagonal tile, which the next group's first pivot waits for, is complete after one
+        // round of panel items instead of after all of them
+        int rr = 0;
+        while (e >= 2 * sz + rr + 1) {
+            e -= 2 * sz + rr + 1;
+            ++rr;
+        }
+        if (e < 2 * sz) {
+            sweep_panel_item<2>(D, q, c0 + rr, e, Gs, Hs);
+            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+            continue;
+        }
+        e -= 2 * sz;
+        if (MULTI && sz > 1)
+            sweep_tile_item<true>(D, q, c0 + rr, c0 + e, Gs, Hs);
+        else
+            sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
+        if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
+    }
+}
+
+SWEEP_OUTLINE void sweep_wb_item_ol(int f, int p, int e)
+{
+    sweep_wb_item(launch_desc(UNI(f)), UNI(p), UNI(e), sw_lds);
+}
+
+// (nxt is thread 0's value: it stays a vector argument)
+SWEEP_OUTLINE void sweep_ragged_item_ol(int f, int p, int I, int J, int rdy, int nxt, int merged)
+{
+    const NextTake nt{nxt, SWEEP_TILE_PUBLISHES, UNI(merged)};
+    sweep_tile_item_ragged(launch_desc(UNI(f)), UNI(p), UNI(I), UNI(J), sw_lds, sw_lds + 2, UNI(rdy), nt);
+}
+
+// a K = 128 tile item inside a launch of multi-block groups (the single blocks of its opening ramp) -- and every panel item of such
+// a launch that comes as two 128 x 64 halves
+SWEEP_OUTLINE void sweep_single_tile_item_ol(int f, int p, int I, int J, int rdy, int nxt, int merged, int inplace)
+{
+    const NextTake nt{nxt, SWEEP_TILE_PUBLISHES, UNI(merged)};
+    sweep_tile_item<false>(launch_desc(UNI(f)), UNI(p), UNI(I), UNI(J), sw_lds, sw_lds + 2, UNI(rdy), nt, UNI(inplace) != 0);
+}
+
+SWEEP_OUTLINE void sweep_half_panel_item_ol(int f, int p, int i, int y)
+{
+    sweep_panel_item<2>(launch_desc(UNI(f)), UNI(p), UNI(i), UNI(y), sw_lds, sw_lds + 2);
+}
+
+SWEEP_OUTLINE void sweep_full_panel_item_ol(int f, int p, int i, int y)
+{
+    sweep_panel_item<4>(launch_desc(UNI(f)), UNI(p), UNI(i), UNI(y), sw_lds, sw_lds + 2);
+}
+
+// One item of the main list of family f, by the calling workgroup.  nt: where its next take goes (tile items publish it themselves,
+// inside tile_item_finish; for the other kinds the caller does, after the item).  Returns true when the item published the take.
+template <bool MULTI>
+__device__ __forceinline__ bool sweep_main_item(const SweepDesc &D, int f, const MainItem &it, int rdy, const NextTake &nt_in)
+{
+    double(*const Gs)[KC][LDS_LD] = sw_lds;
+    double(*const Hs)[KC][LDS_LD] = sw_lds + 2;
+    const NextTake nt{nt_in.nxt, SWEEP_TILE_PUBLISHES, nt_in.merged};
+    if (it.kind == 1 || it.kind == 4) {
+        if (D.rl < T && it.a == D.nblk - 1)
+            sweep_ragged_item_ol(f, it.p, it.a, it.b, rdy, nt.nxt, nt.merged);
+        else if (MULTI && g_size(D, it.p) > 1)
+            sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
+        else {
+            const bool inplace = D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1;
+            if (MULTI)
+                sweep_single_tile_item_ol(f, it.p, it.a, it.b, rdy, nt.nxt, nt.merged, inplace ? 1 : 0);
+            else
+                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt, inplace);
+        }
+        return SWEEP_TILE_PUBLISHES != 0;
+    }
+    if (it.kind == 0) {
+        // the form the item table was built for (D.ppb): 128 x 128 items inline where they are the rule (multi-block groups), 128 x 64
+        // halves inline where THEY are (single blocks); the other form of either launch -- a forced PANEL_HALVES, the groups of
+        // two -- out of line
+        if (D.ppb == 1) {
+            if (MULTI)
+                sweep_panel_item<4>(D, it.p, it.a, it.b, Gs, Hs);
+            else
+                sweep_full_panel_item_ol(f, it.p, it.a, it.b);
+        } else if (MULTI)
+            sweep_half_panel_item_ol(f, it.p, it.a, it.b);
+        else
+            sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
+    } else if (it.kind == 2)
+        sweep_wb_item_ol(f, it.p, it.a);
+    return false;
+}
+
+// trace (between single blocks): the slot of a main-list item of row block b0 + 3 of update it.p in the group's trace record, or -1
+__device__ __forceinline__ int sweep_trace_xslot(const SweepDesc &D, const MainItem &it)
+{
+    const int r3 = g_start(D, it.p) + 3;
+    if (it.kind == 0 && it.a == r3) return 0;
+    if (it.kind == 4 && it.a == r3) return 3 + 2 * (it.b - (r3 - 2));
+    return -1;
+}
+
+// the chain's compute units: a workgroup on XCC x offers itself to family (x + t) % K, t = 0, 1, ..: the first workgroup to reach a
+// family decides its XCD, so with K <= 8 the chains sit on different XCDs (each hands its data on through one L2) whenever the
+// workgroups of a launch are spread over them.  Thread 0; returns the family this workgroup's CU was elected for, or -1.
+__device__ __forceinline__ int sweep_elect(int K)
+{
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    xcc &= 15u;
+    const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
+    for (int t = 0; t < K; ++t) {
+        const int f = (int)((xcc + (unsigned)t) % (unsigned)K);
+        const SweepDesc &Df = launch_desc_k(f);
+        // the XCD of a chain is whichever one the first workgroup to get there runs on (not a fixed id: under a CU mask, in a
+        // partitioned mode or beside another tenant no workgroup of the launch may ever run on XCC 0)
+        const bool candidate = !(Df.debug & 2) && !((Df.debug & 1) && xcc == 0u) && !((Df.debug & 4) && xcc != 0u);
+        if (!candidate) continue;
+        const unsigned old = atomicCAS(Df.mxcc, 0u, xcc + 1u);
+        if (old == 0u || old == xcc + 1u) {
+            for (int k = 0; k < Df.n_mcu; ++k) {
+                const unsigned o2 = atomicCAS(Df.mcu + k, 0u, key);
+                if (o2 == 0u || o2 == key) return f;
+            }
+        }
+    }
+    return -1;
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
+{
+    // the descriptor is read where it lies, in the kernel-argument segment
+    const SweepDesc &D = launch_desc_k(0);
+    (void)Darg;
     // ---- the M list runs on compute units of its own ----
     // The serial chain of a group (128 dependent steps per pivot block, each a handful of VALU / DPP / MFMA instructions) is
     // several times slower when its waves share their SIMDs with the MFMA stream of a tile item, and then IT sets the pace
@@ -1894,126 +2166,57 @@ __device__ __forceinline__ void sweep_one_family(const SweepDesc &D)
     // items of a chain hand their data on through one L2.  Everybody else takes the main list.  The elected CUs are lost to
     // the tiles (2 n_mcu of 512 workgroups) and join them once the M list is exhausted.
     if (threadIdx.x == 0) {
+        launch_desc_init();
         *abort_lds() = 0;
-        unsigned xcc, hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        xcc &= 15u;
-        int worker = 0;
-        // the XCD of the chain is whichever one the first workgroup to get here runs on (not a fixed id: under a CU mask, in
-        // a partitioned mode or beside another tenant no workgroup of the launch may ever run on XCC 0)
-        const bool candidate = !(D.debug & 2) && !((D.debug & 1) && xcc == 0u) && !((D.debug & 4) && xcc != 0u);
-        if (candidate) {
-            const unsigned old = atomicCAS(D.mxcc, 0u, xcc + 1u);
-            if (old == 0u || old == xcc + 1u) {
-                const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
-                for (int k = 0; k < D.n_mcu && !worker; ++k) {
-                    const unsigned o2 = atomicCAS(D.mcu + k, 0u, key);
-                    if (o2 == 0u || o2 == key) worker = 1;
-                }
-            }
-        }
-        s_item = worker;
+        sw_item = sweep_elect(1);
     }
     __syncthreads();
-    const bool m_worker = s_item != 0;
+    const bool m_worker = sw_item >= 0;
     // the clock this launch really ran at (the governor moves it between 1.7 and 2.4 GHz, and not every XCD need run at the
     // same one): every workgroup times itself, the sums give the workgroup-time-weighted average over the chip
-    const bool clock_probe = threadIdx.x == 0;
-    const unsigned long long probe_c0 = clock_probe ? (unsigned long long)clock64() : 0ull;
-    const unsigned long long probe_w0 = clock_probe ? wall_clock64() : 0ull;
-    __syncthreads();
-    if (m_worker) {
-        int q = 0;
-        for (;;) {
-            if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(D.next_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int item = s_item;
-            __syncthreads();
-            if (item >= D.total_m || *abort_lds()) break;
-            while (item >= D.mitem0[q + 1]) ++q;
-            int e = item - D.mitem0[q];
-            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item] = wall_clock64();
-            const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
-            const int nm = m_items(sz);
-            if (e < nm) {
-                sweep_m_item(D, q, e, Gs, Hs, D.dbg ? D.dbg + 2 * item : nullptr);
-                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
-                continue;
-            }
-            e -= nm;
-            if (D.slab) {
-                if (e < SLAB_ITEMS)
-                    sweep_slab_item(D, q, e, 1, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
-                else if (e < 2 * SLAB_ITEMS)
-                    sweep_xslab_item(D, q, e - SLAB_ITEMS, D.dbg ? D.dbg + 2 * item : nullptr);
-                else
-                    sweep_slab_item(D, q, e - 2 * SLAB_ITEMS, 2, &Gs[0][0][0], D.dbg ? D.dbg + 2 * item : nullptr);
-                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
-                continue;
-            }
-            // the next group's rows, one after the other: the 2 sz panel items of row rr, then the tiles (rr, 0 .. rr) of its
-            // diagonal super-block -- its FIRST diagonal tile, which the next group's first pivot waits for, is complete after one
-            // round of panel items instead of after all of them
-            int rr = 0;
-            while (e >= 2 * sz + rr + 1) {
-                e -= 2 * sz + rr + 1;
-                ++rr;
-            }
-            if (e < 2 * sz) {
-                sweep_panel_item<2>(D, q, c0 + rr, e, Gs, Hs);
-                if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
-                continue;
-            }
-            e -= 2 * sz;
-            if (MULTI && sz > 1)
-                sweep_tile_item<true>(D, q, c0 + rr, c0 + e, Gs, Hs);
-            else
-                sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
-            if (D.dbg && threadIdx.x == 0) D.dbg[2 * item + 1] = wall_clock64();
-        }
+    // (thread 0's start stamps wait in LDS: in registers they would be live -- spilled -- across everything below)
+    if (threadIdx.x == 0) {
+        sw_probe[0] = (unsigned long long)clock64();
+        sw_probe[1] = wall_clock64();
     }
+    __syncthreads();
+    if (m_worker) sweep_chain_worker<MULTI>(0);
     int p = 0;  // group whose sequence the last item belonged to (items come in ascending order)
     // the NEXT item is requested while the current one is being worked on (the returning atomic takes a microsecond or two
     // under load); its number stays in a register of thread 0 until the end of the item (so that nobody waits for it) and
-    // reaches the others through s_next; s_ready = the next item is a tile item whose flags were already seen set
-    __shared__ int s_next, s_ready;
+    // reaches the others through sw_next; sw_ready = the next item is a tile item whose flags were already seen set
     if (threadIdx.x == 0) {
-        s_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ready = 0;
+        sw_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sw_ready = 0;
     }
     for (;;) {
         __syncthreads();
-        const int item = s_next, rdy = s_ready;
+        const int item = sw_next, rdy = sw_ready;
         __syncthreads();  // everybody has read them
         if (item >= D.total || *abort_lds()) break;
         int nxt = 0;
         if (threadIdx.x == 0) nxt = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t_item = (D.dbg && threadIdx.x == 0) ? wall_clock64() : 0ull;
-        const unsigned long long c_item = (D.dbg && threadIdx.x == 0) ? (unsigned long long)clock64() : 0ull;
+        // (trace: the item's start stamps wait in LDS, not in registers of thread 0 that would be live across the item)
+        if (D.dbg && threadIdx.x == 0) {
+            sw_stamp[0] = wall_clock64();
+            sw_stamp[1] = (unsigned long long)clock64();
+        }
         const MainItem it = main_decode(D, p, item);
         // trace (between single blocks): when the main list's items of row block b0 + 3 of update it.p were taken and done -- the
         // inputs the chain waits for: [0..2] its panel halves (first taken, last done), [3..] tiles (b0+3, b0+1), (b0+3, b0+2), (b0+3, b0+3)
-        int xslot = -1;
         if (D.dbg && D.slab && threadIdx.x == 0) {
-            const int r3 = g_start(D, it.p) + 3;
-            if (it.kind == 0 && it.a == r3) xslot = 0;
-            if (it.kind == 4 && it.a == r3) xslot = 3 + 2 * (it.b - (r3 - 2));
+            const int xslot = sweep_trace_xslot(D, it);
             if (xslot >= 0) {
                 unsigned long long *xs = D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * it.p;
                 if (xslot == 0) atomicCAS(xs + 0, 0ull, wall_clock64()); else xs[xslot] = wall_clock64();
             }
         }
-        if (it.kind == 1 || it.kind == 4) {
-            const NextTake nt{nxt, &s_next, &s_ready, nullptr, 0, 0, nullptr};
-            if (D.rl < T && it.a == D.nblk - 1)
-                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
-            else if (MULTI && g_size(D, it.p) > 1)
-                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
-            else
-                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt,
-                                       D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
-            if (D.dbg && threadIdx.x == 0) {
+        const NextTake nt{nxt, 1, 0};
+        const bool published = sweep_main_item<MULTI>(D, 0, it, rdy, nt);
+        if (D.dbg && threadIdx.x == 0) {
+            const unsigned long long t_item = sw_stamp[0], c_item = sw_stamp[1];
+            const int xslot = D.slab ? sweep_trace_xslot(D, it) : -1;
+            if (it.kind == 1 || it.kind == 4) {
                 atomicAdd(D.dbg_main + 6, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 7, 1ull);
                 const unsigned long long cyc = (unsigned long long)clock64() - c_item;
@@ -2022,50 +2225,25 @@ __device__ __forceinline__ void sweep_one_family(const SweepDesc &D)
                 atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 1, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 8 + 1024 + 3 * it.p + 2, 1ull);
                 if (xslot >= 3) D.dbg_main[8 + 1024 + 3 * D.ng + 16 * it.p + xslot + 1] = wall_clock64();
-            }
-            continue;
-        }
-        if (it.kind == 0) {
-            if (D.ppb == 1)
-                sweep_panel_item<4>(D, it.p, it.a, it.b, Gs, Hs);
-            else
-                sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
-            if (D.dbg && threadIdx.x == 0) {
+            } else if (it.kind == 0) {
                 atomicAdd(D.dbg_main + 2, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 3, 1ull);
                 if (xslot == 0) atomicMax(D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * it.p + 1, wall_clock64());
-            }
-        } else if (it.kind == 2) {
-            sweep_wb_item(D, it.p, it.a, Gs);
-            if (D.dbg && threadIdx.x == 0) {
+            } else if (it.kind == 2) {
                 atomicAdd(D.dbg_main + 4, wall_clock64() - t_item);
                 atomicAdd(D.dbg_main + 5, 1ull);
             }
         }
-        if (threadIdx.x == 0) {
-            s_next = nxt;
-            s_ready = 0;
+        if (!published && threadIdx.x == 0) {
+            sw_next = nxt;
+            sw_ready = 0;
         }
     }
-    if (clock_probe) {
-        atomicAdd(&D.sc->sweep_cycles, (unsigned long long)clock64() - probe_c0);
-        atomicAdd(&D.sc->sweep_ticks, wall_clock64() - probe_w0);
+    if (threadIdx.x == 0) {
+        atomicAdd(&D.sc->sweep_cycles, (unsigned long long)clock64() - sw_probe[0]);
+        atomicAdd(&D.sc->sweep_ticks, wall_clock64() - sw_probe[1]);
     }
     if (D.dbg && threadIdx.x == 0) D.dbg_main[8 + blockIdx.x] = wall_clock64();  // when this workgroup ran out of work
-}
-
-template <bool MULTI>
-__global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    // the descriptor is read where it lies, in the kernel-argument segment
-    typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
-    const SweepDesc &D = *(const SweepDesc *)(kernarg_desc_t)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)Darg;
-#else
-    const SweepDesc &D = Darg;
-#endif
-    sweep_one_family<MULTI>(D);
 }
 
 // =====================================================================================================================
@@ -2077,9 +2255,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
 // compute unit.  So the launch itself carries K families: one descriptor, item table and flag block per family (exactly what a
 // launch of its own would get, so the arithmetic of a family -- every tile's update order is fixed by ITS flags -- is bit for bit
 // that of a single run), and
-//   * every family's chain gets compute units of its own: a workgroup on XCC x offers itself to family (x + t) % K, t = 0, 1, ..:
-//     the first workgroup to reach a family decides its XCD, so with K <= 8 the chains sit on different XCDs (each hands its
-//     data on through one L2) whenever the workgroups of a launch are spread over them;
+//   * every family's chain gets compute units of its own (sweep_elect);
 //   * everybody else takes main-list items of the families in turn (its j-th take goes to the next family that still has
 //     items): the families advance side by side, and a workgroup parked on an item of family A that waits for A's chain keeps
 //     nothing of family B from running.
@@ -2093,183 +2269,100 @@ struct SweepBatch {
     SweepDesc fam[SWEEP_MAX_MERGE];
     int K;
 };
+static_assert(offsetof(SweepBatch, fam) == 0, "launch_desc(f) finds member f at the start of the kernel-argument segment");
+__shared__ int sw_p[SWEEP_MAX_MERGE];
 
 template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
 {
-    __shared__ __attribute__((aligned(16))) double GHs[4][KC][LDS_LD];
-    double(*const Gs)[KC][LDS_LD] = GHs;
-    double(*const Hs)[KC][LDS_LD] = GHs + 2;
-    __shared__ int s_item, s_fam, s_next, s_ready, s_live;
-    __shared__ int s_p[SWEEP_MAX_MERGE];
+    (void)Barg;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const SweepBatch __attribute__((address_space(4))) *kernarg_batch_t;
-    const SweepBatch &B = *(const SweepBatch *)(kernarg_batch_t)__builtin_amdgcn_kernarg_segment_ptr();
-    (void)Barg;
+    const int K = ((const SweepBatch *)(kernarg_batch_t)__builtin_amdgcn_kernarg_segment_ptr())->K;
 #else
-    const SweepBatch &B = Barg;
+    const int K = Barg.K;
 #endif
-    const int K = B.K;
     if (threadIdx.x == 0) {
+        launch_desc_init();
         *abort_lds() = 0;
-        unsigned xcc, hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        xcc &= 15u;
-        int worker = 0, wf = 0;
-        const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
-        for (int t = 0; t < K && !worker; ++t) {
-            const int f = (int)((xcc + (unsigned)t) % (unsigned)K);
-            const SweepDesc &Df = B.fam[f];
-            const bool candidate = !(Df.debug & 2) && !((Df.debug & 1) && xcc == 0u) && !((Df.debug & 4) && xcc != 0u);
-            if (!candidate) continue;
-            const unsigned old = atomicCAS(Df.mxcc, 0u, xcc + 1u);
-            if (old == 0u || old == xcc + 1u) {
-                for (int k = 0; k < Df.n_mcu && !worker; ++k) {
-                    const unsigned o2 = atomicCAS(Df.mcu + k, 0u, key);
-                    if (o2 == 0u || o2 == key) worker = 1;
-                }
-                if (worker) wf = f;
-            }
-        }
-        s_item = worker;
-        s_fam = wf;
-        for (int f = 0; f < SWEEP_MAX_MERGE; ++f) s_p[f] = 0;
+        sw_item = sweep_elect(K);
+        for (int f = 0; f < SWEEP_MAX_MERGE; ++f) sw_p[f] = 0;
     }
     __syncthreads();
-    const bool m_worker = s_item != 0;
-    const int wfam = __builtin_amdgcn_readfirstlane(s_fam);
-    const bool clock_probe = threadIdx.x == 0;
-    const unsigned long long probe_c0 = clock_probe ? (unsigned long long)clock64() : 0ull;
-    const unsigned long long probe_w0 = clock_probe ? wall_clock64() : 0ull;
-    __syncthreads();
-    if (m_worker) {
-        const SweepDesc &D = B.fam[wfam];
-        int q = 0;
-        for (;;) {
-            if (threadIdx.x == 0) s_item = (int)__hip_atomic_fetch_add(D.next_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int item = s_item;
-            __syncthreads();
-            if (item >= D.total_m || *abort_lds()) break;
-            while (item >= D.mitem0[q + 1]) ++q;
-            int e = item - D.mitem0[q];
-            const int b0 = g_start(D, q), sz = g_size(D, q), c0 = b0 + sz;
-            const int nm = m_items(sz);
-            if (e < nm) {
-                sweep_m_item(D, q, e, Gs, Hs);
-                continue;
-            }
-            e -= nm;
-            if (D.slab) {
-                if (e < SLAB_ITEMS)
-                    sweep_slab_item(D, q, e, 1, &Gs[0][0][0]);
-                else if (e < 2 * SLAB_ITEMS)
-                    sweep_xslab_item(D, q, e - SLAB_ITEMS);
-                else
-                    sweep_slab_item(D, q, e - 2 * SLAB_ITEMS, 2, &Gs[0][0][0]);
-                continue;
-            }
-            int rr = 0;
-            while (e >= 2 * sz + rr + 1) {
-                e -= 2 * sz + rr + 1;
-                ++rr;
-            }
-            if (e < 2 * sz) {
-                sweep_panel_item<2>(D, q, c0 + rr, e, Gs, Hs);
-                continue;
-            }
-            e -= 2 * sz;
-            if (MULTI && sz > 1)
-                sweep_tile_item<true>(D, q, c0 + rr, c0 + e, Gs, Hs);
-            else
-                sweep_tile_item<false>(D, q, c0 + rr, c0 + e, Gs, Hs);
-        }
+    const int wfam = __builtin_amdgcn_readfirstlane(sw_item);
+    if (threadIdx.x == 0) {
+        sw_probe[0] = (unsigned long long)clock64();
+        sw_probe[1] = wall_clock64();
     }
+    __syncthreads();
+    if (wfam >= 0) sweep_chain_worker<MULTI>(wfam);
     // ---- the main lists, the families in turn ----
-    // Which family the next take goes to is thread 0's business (s_live: the families whose list this workgroup has not yet seen
-    // exhausted); the workgroup learns the family of the current item from s_fam, next to its number in s_next.  As in k_sweep the
+    // Which family the next take goes to is thread 0's business (sw_live: the families whose list this workgroup has not yet seen
+    // exhausted); the workgroup learns the family of the current item from sw_fam, next to its number in sw_next.  As in k_sweep the
     // next item is requested while the current one is worked on, its number reaches LDS inside the item (tile_item_finish: with
-    // the look-ahead at that item's flags), and per family the items of a workgroup ascend (s_p: the group its last item there
+    // the look-ahead at that item's flags), and per family the items of a workgroup ascend (sw_p: the group its last item there
     // belonged to).
     if (threadIdx.x == 0) {
-        s_live = (int)((1u << K) - 1u);
+        sw_live = (int)((1u << K) - 1u);
         const int f0 = (int)(blockIdx.x % (unsigned)K);
-        s_fam = f0;
-        s_next = (int)__hip_atomic_fetch_add(B.fam[f0].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ready = 0;
+        sw_fam = f0;
+        sw_next = (int)__hip_atomic_fetch_add(launch_desc_k(f0).next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sw_ready = 0;
     }
     for (;;) {
         __syncthreads();
-        const int item = s_next, rdy = s_ready;
-        const int f = __builtin_amdgcn_readfirstlane(s_fam);
+        const int item = sw_next, rdy = sw_ready;
+        const int f = __builtin_amdgcn_readfirstlane(sw_fam);
         __syncthreads();  // everybody has read them
         if (f < 0 || *abort_lds()) break;
-        const SweepDesc &D = B.fam[f];
+        const SweepDesc &D = launch_desc_k(f);
         if (item >= D.total) {
             // this family's list is exhausted: strike it and take from the next one that is not (none left: f = -1 ends the loop)
             if (threadIdx.x == 0) {
-                const unsigned live = (unsigned)s_live & ~(1u << f);
-                s_live = (int)live;
+                const unsigned live = (unsigned)sw_live & ~(1u << f);
+                sw_live = (int)live;
                 int fn = -1;
                 if (live) {
                     fn = f;
                     do fn = fn + 1 == K ? 0 : fn + 1; while (!((live >> fn) & 1u));
-                    s_next = (int)__hip_atomic_fetch_add(B.fam[fn].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sw_next = (int)__hip_atomic_fetch_add(launch_desc_k(fn).next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                s_fam = fn;
-                s_ready = 0;
+                sw_fam = fn;
+                sw_ready = 0;
             }
             continue;
         }
-        int nxt = 0, fn = 0, pn = 0;
-        if (threadIdx.x == 0) {
-            const unsigned live = (unsigned)s_live;
-            fn = f;
-            do fn = fn + 1 == K ? 0 : fn + 1; while (!((live >> fn) & 1u));
-            nxt = (int)__hip_atomic_fetch_add(B.fam[fn].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pn = s_p[fn];
-        }
-        int p = s_p[f];
+        int nxt = 0;
+        int p = sw_p[f];
         const MainItem it = main_decode(D, p, item);
         if (threadIdx.x == 0) {
-            s_p[f] = p;  // (the others read it again only after the barriers at the top of the loop, or see this very value)
-            if (fn == f) pn = p;
+            const unsigned live = (unsigned)sw_live;
+            int fn = f;
+            do fn = fn + 1 == K ? 0 : fn + 1; while (!((live >> fn) & 1u));
+            nxt = (int)__hip_atomic_fetch_add(launch_desc_k(fn).next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sw_p[f] = p;  // (the others read it again only after the barriers at the top of the loop, or see this very value)
+            sw_fnext = fn;
+            sw_pnext = sw_p[fn];  // (fn == f: the value just written)
         }
-        if (it.kind == 1 || it.kind == 4) {
-            const NextTake nt{nxt, &s_next, &s_ready, &B.fam[fn], pn, fn, &s_fam};
-            if (D.rl < T && it.a == D.nblk - 1)
-                sweep_tile_item_ragged(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
-            else if (MULTI && g_size(D, it.p) > 1)
-                sweep_tile_item<true>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt);
-            else
-                sweep_tile_item<false>(D, it.p, it.a, it.b, Gs, Hs, rdy, nt,
-                                       D.slab && it.kind == 4 && it.a > it.b && it.a > g_start(D, it.p) + 1);
-            continue;
-        }
-        if (it.kind == 0) {
-            if (MULTI && D.ppb == 1)
-                sweep_panel_item<4>(D, it.p, it.a, it.b, Gs, Hs);
-            else
-                sweep_panel_item<2>(D, it.p, it.a, it.b, Gs, Hs);
-        } else if (it.kind == 2)
-            sweep_wb_item(D, it.p, it.a, Gs);
-        if (threadIdx.x == 0) {
-            s_next = nxt;
-            s_fam = fn;
-            s_ready = 0;
+        const NextTake nt{nxt, 1, 1};
+        const bool published = sweep_main_item<MULTI>(D, f, it, rdy, nt);
+        if (!published && threadIdx.x == 0) {
+            sw_next = nxt;
+            sw_fam = sw_fnext;
+            sw_ready = 0;
         }
     }
     if (threadIdx.x == 0) {
-        const unsigned long long cyc = (unsigned long long)clock64() - probe_c0, tk = wall_clock64() - probe_w0;
+        const unsigned long long cyc = (unsigned long long)clock64() - sw_probe[0], tk = wall_clock64() - sw_probe[1];
         const bool aborted = *abort_lds() != 0;
         for (int k = 0; k < K; ++k) {
-            atomicAdd(&B.fam[k].sc->sweep_cycles, cyc);
-            atomicAdd(&B.fam[k].sc->sweep_ticks, tk);
+            const SweepDesc &Dk = launch_desc_k(k);
+            atomicAdd(&Dk.sc->sweep_cycles, cyc);
+            atomicAdd(&Dk.sc->sweep_ticks, tk);
             // a wait of ANY member ran out of time: this workgroup has dropped its items, so no member's result can be trusted
             if (aborted) {
-                __hip_atomic_store(B.fam[k].abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&B.fam[k].sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(Dk.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&Dk.sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

@@ -110,6 +110,11 @@ typedef struct gdca_stats {
                                    (sharp whenever some column has no gap).  Every run whose bound is below REFINE_COND is
                                    KNOWN to be well enough conditioned for the sweep and pays nothing for the screen; +inf at
                                    pseudocount 0; 0 with option REFINE=0 */
+    /* (fields are only ever added at the end: a caller built against an older header reads a valid prefix) */
+    double ms_fn;               /* the FN kernel alone (HBM-bound: one pass over the lower block triangle of the inverse,
+                                   8 n (n - s) / 2 bytes); 0 for the DI score and for a run refined at collect time */
+    double ms_pair_tally;       /* the pair-tally kernel alone, with its pseudocount + covariance epilogue (its one
+                                   compulsory HBM write: 8 n^2 bytes); 0 with option REFINE=0                      */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */

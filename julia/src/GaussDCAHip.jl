@@ -38,6 +38,7 @@ mutable struct GdcaStats
     ms_inverse::Cdouble; ms_inverse_update::Cdouble; ms_score::Cdouble
     inverse_flops::Cdouble; update_flops::Cdouble
     sweep_ghz::Cdouble; inverse_norm1::Cdouble; matrix_norm1::Cdouble; cond_bound::Cdouble
+    ms_fn::Cdouble; ms_pair_tally::Cdouble
     GdcaStats() = new()
 end
 

@@ -42,7 +42,7 @@ def test_python_binding_covers_the_header(lib_path):
     assert sorted(_lib.SYMBOLS) == _declared_symbols()
     lib = _lib.load()
     assert lib.gdca_version() == 4
-    assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 10 + 8 * 13  # ten int32, thirteen more doubles
+    assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 10 + 8 * 15  # ten int32, fifteen more doubles
     assert ctypes.sizeof(_lib.Params) == 24
 
 

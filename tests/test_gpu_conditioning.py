@@ -72,7 +72,7 @@ def _covariance(o, Zo, q, pc):
     return o.compute_C(*o.add_pseudocount(*o.compute_frequencies(Zo, q, W, Meff), pc, q))
 
 
-def _forward_errors(g, o, ctx, C, ncols=5, seed=0):
+def _forward_errors(g, o, ctx, C, ncols=2, seed=0):
     """Forward error (max over sampled refined columns, relative to the largest entry) of the sweep alone (REFINE=0), of the
     default path (REFINE=auto: one Newton-Schulz step beyond kappa_1 = 1e6), of LAPACK's potrf + potri; cond estimate."""
     rng = np.random.default_rng(seed)
@@ -93,6 +93,8 @@ def _forward_errors(g, o, ctx, C, ncols=5, seed=0):
 
 # (the window between the pseudocounts gDCA is used with and the tiny ones -- pc 0.01 .. 0.001 on the reference's own
 # `large` data, ||C||_1 ~ 80, kappa_1 1e7 .. 1e8 -- was untested, and the fused path's screen assumed ||C||_1 ~ 1 there)
+_NORM1 = {}  # ||C||_1 by the oracle, per (family, pseudocount): computed once for both scores
+
 CASES = [("large.fasta.gz", 0.05), ("large.fasta.gz", 0.02), ("large.fasta.gz", 0.01), ("large.fasta.gz", 0.005), ("large.fasta.gz", 0.002),
          ("large.fasta.gz", 0.001), ("large.fasta.gz", 1e-4), ("synthetic N=430 M=600", 0.05), ("synthetic N=430 M=600", 0.01),
          ("synthetic N=430 M=600", 0.003), ("synthetic N=430 M=600", 1e-3), ("synthetic N=430 M=600", 1e-6)]
@@ -150,12 +152,10 @@ def test_scores_at_small_pseudocounts_match_oracle(env, name, pc, score):
     kappa1 = st["matrix_norm1"] * st["inverse_norm1"]
     print("\n%s pc=%g %s: ||C||_1 = %.1f, bound of cond_2 %.2e, ||X||_1 = %.2e, kappa_1 %.2e, refined %d, bar %.1e"
           % (name, pc, score, st["matrix_norm1"], st["cond_bound"], st["inverse_norm1"], kappa1, st["refined"], 1e-6 * slack))
-    C = _covariance(o, Zo, q, pc)
-    assert abs(st["matrix_norm1"] - np.abs(C).sum(axis=0).max()) <= 1e-9 * st["matrix_norm1"]      # ||C||_1 from the tally's epilogue
-    assert st["cond_bound"] == pytest.approx(st["matrix_norm1"] * q * q / pc, rel=1e-12)
-    # the bound is a bound (and sharp on these families: lambda_min(C) = pc / q^2)
-    lam_min = float(np.linalg.eigvalsh(C)[0]) if C.shape[0] <= 1200 else None
-    assert lam_min is None or lam_min >= pc / q ** 2 * (1 - 1e-9)
+    if (name, pc) not in _NORM1:
+        _NORM1[(name, pc)] = float(np.abs(_covariance(o, Zo, q, pc)).sum(axis=0).max())
+    assert abs(st["matrix_norm1"] - _NORM1[(name, pc)]) <= 1e-9 * st["matrix_norm1"]      # ||C||_1 from the tally's epilogue
+    assert st["cond_bound"] == pytest.approx(st["matrix_norm1"] * q * q / pc, rel=1e-12)  # (that it IS a bound: tests/test_oracle_golden.py)
     # ||X||_1 is measured exactly where the bound leaves the question open, and the decision is kappa_1's
     assert (st["inverse_norm1"] > 0.0) == (st["cond_bound"] > 1e6)
     assert st["refined"] == (1 if kappa1 > 1e6 else 0)

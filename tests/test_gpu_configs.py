@@ -297,6 +297,35 @@ def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
         assert got == want.read_bytes(), f
 
 
+def test_config_E_whole_batch_through_the_batch_driver(g, ctx, tmp_path):
+    """BASELINE.json configs[4] WHOLE, on one GPU: all 256 families (N in [100, 600], M in [5k, 80k], 4 GB of FASTA written by the
+    library's own generator) through `gdca_cli --batch` -- every family must come out (`(0 failed)`, 256 ranking files with the
+    length compute_ranking gives for its N), and a sample spread over the sizes must be byte-identical to the single-family path.
+    (The batch of the bench line: `bench.py --config E` runs the same 256 families device-resident.)"""
+    from gaussdca.jl_amd.batch import batch_sizes
+
+    sizes = batch_sizes(256)
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    for f, (N, M) in enumerate(sizes):
+        subprocess.run([CLI, "--synth", str(N), str(M), str(0xE000 + f), str(indir / ("fam%03d.fasta" % f))], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([CLI, "--batch", str(indir), "--out", str(outdir), "--merge", "1"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "256 families" in r.stderr and "(0 failed)" in r.stderr, r.stderr[-2000:]
+    for f, (N, M) in enumerate(sizes):
+        with open(outdir / ("fam%03d.rank.txt" % f), "rb") as fh:
+            assert sum(1 for _ in fh) == (N - 5) * (N - 4) // 2, f       # compute_ranking with min_separation = 5
+    by_size = sorted(range(256), key=lambda f: sizes[f][0] * 100000 + sizes[f][1])
+    want = tmp_path / "want.txt"
+    for f in [by_size[k] for k in (0, 37, 90, 128, 171, 214, 255)] + [7]:
+        N, M = sizes[f]
+        R = g.gDCA(str(indir / ("fam%03d.fasta" % f)), ctx=ctx)
+        st = g.gdca.last_stats
+        assert (st["N"], st["M"]) == (N, M) and st["info"] == 0
+        g.printrank(str(want), R)
+        assert (outdir / ("fam%03d.rank.txt" % f)).read_bytes() == want.read_bytes(), f
+
+
 def _read_rank(path):
     ii, jj, ss = [], [], []
     with open(path) as fh:

@@ -3,7 +3,7 @@
 (408 bytes of scratch per lane) because a count pass that could never count anything in that form kept its 64 accumulators alive
 across the refinement loop: 0.5 ms of a 23 ms family.  Nothing in the test suite could see that -- results were right.  This test
 pins what the compiler reports today, so that the next such regression shows up when it is made: every kernel of these files runs
-without scratch, except the bound form of the Hamming kernel (a bounded remainder around its cold refinement path).
+without scratch.
 (`k_inverse.hip` takes six minutes to compile and is covered by `tools/kernel_resources.py` -> profiles/rNN_kernel_resources.txt.)"""
 import os
 import re
@@ -18,11 +18,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wno-unused-function", "-Wno-pass-failed",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
-# (file, substring of the mangled kernel name) -> (max spilled VGPRs, max scratch bytes per lane); everything else: 0 / 0
-ALLOWED = {
-    ("k_hamming.hip", "k_hammingILi3ELb0E"): (40, 160),   # bound form: 36-37 spills around the refinement, none in the main loop
-    ("k_hamming.hip", "k_hammingILi3ELb1E"): (16, 64),    # its probe
-}
+# (file, substring of the mangled kernel name) -> (max spilled VGPRs, max scratch bytes per lane); everything else: 0 / 0.
+# Round 5: empty -- the bound form of the Hamming kernel, which carried 36 spilled VGPRs around an inlined refinement path (and
+# stored them on every tile: 2.2 GB written per launch at config C), now only lists its candidates; a kernel of its own refines them.
+ALLOWED = {}
 
 
 @pytest.mark.parametrize("src", ["k_hamming.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])

@@ -134,6 +134,23 @@ def test_pseudocount_and_covariance_rules():
         o.spd_inverse(o.compute_C(Pi0, Pij0))
 
 
+@pytest.mark.parametrize("pc", [0.8, 0.2, 0.02, 0.001])
+def test_pseudocount_bounds_the_smallest_eigenvalue_of_the_covariance(refdata, pc):
+    """What the device path's refinement screen rests on (gdca_api.hip, cond_bound): with pseudocount pc the covariance is that of a
+    mixture with weight pc on independent uniform columns, so lambda_min(C) >= pc / q^2 and cond_2(C) <= ||C||_1 q^2 / pc -- on the
+    reference's own alignment, with and without gaps in every column (q = 21 and a gap-free q = 20 one), and on a random one."""
+    Zs = [o.remove_duplicate_sequences(o.read_fasta_alignment(os.path.join(refdata, "small.fasta.gz"), 0.9))[0]]
+    Zs.append(np.where(Zs[0] == 21, 1, Zs[0]).astype(np.int8))       # no gaps at all: q = 20
+    Zs.append(_random_msa(np.random.default_rng(8), 60, 9))
+    for Z in Zs:
+        q = int(Z.max())
+        Pi_t, Pij_t, Meff, W = o.compute_weighted_frequencies(Z, q, "auto")
+        C = o.compute_C(*o.add_pseudocount(Pi_t, Pij_t, pc, q))
+        lam = np.linalg.eigvalsh(C)
+        assert lam[0] >= pc / q ** 2 * (1 - 1e-8), (q, pc, lam[0], pc / q ** 2)
+        assert lam[-1] / lam[0] <= np.abs(C).sum(axis=0).max() * q * q / pc * (1 + 1e-8)
+
+
 def test_apc_and_ranking_rules():
     rng = np.random.default_rng(9)
     S = rng.random((12, 12))
