@@ -113,7 +113,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
-        {"CHOLESKY", &t->cholesky, 0, 2},
+        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -161,13 +161,14 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_mcus = -1;
     t->merge_group = -1;
     t->merge_tiles = 2300;
+    t->phased_fronts = 1;
     t->refine = -1;
     t->refine_cond = 1e6;
     t->cholesky = 1;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -464,7 +465,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
 }
 
 // stage 3: Pi, pair tallies.  mode 0 -> Pij_true (ld) ; mode 1 -> covariance (ld)
-// want_norm1 (mode 1): the covariance build also leaves ||C||_1 in sc->mat_norm1 (a reduction inside its epilogue)
+// want_norm1 (mode 1): the fused path's first build -- sc->pi_max, and sc->mat_norm1 = ||C||_1 where the screen needs it (k_cov_norm1)
 static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, int q, const double *Meff_dev, double pc,
                                int mode, double *Pi_true_out, double *out, size_t ld, bool want_norm1 = false)
 {
@@ -476,7 +477,6 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     CHK(ensure(ctx, ctx->Zp, (size_t)round_up(N, 64) * M + 64));
     CHK(ensure(ctx, ctx->Pifix, (size_t)N * 32 * sizeof(unsigned long long)));
     CHK(ensure(ctx, ctx->Pipc, (size_t)n * sizeof(double)));
-    if (want_norm1) CHK(ensure(ctx, ctx->normws, (size_t)round_up(n, GDCA_TILE) * sizeof(double)));  // (the ||X||_1 pass uses it later)
     gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
     gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
@@ -487,14 +487,16 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
         ctx->meff_pending = false;
     }
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
-                            (double *)ctx->Pipc.p);
+                            (double *)ctx->Pipc.p, want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->pi_max : nullptr);
     const bool tm = want_norm1 && ctx->timing && ctx->n_ev >= 18;  // (the fused path's first build: its own device time, gdca_stats.ms_pair_tally)
     if (tm) HIPCHK(hipEventRecord(ctx->ev[9], s));
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
                            (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
-                           (const double *)ctx->Pipc.p, mode, out, ld, TJ, want_norm1 ? (unsigned long long *)ctx->normws.p : nullptr,
-                           want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->mat_norm1 : nullptr);
+                           (const double *)ctx->Pipc.p, mode, out, ld, TJ);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[10], s));
+    // ||C||_1 for the refinement screen, where the bound that costs nothing (2 N pi_max) does not settle it (k_cov_norm1)
+    if (want_norm1)
+        gdca_launch_cov_norm1(s, out, ld, N, q, pc, ctx->tune.refine_cond, (gdca_dev_scalars *)ctx->sc.p, ctx->tune.refine == 1);
     return check_launch(ctx, "tally");
 }
 
@@ -635,18 +637,21 @@ static gdca_status inverse_norm_stage(gdca_ctx *ctx, int n, int n_pad)
     return check_launch(ctx, "inverse_norm1");
 }
 
-// The screen of the fused path costs no pass over anything: the covariance with pseudocount pc is that of a MIXTURE -- weight 1 - pc
+// The screen of the fused path costs ordinary families nothing: the covariance with pseudocount pc is that of a MIXTURE -- weight 1 - pc
 // on the reweighted alignment, weight pc on independent uniform columns -- so  C >= pc Cov_uniform  in the positive-definite order, and
 // Cov_uniform = blockdiag(I / q - 1 1^T / q^2) (q - 1 states a column) has smallest eigenvalue 1 / q^2:
 //       lambda_min(C) >= pc / q^2,     cond_2(C) <= ||C||_1 q^2 / pc
-// (attained on every alignment tried: a column without gaps makes the bound sharp).  ||C||_1 comes out of the covariance build's
-// epilogue (sc->mat_norm1, no extra pass; on the reference's `large` data 64 .. 94), so at the pseudocounts gDCA is used with the
-// bound is 1e4 .. 1e5 and the run pays nothing; beyond the threshold the collect measures ||X||_1 itself (one pass over the lower
-// triangle) and decides on kappa_1 = ||C||_1 ||X||_1 like the operator-level entry.  Returns +inf where there is no bound (pc = 0).
-static double cond_bound(const gdca_dev_scalars &h, double pc, int q)
+// (attained on every alignment tried: a column without gaps makes the bound sharp).  For ||C||_1 two figures: 2 N pi_max, which the
+// single-site frequencies give away (k_pi_finalize), and the measured norm (64 .. 94 on the reference's `large` data) where the first
+// is not enough -- k_cov_norm1 decides that on the device with this very formula, before the sweep overwrites C.  At the
+// pseudocounts gDCA is used with the bound is 1e4 .. 1e5 and the run pays nothing; beyond the threshold the collect measures ||X||_1
+// (one pass over the lower triangle) and decides on kappa_1 = ||C||_1 ||X||_1 like the operator-level entry.  +inf where there is no
+// bound (pc = 0).
+static double cond_bound(const gdca_dev_scalars &h, double pc, int q, int N)
 {
-    if (!(h.mat_norm1 > 0.0) || !(pc > 0.0)) return HUGE_VAL;
-    return h.mat_norm1 * (double)q * (double)q / pc;
+    const double c1 = h.mat_norm1 > 0.0 ? h.mat_norm1 : 2.0 * (double)N * h.pi_max;
+    if (!(c1 > 0.0) || !(pc > 0.0)) return HUGE_VAL;
+    return c1 * (double)q * (double)q / pc;
 }
 
 static bool wants_refinement(const gdca_ctx *ctx, const gdca_dev_scalars &h)
@@ -702,7 +707,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     ctx->rank_pending = false;  // (collected through this entry, a ranked run's ranking is given up: its arrays are scratch of the next run)
     CHK(fetch_scalars(ctx));
     if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
-        (ctx->tune.refine == 1 || cond_bound(*ctx->sc_host, ctx->pend_p.pseudocount, ctx->pend_q) > ctx->tune.refine_cond)) {
+        (ctx->tune.refine == 1 || cond_bound(*ctx->sc_host, ctx->pend_p.pseudocount, ctx->pend_q, ctx->pend_N) > ctx->tune.refine_cond)) {
         CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));   // cond(C) may be beyond the threshold: ||X||_1 itself
         CHK(fetch_scalars(ctx));
     }
@@ -764,7 +769,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->refined = ctx->pend_refined;
         st->inverse_norm1 = h.inv_norm1;
         st->matrix_norm1 = h.mat_norm1;
-        st->cond_bound = ctx->tune.refine != 0 ? cond_bound(h, ctx->pend_p.pseudocount, ctx->pend_q) : 0.0;
+        st->cond_bound = ctx->tune.refine != 0 ? cond_bound(h, ctx->pend_p.pseudocount, ctx->pend_q, ctx->pend_N) : 0.0;
         st->inverse_flops = inverse_flops_model((double)ctx->pend_n);
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
@@ -783,7 +788,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
             const double share = 1.0 / (double)(ctx->pend_batch > 0 ? ctx->pend_batch : 1);
             HIPCHK(hipEventElapsedTime(&ms, ev[6], ev[4]));  // from the start of its turn (after any pipeline gate)
             st->ms_inverse = ms * share;
-            HIPCHK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+            HIPCHK(hipEventElapsedTime(&ms, ev[11], ev[5]));
             st->ms_score = ms;
             HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
             st->ms_inverse_update = ms * share;
@@ -953,6 +958,8 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
 static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
     ctx->pend_S = S_dev;
+    // (the start of THIS run's score stage: in a phase batch the members' stages follow one another behind the shared inverse)
+    if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev, ctx->pend_timed));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->pending = true;
@@ -1037,21 +1044,33 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
             return vs;
         }
     }
-    // everything goes to the leader's stream, phase by phase: K front ends, K inverses back to back, K score stages.  The
-    // members keep their own workspaces, scalars and timing events; their streams are restored before returning.
+    // Phase by phase: K front ends, K inverses back to back, K score stages.  The inverses and the score stages go to the leader's
+    // stream.  The front ends (reweighting, tallies, covariance: kernels of a few dozen to a few hundred workgroups each for a small
+    // family -- the pair tally of an N = 128 family launches 36 on 256 compute units) run SIDE BY SIDE, each on its member's own
+    // stream, and the leader's stream waits for all of them before the first inverse (option PHASED_FRONTS=0: one after the other
+    // on the leader's stream, as in round 4: 8 x 0.55 ms in front of 8 x 0.43 ms of merged inverses at config B).  The members keep
+    // their own workspaces, scalars and timing events; their streams are restored before returning.
     hipStream_t own[64];
     if (K > 64) return fail(lead, GDCA_EINVAL, "at most 64 families per batch%s%s", "", "");
+    const bool side_by_side = lead->tune.phased_fronts != 0 && K > 1;
     for (int k = 0; k < K; ++k) {
         own[k] = ctxs[k]->stream;
         if (k > 0) (void)hipStreamSynchronize(own[k]);  // nothing of an earlier use is still in flight on the member's own stream
-        ctxs[k]->stream = lead->stream;
+        if (!side_by_side) ctxs[k]->stream = lead->stream;
     }
     gdca_status st = GDCA_OK;
     int done_front = 0;
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
         st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
+        if (st == GDCA_OK && side_by_side && k > 0) {
+            // the batch's stream goes on behind this member's front end
+            if (hipEventRecord(ctxs[k]->ev_batch, own[k]) != hipSuccess || hipStreamWaitEvent(lead->stream, ctxs[k]->ev_batch, 0) != hipSuccess)
+                st = fail(lead, GDCA_EHIP, "event chain of the batch's front ends%s%s", "", "");
+        }
         if (st == GDCA_OK) ++done_front;
     }
+    if (side_by_side)
+        for (int k = 0; k < K; ++k) ctxs[k]->stream = lead->stream;
     if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
     for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
     if (st != GDCA_OK) {
@@ -1060,6 +1079,7 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
         // member's message goes to the leader, whose last_error the caller reads.
         (void)hipStreamSynchronize(lead->stream);
         for (int k = 0; k < K; ++k) {
+            (void)hipStreamSynchronize(own[k]);  // (a front end enqueued side by side)
             if (ctxs[k]->side) (void)hipStreamSynchronize(ctxs[k]->side);
             ctxs[k]->pending = false;
             ctxs[k]->meff_pending = false;

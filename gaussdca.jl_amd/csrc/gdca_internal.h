@@ -26,7 +26,9 @@ struct gdca_dev_scalars {
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
     double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
     double ns_resid;     // max |I - X0 C| seen by the Newton-Schulz step (0: no step)
-    double mat_norm1;  // ||C||_1: from the covariance build's epilogue (fused path) or the caller's matrix (operator-level inverse); 0: not measured
+    double mat_norm1;  // ||C||_1: measured on the covariance before the sweep where the cheap bound leaves the question open (fused path), or on the
+                       // caller's matrix (operator-level inverse); 0: not measured
+    double pi_max;     // max over the n single-site frequencies with pseudocount (k_pi_finalize): ||C||_1 <= 2 N pi_max
 };
 
 // Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
@@ -51,8 +53,9 @@ struct gdca_tuning {
     int merge_mcus;         // GDCA_MERGE_MCUS: chain compute units per member of a merged launch
     int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
+    int phased_fronts;      // GDCA_PHASED_FRONTS: 1 = the front ends of a phase batch run side by side on the members' own streams (default), 0 = one after the other on the leader's
     int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
-    double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: kappa_1 estimate (||C||_1 ||X||_1; fused path: ||X||_1 alone)
+    double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: the a-priori bound of cond_2(C) first, beyond it kappa_1 = ||C||_1 ||X||_1
     int cholesky;           // GDCA_CHOLESKY: the blocked dpotrf + dpotri fallback: 0 = never, 1 = where the sweep gave up (default), 2 = always
     char sweep_trace[256];  // GDCA_SWEEP_TRACE: file the in-kernel trace of the next inverse is written to ("" = off)
 };
@@ -99,7 +102,11 @@ void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const unsigned long lo
                           unsigned long long *Pifix, int N, int M, int q, gdca_dev_scalars *sc);
 // Pi_true[i*s+a] = Pifix * 2^-shift / Meff;  Pi_pc = (1-pc) Pi_true + pc/q
 void gdca_launch_pi_finalize(hipStream_t s, const unsigned long long *Pifix, int N, int q, int fix_shift,
-                             const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc);
+                             const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc, double *pi_max = nullptr);
+// ||C||_1 of the covariance at C (full symmetric, ld) into sc->mat_norm1 -- only where 2 N pi_max q^2 / pc, the bound of cond(C) that
+// costs nothing, exceeds cond_limit (or `always`): otherwise every workgroup leaves at once
+void gdca_launch_cov_norm1(hipStream_t s, const double *C, size_t ld, int N, int q, double pc, double cond_limit, gdca_dev_scalars *sc,
+                           int always);
 // Pair tallies.  mode 0: out = Pij_true (full symmetric, ld);  mode 1: out = C =
 // add_pseudocount + compute_C fused (full symmetric, ld).  Pi_pc used by mode 1 only.
 // Zc: the alignment regrouped as [ceil(N/TJ)][M][TJ] (gdca_launch_colblock), TJ = gdca_tally_tj(q).
@@ -107,9 +114,7 @@ int gdca_tally_tj(int q, int tj_wanted);
 void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ);
 void gdca_launch_pair_tally(hipStream_t s, const int8_t *Zc, const int8_t *Zt, const unsigned long long *Wfix,
                             int N, int M, int q, int fix_shift, const double *Meff_dev, double pc,
-                            const double *Pi_pc, int mode, double *out, size_t ld, int TJ,
-                            unsigned long long *colabs_fix = nullptr, double *norm1_out = nullptr);
-// (mode 1, colabs_fix != nullptr: [N (q-1)] scratch; the kernel also leaves ||C||_1 of the covariance it writes in *norm1_out)
+                            const double *Pi_pc, int mode, double *out, size_t ld, int TJ);
 
 // ---- k_elementwise.hip ---------------------------------------------------------------------
 void gdca_launch_add_pseudocount(hipStream_t s, const double *Pi_true, const double *Pij_true, int N, int q,

@@ -118,6 +118,7 @@ __device__ __forceinline__ void tri_decode(int t, int Mt, int &I, int &J)
 // k - 2) are all past the barrier of call k - 1.  hm_any[0 .. 1] are zeroed at the start of the kernel.  (__syncthreads_or builds a
 // three-dimensional thread index for its own LDS slot: its y and z parts were hoisted out of the chunk loop and kept in scratch.)
 __shared__ int hm_any[3];
+__shared__ unsigned hm_tile_n, hm_tile_base;  // the bound form: candidates of the tile, and where its range of the list starts
 __device__ __forceinline__ bool wg_any(bool pred, int &k)
 {
     const int s = k % 3, n = (k + 1) % 3;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
     if (tid == 0) {
         hm_any[0] = 0;
         hm_any[1] = 0;
+        hm_tile_n = 0u;
     }
     int any_calls = 0;  // (wg_any: calls so far)
 
@@ -309,18 +311,26 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         for (int r = 0; r < 8; ++r)
 #pragma unroll
             for (int c = 0; c < 8; ++c) mn = min(mn, acc[r][c]);
-        if ((int)mn >= thresh) return;
         unsigned long long cand = 0ull;  // bit 8 r + c: pair (r, c) of this thread's micro-tile
+        if ((int)mn < thresh) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
-                const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
-                if ((int)acc[r][c] < thresh && gr < M && gc < M && (diag ? gr < gc : true)) cand |= 1ull << (8 * r + c);
-            }
-        if (cand == 0ull) return;
-        unsigned slot = atomicAdd(&sc->ham_ncand, (unsigned)__builtin_popcountll(cand));
+                for (int c = 0; c < 8; ++c) {
+                    const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));
+                    const int gr = I * GDCA_HTILE + ty * 8 + r, gc = J * GDCA_HTILE + lc;
+                    if ((int)acc[r][c] < thresh && gr < M && gc < M && (diag ? gr < gc : true)) cand |= 1ull << (8 * r + c);
+                }
+        }
+        if (!wg_any(cand != 0ull, any_calls)) return;  // (uniform)
+        // slots: a thread's offset inside the tile's range from a counter in LDS, ONE device-wide atomic per tile (per candidate-holding
+        // thread, a family of close relatives -- tens of thousands of neighbour pairs -- queued up on that one address)
+        const unsigned mine = (unsigned)__builtin_popcountll(cand);
+        const unsigned off = mine ? atomicAdd(&hm_tile_n, mine) : 0u;
+        __syncthreads();
+        if (tid == 0) hm_tile_base = atomicAdd(&sc->ham_ncand, hm_tile_n);
+        __syncthreads();
+        unsigned slot = hm_tile_base + off;
         while (cand) {
             const int e = __builtin_ctzll(cand), r = e >> 3, c = e & 7;
             const int lc = (c < 4) ? (tx * 4 + c) : (64 + tx * 4 + (c - 4));

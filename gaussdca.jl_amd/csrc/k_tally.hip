@@ -80,27 +80,65 @@ void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const u64 *Wfix, u64 *
 
 __global__ __launch_bounds__(256) void k_pi_finalize(const u64 *__restrict__ Pifix, int N, int q, int fix_shift,
                                                       const double *__restrict__ Meff_dev, double pc,
-                                                      double *__restrict__ Pi_true, double *__restrict__ Pi_pc)
+                                                      double *__restrict__ Pi_true, double *__restrict__ Pi_pc, double *__restrict__ pi_max)
 {
     const int s = q - 1;
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * s) return;
-    const int i = e / s, a = e % s;  // state a+1
-    const double Meff = *Meff_dev;
-    const double pt = ldexp((double)Pifix[(size_t)i * 32 + a + 1], -fix_shift) / Meff;
-    if (Pi_true) Pi_true[e] = pt;
-    if (Pi_pc) {
-        const double pcq = pc / (double)q;
-        Pi_pc[e] = (1.0 - pc) * pt + pcq;
+    double mine = 0.0;
+    if (e < N * s) {
+        const int i = e / s, a = e % s;  // state a+1
+        const double Meff = *Meff_dev;
+        const double pt = ldexp((double)Pifix[(size_t)i * 32 + a + 1], -fix_shift) / Meff;
+        if (Pi_true) Pi_true[e] = pt;
+        mine = (1.0 - pc) * pt + pc / (double)q;
+        if (Pi_pc) Pi_pc[e] = mine;
+    }
+    if (pi_max) {  // (uniform) the largest frequency with pseudocount: ||C||_1 <= 2 N pi_max, what k_cov_norm1 decides on
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine = fmax(mine, __shfl_xor(mine, o, 64));
+        // non-negative doubles order like their bit patterns (*pi_max was zeroed with the run's scalars)
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<u64 *>(pi_max), (u64)__double_as_longlong(mine));
     }
 }
 
+// ||C||_1 of the covariance the pair tally has just written (full symmetric, ld) -- but only where it is NEEDED: the refinement
+// screen of the fused path (gdca_api.hip, cond_bound) is  cond_2(C) <= ||C||_1 q^2 / pc,  and  ||C||_1 <= 2 N pi_max  is at hand for
+// nothing (a column of C sums, in absolute value, to at most  sum_j sum_b [Pij(jb, ia) + Pi(jb) Pi(ia)] <= 2 N Pi(ia)).  At the
+// pseudocounts gDCA is used with that cheap bound already settles the question and every workgroup leaves at once; where it does
+// not (pc = 0.2 with a conserved column; small pc), the columns are summed -- one pass over C before the sweep overwrites it.
+__global__ __launch_bounds__(256) void k_cov_norm1(const double *__restrict__ C, size_t ld, int n, int N, int q, double pc, double cond_limit,
+                                                    gdca_dev_scalars *__restrict__ sc, int always)
+{
+    const double cheap = pc > 0.0 ? 2.0 * (double)N * sc->pi_max * (double)q * (double)q / pc : HUGE_VAL;
+    if (!always && cheap <= cond_limit) return;
+    __shared__ double red[256];
+    double best = 0.0;
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        double a = 0.0;
+        for (int r = threadIdx.x; r < n; r += 256) a += fabs(C[(size_t)r + (size_t)c * ld]);
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        best = fmax(best, red[0]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<u64 *>(&sc->mat_norm1), (u64)__double_as_longlong(best));
+}
+
+void gdca_launch_cov_norm1(hipStream_t s, const double *C, size_t ld, int N, int q, double pc, double cond_limit, gdca_dev_scalars *sc, int always)
+{
+    hipLaunchKernelGGL(k_cov_norm1, dim3(512), dim3(256), 0, s, C, ld, N * (q - 1), N, q, pc, cond_limit, sc, always);
+}
+
 void gdca_launch_pi_finalize(hipStream_t s, const u64 *Pifix, int N, int q, int fix_shift, const double *Meff_dev,
-                             double pc, double *Pi_true, double *Pi_pc)
+                             double pc, double *Pi_true, double *Pi_pc, double *pi_max)
 {
     const int n = N * (q - 1);
     hipLaunchKernelGGL(k_pi_finalize, dim3((n + 255) / 256), dim3(256), 0, s, Pifix, N, q, fix_shift, Meff_dev, pc,
-                       Pi_true, Pi_pc);
+                       Pi_true, Pi_pc, pi_max);
 }
 
 // ---- pair tallies -----------------------------------------------------------------------------------
@@ -155,7 +193,7 @@ template <int TJ>
 __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
     const int8_t *__restrict__ Zc, const int8_t *__restrict__ Zt, const u64 *__restrict__ Wfix, int N, int M,
     int q, int fix_shift, const double *__restrict__ Meff_dev, double pc, const double *__restrict__ Pi_pc, int mode,
-    double *__restrict__ out, size_t ld, u64 *__restrict__ colabs_fix)
+    double *__restrict__ out, size_t ld)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = q - 1;
@@ -248,49 +286,24 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
             pi_j[e] = (jj < N) ? Pi_pc[jj * s + (e % s)] : 0.0;
         }
     }
-    // ||C||_1 on the way (colabs_fix != nullptr): the column sums of |C| in 2^-46 fixed point -- integer sums: exact and independent
-    // of the order of the atomics, like the tallies themselves -- of this workgroup's elements, first in LDS: [s] for the columns
-    // (i, a), [TJ s] for the mirror columns (j, b).  The decision on a refinement of the inverse needs cond(C) (gdca_run_collect).
-    u64 *colacc = reinterpret_cast<u64 *>(zs);
-    if (colabs_fix)
-        for (int e = tid; e < s + TJ * s; e += TALLY_THREADS) colacc[e] = 0ull;
     __syncthreads();
     const double Meff = *Meff_dev;
     const double pcq = pc / (double)q;
     const double off_add = pcq / (double)q;
     const int total = s * s * TJ;
     // pass 1: element (row j*s+b, col i*s+a): contiguous over (j, b) for fixed a
-    for (int e0 = 0; e0 < total; e0 += TALLY_THREADS) {
-        const int e = e0 + tid;
+    for (int e = tid; e < total; e += TALLY_THREADS) {
         const int a = e / (TJ * s), rem = e - a * (TJ * s);
         const int l = rem / s, b = rem - l * s;
         const int jj = j0 + l;
-        const bool live = e < total && jj < N && jj >= i;
-        double v = 0.0;
-        if (live) {
-            const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
-            v = pt;
-            if (mode == 1) {
-                const double pij = (jj != i) ? ((1.0 - pc) * pt + off_add) : ((1.0 - pc) * pt + ((a == b) ? pcq : 0.0));
-                v = pij - pi_i[a] * pi_j[rem];
-            }
-            out[(size_t)(jj * s + b) + (size_t)(i * s + a) * ld] = v;
+        if (jj >= N || jj < i) continue;
+        const double pt = ldexp((double)hist[(size_t)a * RS + (b + 1) * TJ + l], -fix_shift) / Meff;
+        double v = pt;
+        if (mode == 1) {
+            const double pij = (jj != i) ? ((1.0 - pc) * pt + off_add) : ((1.0 - pc) * pt + ((a == b) ? pcq : 0.0));
+            v = pij - pi_i[a] * pi_j[rem];
         }
-        if (colabs_fix) {  // (uniform)
-            const u64 fx = live ? (u64)(fabs(v) * 0x1p46) : 0ull;
-            // column (i, a): with s = 20 and 16 or 32 columns per block a wave's 64 elements share one a -- one butterfly, one atomic;
-            // otherwise lane by lane
-            const int a0 = __builtin_amdgcn_readfirstlane(a);
-            if (__all(a == a0)) {
-                u64 t = fx;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                if (lane == 0 && t != 0ull && a0 < s) atomicAdd(&colacc[a0], t);
-            } else if (live)
-                atomicAdd(&colacc[a], fx);
-            // the mirror element lies in column (jj, b) (a diagonal block is written in full by this pass: no mirror)
-            if (live && jj > i) atomicAdd(&colacc[s + rem], fx);
-        }
+        out[(size_t)(jj * s + b) + (size_t)(i * s + a) * ld] = v;
     }
     // pass 2: the mirror element (row i*s+a, col j*s+b): contiguous over a for fixed (j, b)
     for (int e = tid; e < total; e += TALLY_THREADS) {
@@ -306,30 +319,6 @@ __global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
         }
         out[(size_t)(i * s + a) + (size_t)(jj * s + b) * ld] = v;
     }
-    if (colabs_fix) {
-        __syncthreads();
-        for (int e = tid; e < s + TJ * s; e += TALLY_THREADS) {
-            const u64 t = colacc[e];
-            if (t == 0ull) continue;
-            const int col = e < s ? i * s + e : (j0 + (e - s) / s) * s + (e - s) % s;
-            atomicAdd(&colabs_fix[col], t);
-        }
-    }
-}
-
-// *out = max_c colabs_fix[c] 2^-46 = ||C||_1 of the matrix k_pair_tally has just written
-__global__ __launch_bounds__(256) void k_colabs_fix_max(const u64 *__restrict__ colabs_fix, int n, double *__restrict__ out)
-{
-    __shared__ u64 red[256];
-    u64 a = 0ull;
-    for (int k = threadIdx.x; k < n; k += 256) a = max(a, colabs_fix[k]);
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + w]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *out = (double)red[0] * 0x1p-46;
 }
 
 static size_t tally_lds_bytes(int s, int TJ)
@@ -348,21 +337,18 @@ int gdca_tally_tj(int q, int tj_wanted)
 
 void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q,
                             int fix_shift, const double *Meff_dev, double pc, const double *Pi_pc, int mode,
-                            double *out, size_t ld, int TJ, unsigned long long *colabs_fix, double *norm1_out)
+                            double *out, size_t ld, int TJ)
 {
     const int s = q - 1;
-    if (mode != 1) colabs_fix = nullptr;
-    if (colabs_fix) (void)hipMemsetAsync(colabs_fix, 0, (size_t)N * s * sizeof(u64), st);
     if (TJ == 32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld, colabs_fix);
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(k_pair_tally<16>, dim3((N + 15) / 16, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 16), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld, colabs_fix);
+                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
     }
-    if (colabs_fix && norm1_out) hipLaunchKernelGGL(k_colabs_fix_max, dim3(1), dim3(256), 0, st, colabs_fix, N * s, norm1_out);
 }

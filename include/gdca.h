@@ -103,13 +103,15 @@ typedef struct gdca_stats {
     double inverse_norm1;       /* ||inv(C)||_1 as the sweep left it, measured (one pass over the inverse) only where cond_bound is
                                    beyond REFINE_COND: the decision on a refinement is kappa_1 = matrix_norm1 * inverse_norm1 >
                                    REFINE_COND.  0: not measured (the bound settled it, or option REFINE=0) */
-    double matrix_norm1;        /* ||C||_1 of the covariance (src/GaussDCA.jl:32), from the epilogue of its build: 64 .. 94 on the
-                                   reference's test/data/large.fasta.gz, not "of order one"; 0 with option REFINE=0 */
-    double cond_bound;          /* a-priori bound of cond_2(C): matrix_norm1 * q^2 / pseudocount.  The covariance with pseudocount pc is
-                                   that of a mixture with weight pc on independent uniform columns, hence lambda_min(C) >= pc / q^2
-                                   (sharp whenever some column has no gap).  Every run whose bound is below REFINE_COND is
-                                   KNOWN to be well enough conditioned for the sweep and pays nothing for the screen; +inf at
-                                   pseudocount 0; 0 with option REFINE=0 */
+    double matrix_norm1;        /* ||C||_1 of the covariance (src/GaussDCA.jl:32), measured (one pass over C before the sweep overwrites
+                                   it) only where the bound that costs nothing, ||C||_1 <= 2 N max_i Pi(i), leaves cond_bound beyond
+                                   REFINE_COND: 64 .. 94 on the reference's test/data/large.fasta.gz, not "of order one".  0: not
+                                   measured (the cheap bound settled it, or option REFINE=0) */
+    double cond_bound;          /* a-priori bound of cond_2(C): ||C||_1 q^2 / pseudocount, with matrix_norm1 where it was measured
+                                   and 2 N max Pi otherwise.  The covariance with pseudocount pc is that of a mixture with weight pc
+                                   on independent uniform columns, hence lambda_min(C) >= pc / q^2 (sharp whenever some column has
+                                   no gap).  Every run whose bound is below REFINE_COND is KNOWN to be well enough conditioned
+                                   for the sweep and pays nothing for the screen; +inf at pseudocount 0; 0 with option REFINE=0 */
     /* (fields are only ever added at the end: a caller built against an older header reads a valid prefix) */
     double ms_fn;               /* the FN kernel alone (HBM-bound: one pass over the lower block triangle of the inverse,
                                    8 n (n - s) / 2 bytes); 0 for the DI score and for a run refined at collect time */
@@ -143,7 +145,8 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
  * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
- * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS; REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
+ * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS, PHASED_FRONTS (1: the front ends of a phase batch run side by side on the
+ * members' own streams, 0: one after the other); REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
  * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6); CHOLESKY (0 | 1 | 2: the blocked
  * dpotrf + dpotri fallback never / where the sweep gave up [default] / for every inverse).  The schedule switches change results
  * at rounding level at most (another summation order); REFINE improves an ill-conditioned inverse.  GDCA_EINVAL: unknown key

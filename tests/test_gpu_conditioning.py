@@ -154,7 +154,8 @@ def test_scores_at_small_pseudocounts_match_oracle(env, name, pc, score):
           % (name, pc, score, st["matrix_norm1"], st["cond_bound"], st["inverse_norm1"], kappa1, st["refined"], 1e-6 * slack))
     if (name, pc) not in _NORM1:
         _NORM1[(name, pc)] = float(np.abs(_covariance(o, Zo, q, pc)).sum(axis=0).max())
-    assert abs(st["matrix_norm1"] - _NORM1[(name, pc)]) <= 1e-9 * st["matrix_norm1"]      # ||C||_1 from the tally's epilogue
+    # (at these pseudocounts the bound that costs nothing, 2 N pi_max q^2 / pc, is beyond the threshold: ||C||_1 itself was measured)
+    assert st["matrix_norm1"] > 0.0 and abs(st["matrix_norm1"] - _NORM1[(name, pc)]) <= 1e-9 * st["matrix_norm1"]
     assert st["cond_bound"] == pytest.approx(st["matrix_norm1"] * q * q / pc, rel=1e-12)  # (that it IS a bound: tests/test_oracle_golden.py)
     # ||X||_1 is measured exactly where the bound leaves the question open, and the decision is kappa_1's
     assert (st["inverse_norm1"] > 0.0) == (st["cond_bound"] > 1e6)
@@ -163,6 +164,24 @@ def test_scores_at_small_pseudocounts_match_oracle(env, name, pc, score):
         assert (st["refined"] == 1) == (pc <= 0.02)       # ||C||_1 = 64 .. 94: bound 7.5e5 at pc 0.05, kappa_1 5.9e6 at 0.02
     ok, max_rel, max_abs = score_close(S, S_o, rtol=1e-6 * slack, atol_frac=1e-9 * slack, atol_abs=atol_abs)
     assert ok, (name, pc, score, max_rel, max_abs, slack)
+
+
+def test_ordinary_pseudocounts_pay_nothing_for_the_screen(env):
+    """At the pseudocounts gDCA is used with the bound that costs nothing (||C||_1 <= 2 N max Pi) already proves cond(C) below the
+    threshold: no norm is measured (both stay 0 in the stats), nothing is refined -- and the bound IS a bound of the true cond_2(C)."""
+    g, o, ctx = env
+    from gdca_testutil import random_msa
+
+    Zo = random_msa(np.random.default_rng(12), 500, 60)
+    for pc in (0.8, 0.5):
+        S, st = ctx.run(np.asfortranarray(Zo.T), 21, pc, -1.0, 0)
+        assert st["refined"] == 0 and st["matrix_norm1"] == 0.0 and st["inverse_norm1"] == 0.0
+        C = _covariance(o, Zo, 21, pc)
+        lam = np.linalg.eigvalsh(C)
+        print("\npc=%g: cond_2(C) = %.3e <= bound %.3e (||C||_1 = %.2f <= 2 N max Pi = %.2f)"
+              % (pc, lam[-1] / lam[0], st["cond_bound"], np.abs(C).sum(axis=0).max(), st["cond_bound"] * pc / 441.0))
+        assert lam[-1] / lam[0] <= st["cond_bound"] <= 1e6
+        assert np.abs(C).sum(axis=0).max() <= st["cond_bound"] * pc / 441.0 * (1 + 1e-12)
 
 
 def test_a_refinement_that_cannot_converge_is_reported(env):
