@@ -1072,6 +1072,14 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
     if (side_by_side)
         for (int k = 0; k < K; ++k) ctxs[k]->stream = lead->stream;
     if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
+    if (st == GDCA_OK && side_by_side) {
+        // ... and the score stages side by side again, each behind the batch's inverses on its member's own stream
+        if (hipEventRecord(lead->ev_upload, lead->stream) != hipSuccess) st = fail(lead, GDCA_EHIP, "event chain of the batch's score stages%s%s", "", "");
+        for (int k = 1; k < K && st == GDCA_OK; ++k) {
+            if (hipStreamWaitEvent(own[k], lead->ev_upload, 0) != hipSuccess) st = fail(lead, GDCA_EHIP, "event chain of the batch's score stages%s%s", "", "");
+            ctxs[k]->stream = own[k];
+        }
+    }
     for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
     if (st != GDCA_OK) {
         // a member failed to enqueue (allocation, launch): drain what was enqueued -- the batch's stream AND every member's side

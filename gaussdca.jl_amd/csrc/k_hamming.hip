@@ -165,13 +165,26 @@ __global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict
             l = pr.y;
             const int8_t *zk = Z + (size_t)k * N, *zl = Z + (size_t)l * N;
             if ((N & 3) == 0) {
+                // a lane's dwords of both sequences, 1024 bytes of each per round, ALL requested before the first is looked at: the pairs
+                // of a list are scattered over the alignment, and a round costs one trip to memory instead of sixteen dependent ones
                 const uint32_t *a = reinterpret_cast<const uint32_t *>(zk), *b = reinterpret_cast<const uint32_t *>(zl);
-                for (int w = sub; w < (N >> 2); w += 16) {
-                    uint32_t x = a[w] ^ b[w];  // bytes that differ -> one bit each
-                    x |= x >> 4;
-                    x |= x >> 2;
-                    x |= x >> 1;
-                    d += __builtin_popcount(x & 0x01010101u);
+                const int nw = N >> 2;
+                for (int w0 = 0; w0 < nw; w0 += 256) {
+                    uint32_t xa[16], xb[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int w = w0 + 16 * u + sub;
+                        xa[u] = w < nw ? a[w] : 0u;
+                        xb[u] = w < nw ? b[w] : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        uint32_t x = xa[u] ^ xb[u];  // bytes that differ -> one bit each
+                        x |= x >> 4;
+                        x |= x >> 2;
+                        x |= x >> 1;
+                        d += __builtin_popcount(x & 0x01010101u);
+                    }
                 }
             } else {
                 for (int i = sub; i < N; i += 16) d += zk[i] != zl[i];
@@ -417,7 +430,7 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int
     const int form = decided ? (force < 0 ? 0 : force) : -1;
     if (form != 0) {
         hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
-        hipLaunchKernelGGL(k_hamming_refine, dim3(1024), dim3(256), 0, s, Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc);
+        hipLaunchKernelGGL(k_hamming_refine, dim3(2048), dim3(256), 0, s, Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc);
     }
     hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
 }

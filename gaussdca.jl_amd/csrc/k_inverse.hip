@@ -854,6 +854,7 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
             const int idx = tid + 256 * u;  // r = idx & 127, c = idx >> 7
             v[u] = H[(size_t)(idx & 127) + (size_t)(idx >> 7) * pld];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (all 64 loads in flight before the first store: left to itself hipcc interleaves them)
 #pragma unroll
         for (int u = 0; u < 64; ++u) {
             const int idx = tid + 256 * u;
@@ -862,12 +863,31 @@ __device__ __forceinline__ void panel_writeback_tile(double *__restrict__ A, siz
     } else {
         double *dst = A + (size_t)kblk * T + (size_t)i * T * ld;  // dst(c, r) = -H(r, c)
         // 16 columns of H at a time through LDS: Ts[c][r], then rows of dst are read across c
+        // (the next 16 columns are requested before this round's barrier and stores: as one load / one LDS store per loop trip the
+        // function form of this item waited out 64 round trips one after the other: 44 us an item instead of 26)
+        double nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 256 * u;  // r = idx & 127, c = idx >> 7 (0..15)
+            nx[u] = H[(size_t)(idx & 127) + (size_t)(idx >> 7) * pld];
+        }
         for (int cb = 0; cb < T; cb += KC) {
+            double cur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nx[u];
+            if (cb + KC < T) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = tid + 256 * u;
+                    nx[u] = H[(size_t)(idx & 127) + (size_t)(cb + KC + (idx >> 7)) * pld];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = tid + 256 * u;  // r = idx & 127, c = idx >> 7 (0..15)
-                Ts[idx >> 7][idx & 127] = -H[(size_t)(idx & 127) + (size_t)(cb + (idx >> 7)) * pld];
+                const int idx = tid + 256 * u;
+                Ts[idx >> 7][idx & 127] = -cur[u];
             }
             __syncthreads();
 #pragma unroll
@@ -953,16 +973,33 @@ struct SweepDesc {
 // handed to them as generic pointers: the staging buffers of the tile paths -- ONE array: the pivot's images (pivot_chain) span
 // both staging buffers off one base -- and the few words a workgroup's threads share about its current and next item
 __shared__ __attribute__((aligned(16))) double sw_lds[4][KC][LDS_LD];
-__shared__ int sw_item, sw_next, sw_ready, sw_fam, sw_live, sw_fnext, sw_pnext;
-__shared__ unsigned long long sw_probe[2];  // the workgroup's start: shader clock, wall clock (the launch's clock measurement)
-__shared__ unsigned long long sw_stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
+// (ONE object: its members are immediate offsets off one address.  As separate variables each had an address register of its own,
+// hoisted out of the persistent loop and parked in scratch across the items)
+struct SweepShared {
+    unsigned long long kbase;     // address of the kernel-argument segment (launch_desc)
+    unsigned long long probe[2];  // the workgroup's start: shader clock, wall clock (the launch's clock measurement)
+    unsigned long long stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
+    int item, next, ready, fam, live, fnext, pnext;
+    int p[8];                     // merged launch: per family, the group this workgroup's last item belonged to
+};
+__shared__ SweepShared sw;
+#define sw_item sw.item
+#define sw_next sw.next
+#define sw_ready sw.ready
+#define sw_fam sw.fam
+#define sw_live sw.live
+#define sw_fnext sw.fnext
+#define sw_pnext sw.pnext
+#define sw_probe sw.probe
+#define sw_stamp sw.stamp
+#define sw_kbase sw.kbase
+#define sw_p sw.p
 
 // The descriptor of family f of the running launch, read where it lies: in the kernel-argument segment (constant address space:
 // scalar loads).  k_sweep's argument is one SweepDesc (f = 0), k_sweep_merged's a SweepBatch, whose first member is fam[].
 // launch_desc_k: inside the kernels themselves.  launch_desc: anywhere -- the out-of-line item functions take the family's index,
 // not a reference to its descriptor, and `llvm.amdgcn.kernarg.segment.ptr` is NULL outside a kernel: the kernels leave the
 // segment's address in LDS (sw_kbase, thread 0, before their first barrier).
-__shared__ unsigned long long sw_kbase;
 typedef const SweepDesc __attribute__((address_space(4))) *kernarg_desc_t;
 
 __device__ __forceinline__ const SweepDesc &launch_desc_k(int f)
@@ -2191,7 +2228,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     }
     for (;;) {
         __syncthreads();
-        const int item = sw_next, rdy = sw_ready;
+        const int item = UNI(sw_next), rdy = UNI(sw_ready);  // (scalar: as vector registers they were live -- spilled -- across the item)
         __syncthreads();  // everybody has read them
         if (item >= D.total || *abort_lds()) break;
         int nxt = 0;
@@ -2270,7 +2307,7 @@ struct SweepBatch {
     int K;
 };
 static_assert(offsetof(SweepBatch, fam) == 0, "launch_desc(f) finds member f at the start of the kernel-argument segment");
-__shared__ int sw_p[SWEEP_MAX_MERGE];
+static_assert(SWEEP_MAX_MERGE <= 8, "SweepShared::p");
 
 template <bool MULTI>
 __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
@@ -2311,7 +2348,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
     }
     for (;;) {
         __syncthreads();
-        const int item = sw_next, rdy = sw_ready;
+        const int item = UNI(sw_next), rdy = UNI(sw_ready);
         const int f = __builtin_amdgcn_readfirstlane(sw_fam);
         __syncthreads();  // everybody has read them
         if (f < 0 || *abort_lds()) break;

@@ -47,3 +47,33 @@ def test_front_end_and_score_kernels_do_not_spill(src, tmp_path):
         seen.append((name, vgprs, spills, scratch, occ))
         assert spills <= max_spill and scratch <= max_scratch, (name, "VGPRs", vgprs, "spilled", spills, "scratch B/lane", scratch)
     print("\n".join("%-70s VGPRs %3d spilled %3d scratch %3d B occupancy %d" % s for s in seen))
+
+
+def test_sweep_kernels_keep_scratch_out_of_every_block_that_holds_an_mfma(tmp_path):
+    """The four persistent sweep kernels (round 4: 144 scratch instructions in `k_sweep<true>`, 105 of them inside blocks of 32 MFMAs
+    and more -- and a wrong-result incident that moved with the spill placement): since round 5 the cold item kinds are
+    functions of their own and what is left in a kernel is the save of ONE register (the one holding spilled SGPRs) around the
+    once-per-workgroup call of the chain worker.  Per basic block of the compiler's assembly: no scratch instruction in any block that
+    holds an MFMA, at most eight in the whole kernel (saves around the calls of the out-of-line items)."""
+    if not os.path.exists(HIPCC) or shutil.which("c++filt") is None:
+        pytest.skip("no hipcc")
+    asm = tmp_path / "k_inverse.s"
+    r = subprocess.run([HIPCC, *FLAGS, "--cuda-device-only", "-S", os.path.join(CSRC, "k_inverse.hip"), "-o", str(asm)], capture_output=True,
+                       text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = asm.read_text()
+    funcs = re.split(r"\n(?=_Z[A-Za-z0-9_]+:)", text)
+    seen = 0
+    for f in funcs:
+        m = re.match(r"(_Z\d+k_sweep(?:_merged)?ILb[01]EE[A-Za-z0-9_]*):", f)
+        if not m or not re.search(r"^\s+s_endpgm", f, re.M):
+            continue
+        seen += 1
+        body = f.split(".Lfunc_end")[0]
+        blocks = re.split(r"\n\.LBB[0-9_]+:", body)
+        total = len(re.findall(r"\bscratch_(?:load|store)", body))
+        hot = sum(len(re.findall(r"\bscratch_(?:load|store)", b)) for b in blocks if re.search(r"\bv_mfma_", b))
+        print("%-50s %4d basic blocks, %4d MFMAs, scratch instructions %d (in MFMA blocks: %d)"
+              % (m.group(1), len(blocks), len(re.findall(r"\bv_mfma_", body)), total, hot))
+        assert hot == 0 and total <= 8, (m.group(1), total, hot)
+    assert seen == 4, seen
