@@ -130,8 +130,9 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
  * execute their SPD-inverse stages one after the other (device-side event chain), so that with
  * gdca_run_dev_async the reweighting/tally stages of the next family overlap the inverse of the current
  * one.  All members of a pipeline are driven by one host thread.  Contexts that run on one GPU at the same time SHOULD be such
- * peers: the SPD inverse is a persistent kernel, and two of its launches that become resident side by side can wait for each
- * other's workgroups until the watchdog ends one with GDCA_EHIP. */
+ * peers: the SPD inverse is a persistent kernel.  Launches of one family each that share the device without a gate take turns for
+ * the compute units and both finish (tested: two non-peer contexts, two processes); a MERGED launch (gdca_run_dev_phased) beside
+ * another sweep can be kept from its main lists until the watchdog ends it with GDCA_EHIP ("Sharing a device"). */
 gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out);
 gdca_status gdca_ctx_destroy(gdca_ctx *ctx);
 gdca_status gdca_ctx_synchronize(gdca_ctx *ctx);

@@ -893,3 +893,19 @@ def test_inverse_on_a_cu_masked_stream_without_xcc0(n):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["enabled_cus"] == 208 and out["rel"] <= 1e-10 and out["rel_merged"] <= 1e-10, out
+
+
+def test_two_ungated_sweeps_side_by_side():
+    """two sweep launches that nothing orders against each other -- two contexts that are NOT peers, each driven by a
+    thread of its own, and then two processes -- on one GPU, n = 9100 (72 pivot blocks, groups of four): the persistent kernels share
+    the compute units, both finish, and every inverse is LAPACK's (tools/side_by_side_probe.py; a dependency wait that ran out of
+    time would surface as GDCA_EHIP and a non-zero exit)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "side_by_side_probe.py"), "9100", "2"], capture_output=True, text=True,
+                       env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="6000"), timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "two processes: exit codes [0, 0]" in r.stdout
