@@ -587,7 +587,7 @@ static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int sc
     } else {
         const bool tm = time_fn && ctx->n_ev >= 18;  // (a timed fused run: gdca_stats.ms_fn)
         if (tm) HIPCHK(hipEventRecord(ctx->ev[7], s));
-        gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev);
+        gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev, ctx->ncu);
         if (tm) HIPCHK(hipEventRecord(ctx->ev[8], s));
         if (time_fn) ctx->pend_fn_timed = tm;
     }

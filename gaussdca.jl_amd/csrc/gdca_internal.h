@@ -24,7 +24,6 @@ struct gdca_dev_scalars {
     unsigned ham_ncand;  // pairs the bound form has put (or tried to put) into its candidate list: beyond the list's capacity the exact form counts
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
-    double inv_diagmax;  // max_i |inverse(i, i)|: the screen that decides whether ||inverse||_1 is worth a pass
     double ns_resid;     // max |I - X0 C| seen by the Newton-Schulz step (0: no step)
     double mat_norm1;  // ||C||_1: measured on the covariance before the sweep where the cheap bound leaves the question open (fused path), or on the
                        // caller's matrix (operator-level inverse); 0: not measured
@@ -178,7 +177,6 @@ void gdca_launch_cholesky_inverse(hipStream_t s, double *C2, double *U, double *
 // colsum_ws: n_pad doubles
 void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out);
 // *out = max_i |A(i, i)|, i < n
-void gdca_launch_inverse_diagmax(hipStream_t s, const double *A, int n_pad, int n, double *out);
 // *out = ||C||_1 of a plain n x n matrix
 void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out);
 // one Newton-Schulz step on the sweep's result: A (-X0 lower block triangle -> -X1), C2 = the matrix that was inverted (full
@@ -188,7 +186,7 @@ void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, doubl
 
 // ---- k_score.hip ---------------------------------------------------------------------------
 // S (N x N) from the lower triangle of A = -mJ (ld).  Diagonal 0.
-void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S);
+void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S, int ncu = 0);
 // Ld[i] = chol(D[i]) lower, packed s x s
 void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, double *Ld);
 // Tws: workspace of gdca_di_ws_bytes(N, sdim) bytes (tridiagonals of all site pairs)

@@ -947,6 +947,7 @@ struct SweepDesc {
     double *Pw;            // 128 x 128: inverse of the current pivot block
     unsigned *gen, *rb, *mc, *done, *next, *next_m, *mcu;
     unsigned *mxcc;        // XCC the chain's compute units are elected on (0 = not chosen yet, else id + 1): the first workgroup to arrive decides
+    unsigned *arrived;     // workgroups of the launch that have shown up so far (the first member's counter serves a merged launch)
     unsigned *abort;       // set by a workgroup whose dependency wait ran out of time: everybody leaves (watchdog)
     unsigned long long timeout_ticks;  // bound of a single dependency wait, 100 MHz ticks
     int debug;             // GDCA_SWEEP_DEBUG bits (tests): 1 = workgroups on XCC 0 stay out of the election; 2 = nobody is elected
@@ -2171,8 +2172,19 @@ __device__ __forceinline__ int sweep_elect(int K)
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     xcc &= 15u;
     const unsigned key = 1u + (((hw >> 8) & 0xFFu));  // cu_id, sh_id, se_id
+    const unsigned first = xcc;
+    if (K > 1) {
+        // A merged launch that shares the device with another persistent launch may have a few dozen workgroups resident for a long
+        // time -- fewer than its members' chains have seats (up to 64).  Left to the first-come rule alone they ALL became chain
+        // workers, nobody served the main lists the chains wait for, and the launch stood still until the watchdog ended it (seen in
+        // round 4's batch driver).  The FIRST workgroup of the launch to show up therefore stays a main-list worker: with it the
+        // lists move, however slowly, until the rest of the grid gets its compute units.  (Every fourth of the first 32 arrivals, tried
+        // first, cost the merged launch of config B 10 %: chain workers then share compute units with tile items.)
+        const unsigned a = __hip_atomic_fetch_add(launch_desc_k(0).arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a == 0u) return -1;
+    }
     for (int t = 0; t < K; ++t) {
-        const int f = (int)((xcc + (unsigned)t) % (unsigned)K);
+        const int f = (int)((first + (unsigned)t) % (unsigned)K);
         const SweepDesc &Df = launch_desc_k(f);
         // the XCD of a chain is whichever one the first workgroup to get there runs on (not a fixed id: under a CU mask, in a
         // partitioned mode or beside another tenant no workgroup of the launch may ever run on XCC 0)
@@ -2551,6 +2563,7 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     D.next_m = f + 1;
     D.mcu = f + 2;
     D.mxcc = f + 18;
+    D.arrived = f + 19;
     D.abort = f + 64;
     // bound of one dependency wait (GDCA_SWEEP_TIMEOUT_MS; a healthy wait is microseconds).  By default it grows with the work the
     // launch holds: the early workgroups of a launch that starts behind another one (two contexts in flight on one GPU, another
@@ -2785,28 +2798,6 @@ __global__ __launch_bounds__(256) void k_vec_max(const double *__restrict__ v, i
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = red[0];
-}
-
-// *out = max(*out, max_i |A(i, i)|), i < n: for the SPD inverse a lower bound of every norm of it, read off n entries -- the screen that runs
-// after every inverse (the full ||X||_1 costs a pass over the lower triangle: 0.11 ms at n = 10 000, half a percent of a family)
-__global__ __launch_bounds__(256) void k_diag_absmax(const double *__restrict__ A, size_t ld, int n, double *__restrict__ out)
-{
-    __shared__ double red[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    red[threadIdx.x] = i < n ? fabs(A[(size_t)i + (size_t)i * ld]) : 0.0;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
-        __syncthreads();
-    }
-    // non-negative doubles order like their bit patterns: one integer atomic per workgroup (*out was zeroed with the scalars)
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(red[0]));
-}
-
-void gdca_launch_inverse_diagmax(hipStream_t s, const double *A, int n_pad, int n, double *out)
-{
-    // (*out lives in the run's scalar block, which every run zeroes when it begins)
-    hipLaunchKernelGGL(k_diag_absmax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, (size_t)n_pad, n, out);
 }
 
 void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n, double *colsum_ws, double *out)

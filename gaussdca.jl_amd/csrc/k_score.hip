@@ -133,7 +133,155 @@ __global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t
     }
 }
 
-void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S)
+// ---- FN, s = 20 (the q = 21 alphabet): a persistent form, three pairs per wave --------------------------------------------------
+// `k_fn` above gets 0.44 of the HBM peak: half of its 62 000 workgroups leave at once (dispatch of the empty half of
+// the triangle is a third of its time), a workgroup's loads and its scoring do not overlap, and one wave per pair spends ~220
+// instructions on a 20 x 20 block with most lanes idle in the means.  Here FN20_WG workgroups per compute unit walk a LIST of items
+// -- (column site i, FN20_PG consecutive row sites below it): one contiguous run of FN20_PG 160 B per column -- a stride apart; the
+// NEXT item's twenty runs are requested (16-byte loads into registers) before the current one is scored from LDS, and a wave scores
+// THREE pairs at a time: lanes 20 g .. 20 g + 19 own pair g, lane l of the group holds ROW l of the block in registers (one LDS read
+// per element), sums it, sums column l from LDS, and the Frobenius norm of the centred block is row-wise partial sums added in row
+// order.  ~70 instructions per pair.  Same formula as rule 9 of the survey (src/GaussDCA.jl:39), another order of summation than
+// `k_fn`: scores agree to rounding (<= 1e-15 relative).
+#ifndef FN20_PG
+#define FN20_PG 6          // row sites per item (per column a run of FN20_PG 160 B)
+#define FN20_THREADS 128   // threads per workgroup: 3 pairs per wave and round, FN20_PG = 3 FN20_THREADS / 64
+#define FN20_WG 6          // workgroups per compute unit: what 142 registers and 22 KB of LDS let run at once
+#endif
+#define FN20_LP (FN20_PG * 20 + 2)
+#define FN20_MAXU 10       // 16-byte loads per thread that hold an item: 20 columns x (10 FN20_PG) double2 / FN20_THREADS, rounded up
+static_assert(20 * 10 * FN20_PG <= FN20_MAXU * FN20_THREADS, "ten units per thread hold an item");
+
+// items of the column sites before site i: sum_{m = 1..i} [(N - 1) / PG - m / PG + 1], in closed form
+__host__ __device__ __forceinline__ int fn20_first(int i, int N)
+{
+    const int C = (N - 1) / FN20_PG, q = i / FN20_PG, r = i - q * FN20_PG;
+    return i * (C + 1) - (FN20_PG * (q * (q - 1) / 2) + q * (r + 1));
+}
+
+// item t of the list: column site i, row chunk J (rows J PG .. J PG + PG - 1, from i + 1 on); items of one column site are
+// consecutive, so the streams in flight at any moment are few and long
+__device__ __forceinline__ void fn20_item(int t, int N, int &i, int &J)
+{
+    int lo = 0, hi = N - 1;   // fn20_first(lo) <= t < fn20_first(hi)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (fn20_first(mid, N) <= t) lo = mid; else hi = mid;
+    }
+    i = lo;
+    J = (i + 1) / FN20_PG + (t - fn20_first(i, N));
+}
+
+// One 16-byte unit of an item in flight: where it goes in the LDS image, and the data.  Ten NAMED units per thread (FN20_UNITS):
+// as arrays `v[u]`, `off[u]` written at the bottom of the persistent loop and read at its top they stayed in scratch (176 B per lane).
+struct Fn20Unit {
+    double2 v;
+    int off;
+};
+#define FN20_UNITS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+
+__device__ __forceinline__ void fn20_unit_load(Fn20Unit &q, int u, int tid, int n_units, int L2, const double *__restrict__ src, size_t ld)
+{
+    const int e = min(tid + FN20_THREADS * u, n_units - 1);  // (past the end: the last unit once more, loaded and not stored)
+    const int c = e / L2, r2 = e - c * L2;
+    q.off = c * FN20_LP + 2 * r2;
+    q.v = *reinterpret_cast<const double2 *>(src + (size_t)c * ld + 2 * r2);
+}
+
+__global__ __launch_bounds__(FN20_THREADS) void k_fn20(const double *__restrict__ A, size_t ld, int N, int total, double *__restrict__ S)
+{
+    constexpr int s = 20, Lp = FN20_LP;
+    static_assert(FN20_MAXU == 10, "FN20_UNITS lists ten units");
+    __shared__ __attribute__((aligned(16))) double img[s * Lp];   // img[c * Lp + (row of the run)]
+    __shared__ double red[FN20_THREADS / 64][3][3][s];             // per wave and pair: row means, column means, partial norms
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane / s, l = lane - g * s;                      // pair of the wave's three, row / column inside it (lanes 60..63: none)
+#define FN20_DECL(u) Fn20Unit q##u;
+    FN20_UNITS(FN20_DECL)
+    int n_units = 0, i = 0, j_lo = 0, j_hi = 0;
+    // the loads of item T (uniform): the ten units, n_units; and its (i, j_lo, j_hi)
+#define FN20_LOAD(u) fn20_unit_load(q##u, u, tid, n_units, L2_, src_, ld);
+#define FN20_REQUEST(T)                                                       \
+    do {                                                                      \
+        int J_;                                                               \
+        fn20_item((T), N, i, J_);                                             \
+        j_lo = max(J_ * FN20_PG, i + 1);                                      \
+        j_hi = min(N, J_ * FN20_PG + FN20_PG);                                \
+        const int L2_ = (j_hi - j_lo) * (s / 2);                              \
+        n_units = s * L2_;                                                    \
+        const double *src_ = A + (size_t)j_lo * s + (size_t)i * s * ld;       \
+        FN20_UNITS(FN20_LOAD)                                                 \
+    } while (0)
+#define FN20_STORE(u) \
+    if (tid + FN20_THREADS * u < n_units) *reinterpret_cast<double2 *>(img + q##u.off) = q##u.v;
+    int t = blockIdx.x;
+    if (t >= total) return;
+    FN20_REQUEST(t);
+    for (;;) {
+        // the requested item goes to LDS (everybody is done with the image of the item before)
+        FN20_UNITS(FN20_STORE)
+        const int ci = i, cj_lo = j_lo, npair = j_hi - j_lo;
+        __syncthreads();
+        const int tn = t + (int)gridDim.x;
+        if (tn < total) FN20_REQUEST(tn);   // in flight while this item is scored
+        for (int p0 = 3 * wv; p0 < npair; p0 += 3 * (FN20_THREADS / 64)) {      // (wave-uniform trip count)
+            const int tp = p0 + g;
+            const bool live = g < 3 && tp < npair;
+            const double *blk = img + (live ? tp : 0) * s;  // element (r, c) of the pair's block: blk[r + c * Lp]
+            double x[s];
+            double rs = 0.0, cs = 0.0;
+#pragma unroll
+            for (int c = 0; c < s; ++c) {
+                x[c] = blk[l + c * Lp];
+                rs += x[c];
+            }
+#pragma unroll
+            for (int r = 0; r < s; ++r) cs += blk[r + l * Lp];
+            const double rm = rs / (double)s, cm = cs / (double)s;
+            double(*my)[s] = red[wv][g < 3 ? g : 0];
+            if (live) {
+                my[0][l] = rm;
+                my[1][l] = cm;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            double tot = 0.0;
+#pragma unroll
+            for (int r = 0; r < s; ++r) tot += my[0][r];
+            tot /= (double)s;  // = sum(block) / s^2
+            double f = 0.0;
+#pragma unroll
+            for (int c = 0; c < s; ++c) {
+                const double kx = x[c] - rm - my[1][c] + tot;
+                f += kx * kx;
+            }
+            if (live) my[2][l] = f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (live && l == 0) {
+                double ff = 0.0;
+#pragma unroll
+                for (int r = 0; r < s; ++r) ff += my[2][r];
+                const int j = cj_lo + tp;
+                const double sc = sqrt(ff);
+                S[(size_t)ci + (size_t)j * N] = sc;
+                S[(size_t)j + (size_t)ci * N] = sc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // red is rewritten by the wave's next trip
+        }
+        if (tn >= total) break;
+        t = tn;
+        __syncthreads();   // the image is free
+    }
+#undef FN20_DECL
+#undef FN20_LOAD
+#undef FN20_REQUEST
+#undef FN20_STORE
+}
+
+// ncu: compute units of the device (the s = 20 form is a persistent grid)
+void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S, int ncu)
 {
     (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
     if (N < 2) return;
@@ -142,7 +290,11 @@ void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, 
     const size_t lds = ((size_t)sdim * (FN_PG * sdim + 2) + 4 * 64) * sizeof(double);
     const int units = (sdim * (FN_PG * sdim / 2) + 255) / 256;   // s = 20: 7
     constexpr int units20 = (20 * (FN_PG * 20 / 2) + 255) / 256;
-    if (sdim == 20)
+    if (sdim == 20 && (ld & 1) == 0) {
+        const int total = fn20_first(N - 1, N);
+        const int grid = std::min(total, FN20_WG * (ncu > 0 ? ncu : 256));
+        hipLaunchKernelGGL(k_fn20, dim3((unsigned)grid), dim3(FN20_THREADS), 0, s, A, ld, N, total, S);
+    } else if (sdim == 20)
         hipLaunchKernelGGL((k_fn<units20, 20>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
     else if (units <= 4)
         hipLaunchKernelGGL((k_fn<4, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);

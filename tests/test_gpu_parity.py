@@ -909,3 +909,9 @@ def test_two_ungated_sweeps_side_by_side():
     print(r.stdout[-1500:])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "two processes: exit codes [0, 0]" in r.stdout
+    # ... and MERGED launches of eight beside an ungated sweep of n rows (the first workgroup of a merged launch to show up stays a
+    # main-list worker: with the rest of its grid kept out by the other launch its lists still move)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "side_by_side_probe.py"), "9100", "2", "merged"], capture_output=True, text=True,
+                       env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="8000"), timeout=600)
+    print(r.stdout[-800:])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])

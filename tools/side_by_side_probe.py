@@ -25,6 +25,27 @@ def work(g, ctx, A, Xr, rounds, tag, out):
     out[tag] = (worst, time.time() - t0)
 
 
+def merged_work(g, rounds, out):
+    """eight matrices of config B's size through ONE merged launch, again and again (gdca_spd_inverse_batch_dev)"""
+    import torch
+
+    pool = [g.Context(0) for _ in range(8)]
+    ns = [2560 - 16 * k for k in range(8)]
+    As = [spd(n, 100 + k) for k, n in enumerate(ns)]
+    Xr = [np.linalg.inv(A) for A in As]
+    worst, t0 = 0.0, time.time()
+    try:
+        for _ in range(rounds):
+            ds = [torch.from_numpy(A).cuda() for A in As]
+            torch.cuda.synchronize()
+            g.spd_inverse_batch_dev(pool, [d.data_ptr() for d in ds], ns)
+            for d, X0 in zip(ds, Xr):
+                worst = max(worst, float(np.max(np.abs(d.cpu().numpy() - X0)) / np.max(np.abs(X0))))
+        out["merged"] = (worst, time.time() - t0)
+    except Exception as e:  # noqa: BLE001
+        out["merged"] = (float("inf"), "%s: %s" % (type(e).__name__, str(e)[:100]))
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 9100
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -38,6 +59,22 @@ if __name__ == "__main__":
         work(g, g.Context(0), A, Xr, rounds, "p", out)
         print("child %s: worst rel %.2e, %.2f s" % (sys.argv[4], out["p"][0], out["p"][1]), flush=True)
         sys.exit(0 if out["p"][0] <= 1e-10 else 1)
+    if len(sys.argv) > 3 and sys.argv[3] == "merged":
+        # a MERGED launch (eight members) beside an ungated single-family sweep of n rows: the case the batch driver once died of
+        import torch
+
+        torch.zeros(1).cuda()   # (torch's device context is created by the main thread; the worker threads only use it)
+        c1 = g.Context(0)
+        out = {}
+        work(g, c1, A, Xr, 1, "warm", out)
+        ts = [threading.Thread(target=work, args=(g, c1, A, Xr, rounds, "big", out)), threading.Thread(target=merged_work, args=(g, 6 * rounds, out))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        print("merged launches of 8 beside n=%d: big %s, merged %s" % (n, out.get("big"), out.get("merged")), flush=True)
+        ok = out["big"][0] <= 1e-10 and out["merged"][0] <= 1e-10
+        sys.exit(0 if ok else 1)
     c1, c2 = g.Context(0), g.Context(0)          # NOT peers: nothing orders their inverses
     out = {}
     work(g, c1, A, Xr, 1, "warm", out)
