@@ -495,7 +495,10 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
                            (const double *)ctx->Pipc.p, mode, out, ld, TJ);
     if (tm) HIPCHK(hipEventRecord(ctx->ev[10], s));
     // ||C||_1 for the refinement screen, where the bound that costs nothing (2 N pi_max) does not settle it (k_cov_norm1)
-    if (want_norm1)
+    // (not even launched where the answer is known on the host: pi_max <= (1 - pc) + pc / q whatever the alignment)
+    const double pi_cap = (1.0 - pc) + pc / (double)q;
+    const bool settled = pc > 0.0 && 2.0 * (double)N * pi_cap * (double)q * (double)q / pc <= ctx->tune.refine_cond && ctx->tune.refine != 1;
+    if (want_norm1 && !settled)
         gdca_launch_cov_norm1(s, out, ld, N, q, pc, ctx->tune.refine_cond, (gdca_dev_scalars *)ctx->sc.p, ctx->tune.refine == 1);
     return check_launch(ctx, "tally");
 }
