@@ -36,7 +36,7 @@ METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0  # HBM3E peak bandwidth (MI355X_MICROARCH.md)
 SPEC_SHADER_GHZ = 2.4  # the clock the spec peak is quoted at; the clock of the timed launches is measured by k_sweep itself
-PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_update_traffic.json")
+PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r05_pmc_update_traffic.json")
 
 CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
     "B": dict(N=128, M=10000, theta=0.2, seed=0xB128, ref="BASELINE.json configs[1]"),
