@@ -40,8 +40,6 @@ struct gdca_tuning {
     int rem_tail;           // GDCA_REM_TAIL: remainder tiles of update p listed after panel(p+1)
     int panel_halves;       // GDCA_PANEL_HALVES: 1 = two 128 x 64 panel items per pivot block and row, 0 = one 128 x 128
     int slab;               // GDCA_SLAB: 0 = panel and tile items between single blocks instead of the fused row slabs
-    int xcd;                // GDCA_XCD: 1 = the remainder tiles of an update are handed out XCD by XCD (super-blocks of tiles per L2), 0 = in list order
-    int xcd_sb;             // GDCA_XCD_SB: edge of those super-blocks (0 = 8 for single-block groups, 4 for multi-block ones)
     int ring;               // GDCA_RING: panel / Pg slots between single blocks (2..8)
     int mcus;               // GDCA_MCUS: compute units elected for the pivot chain (1..16)
     int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected

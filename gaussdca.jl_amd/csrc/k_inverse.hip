@@ -779,7 +779,7 @@ __device__ __forceinline__ void tile_chunk(double4_t (&acc)[4][4], Frag &f, Stag
     mma_all<TM0>(acc, f);  // k4 = 0
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (CI >= 0) cpiece_add<(CI >= 0 ? CI : 0)>(acc, cp);
-    if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, tile_off(ld, wr, wc, l15, lq));  // (offsets made where they are used: not live across chunks)
+    if constexpr (CI >= 0 && CI < 7) cpiece_load<(CI >= 0 && CI < 7 ? CI + 1 : 0)>(cp, At, ld, to);
     frag_read<GT>(f, Gc, Hc, 8, wr, wc, l15, lq);
     __builtin_amdgcn_sched_barrier(0);
     stage_unit<0, STORE, LOAD, GT>(acc, f1, R, Gn, Hn, g, h, io, tid, gc);  // k4 = 4, two MFMAs per unit
@@ -963,8 +963,6 @@ struct SweepDesc {
     int ring;              // Pg / panel buffers per kind: 2 (group parity) or 8 (single-block groups), see ring_panel
     int slab;              // single-block groups: the next pivot row's panel and diagonal tile as SLAB_ITEMS fused row-slab items (0: off)
     unsigned *sl;          // [3 ng] slab items of group p done (row b0 + 1), its xslab items, its slab items of row b0 + 2
-    unsigned *xq;          // [ng][8] XCD-aware hand-out of the remainder tiles (rem_claim): claim counter of XCD x's queue of update p; nullptr: off
-    int xsb;               // ... edge of a queue's super-blocks of tiles (8: 64 tiles share 8 + 8 panel rows; 4 for the deep panels of multi-block groups)
     int n_real;
     int rl;                // real (non-padding) rows of the last block, rounded up to 16: 16 .. 128
     gdca_dev_scalars *sc;
@@ -983,8 +981,6 @@ struct SweepShared {
     unsigned long long probe[2];  // the workgroup's start: shader clock, wall clock (the launch's clock measurement)
     unsigned long long stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
     int item, next, ready, fam, live, fnext, pnext;
-    int cI, cJ, cok;              // XCD-aware hand-out: the tile claimed for item `next` (cok = 1; cI < 0: none left)
-    int xcc;                      // the XCD this workgroup runs on
     int p[8];                     // merged launch: per family, the group this workgroup's last item belonged to
 };
 __shared__ SweepShared sw;
@@ -1159,28 +1155,6 @@ __device__ __forceinline__ int m_items(int sz)
     return sz == 1 ? 1 : sz * (sz + 1) + sz * (1 + SLAB_ITEMS * (sz - 1));
 }
 
-// geometry of update p's remainder tiles (shared by the list's decoder and the XCD-aware hand-out, rem_claim below)
-struct RemGeom {
-    int b0, sz, nsz, n2, d0, nrest;
-};
-__device__ __forceinline__ RemGeom rem_geom(const SweepDesc &D, int p)
-{
-    RemGeom g;
-    g.b0 = g_start(D, p);
-    g.sz = g_size(D, p);
-    g.nsz = p + 1 < D.ng ? g_size(D, p + 1) : 0;
-    g.n2 = p + 2 < D.ng ? g_size(D, p + 2) : 0;
-    g.d0 = g.b0 + g.sz + g.nsz;
-    g.nrest = D.nblk - g.sz - g.nsz;
-    return g;
-}
-// physical block indices (ii >= jj) of a remainder tile that is somebody else's (the chain's, an early slot's, diag2's)
-__device__ __forceinline__ bool rem_excluded(const SweepDesc &D, const RemGeom &g, int ii, int jj)
-{
-    if (D.slab) return (jj >= g.d0 && ii <= g.d0 + 1) || jj == g.d0;
-    return jj >= g.d0 && ii < g.d0 + g.n2;
-}
-
 // ---- the main list: item number -> what to do --------------------------------------------------------------------------
 // The first D.pro items are panel(0); then, group after group,
 //     diag2(p+2) | rest(p+1) | wb(p) | rem(p) but for its tail | panel(p+1) | the tail of rem(p)
@@ -1253,64 +1227,12 @@ __device__ __forceinline__ MainItem main_decode(const SweepDesc &D, int &p, int 
     int jj = e - (int)((long long)ii * (ii + 1) / 2);
     if (ii >= b0) ii += sz + nsz;
     if (jj >= b0) jj += sz + nsz;
-    // (between single blocks: (b0+2, b0+2) is the chain's, (b0+3, b0+3) and column b0 + 2 below the diagonal are early slots; else: inside
-    // the diagonal super-block of group p+2: done as diag2)
-    if (rem_excluded(D, RemGeom{b0, sz, nsz, n2, d0, nrest}, ii, jj)) return MainItem{3, p, 0, 0};
+    if (D.slab) {
+        // (b0+2, b0+2): the chain's; (b0+3, b0+3) and column b0 + 2 below the diagonal: early slots
+        if ((jj >= d0 && ii <= d0 + 1) || jj == d0) return MainItem{3, p, 0, 0};
+    } else if (jj >= d0 && ii < d0 + n2)
+        return MainItem{3, p, 0, 0};  // inside the diagonal super-block of group p+2: done as diag2
     return MainItem{1, p, ii, jj};
-}
-
-// ---- XCD-aware hand-out of the remainder tiles ---------------------------------------------------------------------------------
-// Every remainder tile of update p reads the panel rows of ITS row block and ITS column block (K = 128 sz columns of G and H: 128 KB
-// to 1 MB each); handed out in list order by the device-wide counter, neighbouring tiles went to workgroups on arbitrary XCDs and
-// every tile item fetched both of its panel rows through the fabric (58 GB per inverse at n = 10 000 for 1.6 GB of matrix).  Each of
-// the eight XCDs has an L2 of its own.  So the remainder SLOTS of the main list stay what they are -- the list order is what makes
-// the sweep deadlock-free, and every remainder tile of update p has dependencies of the same shape (its two panel rows, handed out
-// earlier in the list; the tile at generation p) -- but WHICH tile a slot's taker works on is decided by the XCD it runs on: the
-// lower triangle (in the compressed coordinates of the blocks outside groups p and p + 1) is cut into super-blocks of xsb x xsb
-// tiles, super-block number s belongs to XCD s % 8, and a workgroup claims the next tile of its XCD's queue with one atomic (from the
-// neighbours' queues once its own is exhausted: as many slots as tiles, nobody goes away empty).  The workgroups of an XCD are then
-// at work on one or two super-blocks at a time: xsb + xsb panel rows for xsb^2 tiles.  Tiles that other items of the list own
-// (main_decode's "nothing" slots) are skipped by the claim.
-// thread 0: the next tile of update p for a workgroup on XCD xcc -> (I, J) physical block indices; false: none left (cannot
-// happen while remainder slots of update p are outstanding)
-__device__ __forceinline__ bool rem_claim(const SweepDesc &D, int p, int xcc, int &I, int &J)
-{
-    const RemGeom g = rem_geom(D, p);
-    const int sb = D.xsb, R = g.nrest, R8 = (R + sb - 1) / sb, T8 = R8 * (R8 + 1) / 2;
-    for (int t = 0; t < 8; ++t) {
-        const int x = (xcc + t) & 7;
-        const int nsb = x < T8 ? (T8 - x + 7) / 8 : 0;        // super-blocks of queue x: s = x, x + 8, ..
-        const unsigned size = (unsigned)(nsb * sb * sb);
-        unsigned *q = D.xq + (size_t)p * 8 + x;
-        if (flag_load(q) >= size) continue;                   // (exhausted: no atomic)
-        for (;;) {
-            const unsigned k = __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k >= size) break;
-            const int sidx = x + 8 * (int)(k / (unsigned)(sb * sb)), slot = (int)(k % (unsigned)(sb * sb));
-            int rr = (int)((sqrt(8.0 * (double)sidx + 1.0) - 1.0) * 0.5);
-            while (rr * (rr + 1) / 2 > sidx) --rr;
-            while ((rr + 1) * (rr + 2) / 2 <= sidx) ++rr;
-            const int cc = sidx - rr * (rr + 1) / 2;
-            int ii = rr * sb + slot / sb, jj = cc * sb + slot % sb;   // compressed coordinates
-            if (ii >= R || jj > ii) continue;                     // padding of a super-block at the triangle's edge
-            if (ii >= g.b0) ii += g.sz + g.nsz;
-            if (jj >= g.b0) jj += g.sz + g.nsz;
-            if (rem_excluded(D, g, ii, jj)) continue;
-            I = ii;
-            J = jj;
-            return true;
-        }
-    }
-    return false;
-}
-
-// (out of line: thread 0 calls it from inside the tile item's epilogue, where the kernel has no registers to spare.  Returns
-// I << 16 | J, or -1.)
-__device__ __attribute__((noinline)) int rem_claim_ol(int f, int p, int xcc)
-{
-    int I = 0, J = 0;
-    if (!rem_claim(launch_desc(__builtin_amdgcn_readfirstlane(f)), __builtin_amdgcn_readfirstlane(p), __builtin_amdgcn_readfirstlane(xcc), I, J)) return -1;
-    return (I << 16) | J;
 }
 
 // One 128 x 128 pivot by the calling 256-thread workgroup (LDS of the tile paths reused: Gs and Hs are the two halves of ONE array,
@@ -1895,28 +1817,17 @@ __device__ __forceinline__ void tile_item_finish(const SweepDesc &D, int p, int 
         const int fn = nt.merged ? sw_fnext : 0;
         if (nt.merged) sw_fam = fn;
         const SweepDesc &Dn = nt.merged ? launch_desc(fn) : D;
-        int r = 0, cok = 0;
+        int r = 0;
         if (nt.nxt < Dn.total) {
             int ph = nt.merged ? sw_pnext : p;
             const MainItem ni = main_decode(Dn, ph, nt.nxt);
-            int nI = ni.a, nJ = ni.b;
-            if (ni.kind == 1 && Dn.xq) {
-                // XCD-aware hand-out: the next remainder slot's tile is claimed here, while this item's stores drain
-                const int c = rem_claim_ol(nt.merged ? fn : 0, ni.p, sw.xcc);
-                nI = c < 0 ? -1 : c >> 16;
-                nJ = c & 0xffff;
-                sw.cI = nI;
-                sw.cJ = nJ;
-                cok = 1;
-            }
-            if ((ni.kind == 1 || ni.kind == 4) && nI >= 0) {
+            if (ni.kind == 1 || ni.kind == 4) {
                 const int nsz2 = g_size(Dn, ni.p);
-                const unsigned f1 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + nI), f2 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + nJ),
-                               f3 = flag_load(Dn.gen + (size_t)nI * Dn.nblk + nJ);
+                const unsigned f1 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + ni.a), f2 = flag_load(Dn.rb + (size_t)ni.p * Dn.nblk + ni.b),
+                               f3 = flag_load(Dn.gen + (size_t)ni.a * Dn.nblk + ni.b);
                 r = (f1 >= 2u * (unsigned)nsz2) & (f2 >= 2u * (unsigned)nsz2) & (f3 >= (unsigned)ni.p);
             }
         }
-        sw.cok = cok;
         sw_ready = r;
     }
     publish_wt_begin();
@@ -2202,30 +2113,6 @@ SWEEP_OUTLINE void sweep_full_panel_item_ol(int f, int p, int i, int y)
     sweep_panel_item<4>(launch_desc(UNI(f)), UNI(p), UNI(i), UNI(y), sw_lds, sw_lds + 2);
 }
 
-// XCD-aware hand-out, at the start of an item: a remainder slot (it.kind == 1) works on the tile its taker claims -- already claimed by
-// the previous item's look-ahead (cok: cI, cJ as read at the loop's top), or claimed now (thread 0; two barriers: the first item of a
-// workgroup, or one behind an item without a look-ahead).  Returns the item to run (kind 3: the queues are empty).
-__device__ __forceinline__ MainItem sweep_resolve_rem(const SweepDesc &D, int f, MainItem it, int cok, int cI, int cJ, int &rdy)
-{
-    if (it.kind != 1 || !D.xq) return it;
-    if (!cok) {
-        if (threadIdx.x == 0) {
-            const int c = rem_claim_ol(f, it.p, sw.xcc);
-            sw.cI = c < 0 ? -1 : c >> 16;
-            sw.cJ = c & 0xffff;
-        }
-        __syncthreads();
-        cI = UNI(sw.cI);
-        cJ = UNI(sw.cJ);
-        __syncthreads();
-        rdy = 0;
-    }
-    if (cI < 0) return MainItem{3, it.p, 0, 0};
-    it.a = cI;
-    it.b = cJ;
-    return it;
-}
-
 // One item of the main list of family f, by the calling workgroup.  nt: where its next take goes (tile items publish it themselves,
 // inside tile_item_finish; for the other kinds the caller does, after the item).  Returns true when the item published the take.
 template <bool MULTI>
@@ -2278,13 +2165,6 @@ __device__ __forceinline__ int sweep_trace_xslot(const SweepDesc &D, const MainI
 // the chain's compute units: a workgroup on XCC x offers itself to family (x + t) % K, t = 0, 1, ..: the first workgroup to reach a
 // family decides its XCD, so with K <= 8 the chains sit on different XCDs (each hands its data on through one L2) whenever the
 // workgroups of a launch are spread over them.  Thread 0; returns the family this workgroup's CU was elected for, or -1.
-__device__ __forceinline__ int sweep_xcc()
-{
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    return (int)(xcc & 7u);
-}
-
 __device__ __forceinline__ int sweep_elect(int K)
 {
     unsigned xcc, hw;
@@ -2336,7 +2216,6 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     // the tiles (2 n_mcu of 512 workgroups) and join them once the M list is exhausted.
     if (threadIdx.x == 0) {
         launch_desc_init();
-        sw.xcc = sweep_xcc();
         *abort_lds() = 0;
         sw_item = sweep_elect(1);
     }
@@ -2358,13 +2237,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     if (threadIdx.x == 0) {
         sw_next = (int)__hip_atomic_fetch_add(D.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sw_ready = 0;
-        sw.cok = 0;
     }
     for (;;) {
         __syncthreads();
-        const int item = UNI(sw_next);  // (scalar: as vector registers they were live -- spilled -- across the item)
-        int rdy = UNI(sw_ready);
-        const int cok = UNI(sw.cok), cI = UNI(sw.cI), cJ = UNI(sw.cJ);
+        const int item = UNI(sw_next), rdy = UNI(sw_ready);  // (scalar: as vector registers they were live -- spilled -- across the item)
         __syncthreads();  // everybody has read them
         if (item >= D.total || *abort_lds()) break;
         int nxt = 0;
@@ -2374,7 +2250,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             sw_stamp[0] = wall_clock64();
             sw_stamp[1] = (unsigned long long)clock64();
         }
-        const MainItem it = sweep_resolve_rem(D, 0, main_decode(D, p, item), cok, cI, cJ, rdy);
+        const MainItem it = main_decode(D, p, item);
         // trace (between single blocks): when the main list's items of row block b0 + 3 of update it.p were taken and done -- the
         // inputs the chain waits for: [0..2] its panel halves (first taken, last done), [3..] tiles (b0+3, b0+1), (b0+3, b0+2), (b0+3, b0+3)
         if (D.dbg && D.slab && threadIdx.x == 0) {
@@ -2410,7 +2286,6 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         if (!published && threadIdx.x == 0) {
             sw_next = nxt;
             sw_ready = 0;
-            sw.cok = 0;
         }
     }
     if (threadIdx.x == 0) {
@@ -2458,7 +2333,6 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
 #endif
     if (threadIdx.x == 0) {
         launch_desc_init();
-        sw.xcc = sweep_xcc();
         *abort_lds() = 0;
         sw_item = sweep_elect(K);
         for (int f = 0; f < SWEEP_MAX_MERGE; ++f) sw_p[f] = 0;
@@ -2483,13 +2357,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
         sw_fam = f0;
         sw_next = (int)__hip_atomic_fetch_add(launch_desc_k(f0).next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sw_ready = 0;
-        sw.cok = 0;
     }
     for (;;) {
         __syncthreads();
-        const int item = UNI(sw_next);
-        int rdy = UNI(sw_ready);
-        const int cok = UNI(sw.cok), cI = UNI(sw.cI), cJ = UNI(sw.cJ);
+        const int item = UNI(sw_next), rdy = UNI(sw_ready);
         const int f = __builtin_amdgcn_readfirstlane(sw_fam);
         __syncthreads();  // everybody has read them
         if (f < 0 || *abort_lds()) break;
@@ -2507,13 +2378,12 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
                 }
                 sw_fam = fn;
                 sw_ready = 0;
-                sw.cok = 0;
             }
             continue;
         }
         int nxt = 0;
         int p = sw_p[f];
-        const MainItem it0 = main_decode(D, p, item);
+        const MainItem it = main_decode(D, p, item);
         if (threadIdx.x == 0) {
             const unsigned live = (unsigned)sw_live;
             int fn = f;
@@ -2523,14 +2393,12 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
             sw_fnext = fn;
             sw_pnext = sw_p[fn];  // (fn == f: the value just written)
         }
-        const MainItem it = sweep_resolve_rem(D, f, it0, cok, cI, cJ, rdy);
         const NextTake nt{nxt, 1, 1};
         const bool published = sweep_main_item<MULTI>(D, f, it, rdy, nt);
         if (!published && threadIdx.x == 0) {
             sw_next = nxt;
             sw_fam = sw_fnext;
             sw_ready = 0;
-            sw.cok = 0;
         }
     }
     if (threadIdx.x == 0) {
@@ -2554,7 +2422,7 @@ size_t gdca_inverse_flag_bytes(int n_pad)
     const size_t nblk = (size_t)(n_pad / T);
     // gen, rb (ng <= nblk), mc, done, sl | next, next_m, mcu[16], mxcc | the abort word on a 128-byte line of its own (every wait
     // of the kernel reads it; the line of the item counters is busy with atomics)
-    return (nblk * nblk + nblk * nblk + 13 * nblk + 96) * sizeof(unsigned);   // (+ 8 ng: the XCD queues' claim counters)
+    return (nblk * nblk + nblk * nblk + 5 * nblk + 96) * sizeof(unsigned);
 }
 
 int gdca_inverse_max_merge(void)
@@ -2691,11 +2559,6 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     f += ng;
     D.sl = f;
     f += 3 * ng;
-    D.xq = tu.xcd != 0 ? f : nullptr;
-    f += 8 * ng;
-    // super-blocks of 8 x 8 tiles where a panel row is 128 KB (single-block groups: 16 rows = 2 MB of an XCD's 4 MB L2), of 4 x 4 where
-    // it is up to 512 KB (option XCD_SB)
-    D.xsb = tu.xcd_sb > 0 ? tu.xcd_sb : (g == 1 ? 8 : 4);
     D.next = f;
     D.next_m = f + 1;
     D.mcu = f + 2;
