@@ -48,7 +48,6 @@ struct gdca_ctx {
     gdca_status rank_status = GDCA_OK;
     int32_t *rank_i = nullptr, *rank_j = nullptr;
     double *rank_s = nullptr;
-    hipStream_t side;          // side stream: the serial Meff chain beside the transposes / Pi tallies
     int ncu;                   // compute units of the device
     int *item0_host;           // pinned staging of the sweep's item table
     int item0_cap;
@@ -57,8 +56,7 @@ struct gdca_ctx {
     hipEvent_t ev[MAX_EV];
     int n_ev;
     // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
-    bool meff_pending;  // k_meff enqueued on the side stream, not yet joined
-    hipEvent_t ev_weights, ev_meff, ev_batch, ev_upload;
+    hipEvent_t ev_batch, ev_upload;
     bool pending;
     bool pend_timed;
     bool pend_fn_timed, pend_tally_timed;  // events 7 / 8 around k_fn, 9 / 10 around k_pair_tally were recorded by this run
@@ -254,16 +252,8 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
         hipDeviceProp_t prop0;
         ctx->ncu = hipGetDeviceProperties(&prop0, device_id) == hipSuccess ? prop0.multiProcessorCount : 256;
     }
-    ctx->side = nullptr;
     // from here on every failure goes through gdca_ctx_destroy, which frees whatever has been created so far
-    if (!ctx->side && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) {
-        ctx->side = nullptr;
-        gdca_ctx_destroy(ctx);
-        return GDCA_EHIP;
-    }
-    if (hipEventCreateWithFlags(&ctx->ev_weights, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_meff, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&ctx->ev_batch, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) {
         gdca_ctx_destroy(ctx);
         return GDCA_EHIP;
@@ -332,14 +322,8 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     }
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->item0_host) (void)hipHostFree(ctx->item0_host);
-    if (ctx->ev_weights) (void)hipEventDestroy(ctx->ev_weights);
-    if (ctx->ev_meff) (void)hipEventDestroy(ctx->ev_meff);
     if (ctx->ev_batch) (void)hipEventDestroy(ctx->ev_batch);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
-    if (ctx->side) {
-        (void)hipStreamSynchronize(ctx->side);
-        (void)hipStreamDestroy(ctx->side);
-    }
     if (ctx->sc_host) (void)hipHostFree(ctx->sc_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
@@ -454,13 +438,9 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
         gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, Zd, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode, ctx->hcand.p);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
-    // Meff is one long dependent chain on a single CU: run it on the side stream, next to the kernels that
-    // do not need it yet (transposes, Pi tallies); tally_stage() joins before the first consumer
-    HIPCHK(hipEventRecord(ctx->ev_weights, s));
-    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_weights, 0));
-    gdca_launch_meff(ctx->side, (const double *)ctx->W.p, M, sc);
-    HIPCHK(hipEventRecord(ctx->ev_meff, ctx->side));
-    ctx->meff_pending = true;
+    // (Meff: an exact integer sum by one workgroup, microseconds.  Rounds 1-4 summed left to right in f64 -- 0.3 ms of dependent adds at
+    // M = 50 000 -- on a side stream of the context, joined before the first consumer.)
+    gdca_launch_meff(s, (const double *)ctx->W.p, M, sc);
     return check_launch(ctx, "weights");
 }
 
@@ -482,10 +462,6 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
     gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M, q,
                          (gdca_dev_scalars *)ctx->sc.p);
-    if (ctx->meff_pending) {
-        HIPCHK(hipStreamWaitEvent(s, ctx->ev_meff, 0));
-        ctx->meff_pending = false;
-    }
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
                             (double *)ctx->Pipc.p, want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->pi_max : nullptr);
     const bool tm = want_norm1 && ctx->timing && ctx->n_ev >= 18;  // (the fused path's first build: its own device time, gdca_stats.ms_pair_tally)
@@ -612,10 +588,6 @@ static gdca_status validate(gdca_ctx *ctx, int N, int M, int q)
 
 static gdca_status fetch_scalars(gdca_ctx *ctx)
 {
-    if (ctx->meff_pending) {
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_meff, 0));
-        ctx->meff_pending = false;
-    }
     HIPCHK(hipMemcpyAsync(ctx->sc_host, ctx->sc.p, sizeof(gdca_dev_scalars), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return GDCA_OK;
@@ -1085,15 +1057,12 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
     }
     for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
     if (st != GDCA_OK) {
-        // a member failed to enqueue (allocation, launch): drain what was enqueued -- the batch's stream AND every member's side
-        // stream, where its k_meff may still be writing the member's scalars -- and leave nobody half-pending.  The failing
-        // member's message goes to the leader, whose last_error the caller reads.
+        // a member failed to enqueue (allocation, launch): drain what was enqueued -- the batch's stream AND every member's own
+        // stream -- and leave nobody half-pending.  The failing member's message goes to the leader, whose last_error the caller reads.
         (void)hipStreamSynchronize(lead->stream);
         for (int k = 0; k < K; ++k) {
             (void)hipStreamSynchronize(own[k]);  // (a front end enqueued side by side)
-            if (ctxs[k]->side) (void)hipStreamSynchronize(ctxs[k]->side);
             ctxs[k]->pending = false;
-            ctxs[k]->meff_pending = false;
             if (k > 0 && ctxs[k]->err[0] && k == done_front) {
                 char msg[sizeof(lead->err)];
                 snprintf(msg, sizeof(msg), "member %d: %.400s", k, ctxs[k]->err);

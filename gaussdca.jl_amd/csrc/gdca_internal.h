@@ -88,7 +88,7 @@ void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, 
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)
 void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W,
                          unsigned long long *Wfix);
-// Meff = W[0] + W[1] + ... strictly left to right (one wave)
+// Meff = the exact sum of the weights, rounded once (one workgroup; order-independent)
 void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc);
 // Wfix from caller-given W (operator-level gdca_frequencies)
 void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix,

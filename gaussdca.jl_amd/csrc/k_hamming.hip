@@ -520,52 +520,100 @@ void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shif
     hipLaunchKernelGGL(k_fix_weights, dim3((M + 255) / 256), dim3(256), 0, s, W, M, fix_shift, Wfix, sc);
 }
 
-// Meff = ((W[0] + W[1]) + W[2]) + ...  -- the strictly sequential f64 sum the oracle uses, so the
-// value is bit-identical to it.  The chain of M dependent v_add_f64 is the whole cost; one thread
-// walks it out of LDS (b128 reads, issued ahead of the adds) while the other 255 threads stage
-// the next 2048 weights.  Zero padding of the last tile is exact (x + 0.0 == x for x > 0).
-#define MEFF_TILE 2048
-__global__ __launch_bounds__(256) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
+// Meff = the sum of the weights, EXACT and rounded once (round to nearest even): what Python's math.fsum returns, whatever the
+// order of the terms.  (Rounds 1-4 walked the strictly sequential f64 sum ((W[0] + W[1]) + W[2]) + ... -- one thread, M dependent
+// v_add_f64: 0.3 ms at M = 50 000 on a stream of its own.  The reference's own sum(W) is Julia's pairwise, SIMD-reassociated sum,
+// so no f64 summation order pins its last bit; an exactly rounded sum is the one definition that needs no order.)
+// Every weight 1 / n_k is m 2^(E - 1075) with a 53-bit m and E - 1023 in [-31, 0]: as an integer multiple of 2^-84 it has at most
+// 85 bits.  A thread adds the three 32-bit limbs of its terms into 64-bit counters (no carries: < 2^24 terms per thread), the
+// workgroup adds those into LDS, and thread 0 resolves the carries into one 128-bit integer and rounds it to 53 bits.
+#define MEFF_FRAC 84
+__global__ __launch_bounds__(1024) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
 {
-    __shared__ __attribute__((aligned(16))) double buf[2][MEFF_TILE];
+    __shared__ unsigned long long limb[3];
     const int tid = threadIdx.x;
-    const int ntile = (M + MEFF_TILE - 1) / MEFF_TILE;
-    double r[8];
+    if (tid < 3) limb[tid] = 0ull;
+    __syncthreads();
+    unsigned long long l0 = 0ull, l1 = 0ull, l2 = 0ull;
+    // (eight loads in flight per thread: the loop is the latency of its loads, 49 trips at M = 50 000)
+    for (int k0 = tid; k0 < M; k0 += 8 * (int)blockDim.x) {
+        double w[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int k = tid + 256 * u;
-        buf[0][tid + 256 * u] = (k < M) ? W[k] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * (int)blockDim.x;
+            w[u] = k < M ? W[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(w[u]);
+        const int E = (int)((b >> 52) & 0x7ffull);
+        unsigned long long m = b & 0xfffffffffffffull;
+        int sh = E - 1075 + MEFF_FRAC;  // 1 / n_k, n_k < 2^31: 1 .. 32
+        if (E != 0) m |= 1ull << 52; else sh += 1;  // (subnormal: no hidden bit -- never a weight)
+        if (sh < 0) {  // smaller than anything compute_weights produces: what is below 2^-84 is dropped
+            m = sh > -64 ? m >> (-sh) : 0ull;
+            sh = 0;
+        }
+        if (sh > 43) sh = 43;  // (a weight above 2^11 does not exist either: the limbs below stay exact for everything <= 1)
+        const unsigned long long lo = m << sh, hi = sh ? m >> (64 - sh) : 0ull;
+        l0 += lo & 0xffffffffull;
+        l1 += lo >> 32;
+        l2 += hi;
+        }
+    }
+    // wave sums first (64 lanes x 2^24 terms x 2^32 < 2^64), then one LDS atomic per wave and limb
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        l0 += __shfl_xor(l0, o);
+        l1 += __shfl_xor(l1, o);
+        l2 += __shfl_xor(l2, o);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&limb[0], l0);
+        atomicAdd(&limb[1], l1);
+        atomicAdd(&limb[2], l2);
     }
     __syncthreads();
-    double acc = 0.0;
-    for (int t = 0; t < ntile; ++t) {
-        const bool more = t + 1 < ntile;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = (t + 1) * MEFF_TILE + tid + 256 * u;
-                r[u] = (k < M) ? W[k] : 0.0;
+    if (tid == 0) {
+        // S = limb0 + limb1 2^32 + limb2 2^64 as (hi : lo)
+        unsigned long long lo = limb[0], hi = limb[2];
+        const unsigned long long mid = limb[1];
+        const unsigned long long add = mid << 32;
+        lo += add;
+        hi += (mid >> 32) + (lo < add ? 1ull : 0ull);
+        double r;
+        if (hi == 0ull && lo < (1ull << 53)) {
+            r = ldexp((double)lo, -MEFF_FRAC);
+        } else {
+            const int p = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);  // top bit of S
+            const int shift = p - 52;                                                   // >= 1: bits to drop
+            unsigned long long kept, rem_hi, rem_lo, half_hi, half_lo;
+            if (shift >= 64) {
+                kept = hi >> (shift - 64);
+                rem_hi = shift > 64 ? hi & ((1ull << (shift - 64)) - 1ull) : 0ull;
+                rem_lo = lo;
+            } else {
+                kept = (lo >> shift) | (hi << (64 - shift));  // (hi < 2^(p - 63): nothing of it is lost)
+                rem_hi = 0ull;
+                rem_lo = lo & ((1ull << shift) - 1ull);
             }
-        }
-        if (tid == 0) {
-            const double2 *b2 = reinterpret_cast<const double2 *>(buf[t & 1]);
-#pragma unroll 8
-            for (int e = 0; e < MEFF_TILE / 2; ++e) {
-                const double2 v = b2[e];
-                acc += v.x;
-                acc += v.y;
+            if (shift - 1 >= 64) {
+                half_hi = 1ull << (shift - 1 - 64);
+                half_lo = 0ull;
+            } else {
+                half_hi = 0ull;
+                half_lo = 1ull << (shift - 1);
             }
+            const bool above = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
+            const bool tie = rem_hi == half_hi && rem_lo == half_lo;
+            if (above || (tie && (kept & 1ull))) ++kept;  // (2^53 after the carry is still exact in f64)
+            r = ldexp((double)kept, shift - MEFF_FRAC);
         }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) buf[(t + 1) & 1][tid + 256 * u] = r[u];
-        }
-        __syncthreads();
+        sc->Meff = r;
     }
-    if (tid == 0) sc->Meff = acc;
 }
 
 void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_meff, dim3(1), dim3(256), 0, s, W, M, sc);
+    hipLaunchKernelGGL(k_meff, dim3(1), dim3(1024), 0, s, W, M, sc);
 }

@@ -236,7 +236,7 @@ gdca_status gdca_compute_theta(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_
 /* n_out[k] = 1 + #{l != k : Hamming(k,l) < thresh}  (compute_weights, :28) */
 gdca_status gdca_neighbour_counts(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t thresh,
                                   int32_t *n_out);
-/* compute_weights(Z, q, theta): W[M] = 1/n_k, Meff = W[0]+W[1]+... left to right.
+/* compute_weights(Z, q, theta): W[M] = 1/n_k, Meff = the sum of the W[k], exact and rounded once (order-independent).
  * theta < 0 selects :auto.  theta_used / thresh may be NULL. */
 gdca_status gdca_compute_weights(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, double theta,
                                  double *W, double *Meff, double *theta_used, int32_t *thresh);

@@ -232,9 +232,11 @@ def neighbour_counts(Z: np.ndarray, thresh: int) -> np.ndarray:
 
 
 def weights_from_counts(n: np.ndarray) -> Tuple[np.ndarray, float]:
-    """W_k = 1/n_k; Meff = W_1 + W_2 + ... accumulated left to right in f64."""
+    """W_k = 1/n_k; Meff = sum(W), the exact sum rounded once (math.fsum).  DCAUtils returns ``sum(W)``: Julia's pairwise,
+    SIMD-reassociated sum, whose last bit depends on the machine -- no f64 evaluation order pins it (header, "Parity pinning"),
+    so the restatement uses the one value that needs no order.  (Rounds 1-4 of this repository summed left to right.)"""
     W = 1.0 / n.astype(np.float64)
-    Meff = float(np.cumsum(W)[-1])  # np.cumsum is a sequential left-to-right sum
+    Meff = math.fsum(W.tolist())
     return W, Meff
 
 

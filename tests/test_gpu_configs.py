@@ -13,6 +13,7 @@ Bars (north_star): Hamming counts / thresholds / identity sums / ranking indices
 import os
 import subprocess
 
+import math
 import numpy as np
 import pytest
 
@@ -171,7 +172,7 @@ def test_config_D_properties_at_full_size(g, ctx, o):
         d = np.count_nonzero(Zo != Zo[k], axis=1)
         assert n_gpu[k] == int(np.count_nonzero(d < thr))                   # includes k itself (d = 0): bit-exact
     W = 1.0 / n_gpu
-    Meff = float(np.cumsum(W)[-1])
+    Meff = math.fsum(W.tolist())   # the exact sum, rounded once
     assert st["Meff"] == Meff
 
     # the device-resident statement chain, keeping C and mJ
