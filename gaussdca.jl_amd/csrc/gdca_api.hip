@@ -53,6 +53,8 @@ struct gdca_ctx {
     int item0_cap;
     gdca_buf scratch[N_SCRATCH];
     gdca_dev_scalars *sc_host;  // pinned
+    gdca_dev_scalars *sc_host_dev;  // ... as the device addresses it (k_publish_scalars)
+    bool sc_published;          // the enqueued run ends with k_publish_scalars: its collect reads sc_host after a stream synchronisation
     hipEvent_t ev[MAX_EV];
     int n_ev;
     // state of an enqueued, not yet collected run (gdca_run_dev_async / gdca_run_collect)
@@ -111,7 +113,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
-        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1},
+        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -160,13 +162,14 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_group = -1;
     t->merge_tiles = 2300;
     t->phased_fronts = 1;
+    t->phased_streams = 4;
     t->refine = -1;
     t->refine_cond = 1e6;
     t->cholesky = 1;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_STREAMS"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -263,6 +266,7 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
         gdca_ctx_destroy(ctx);
         return GDCA_ENOMEM;
     }
+    if (hipHostGetDevicePointer((void **)&ctx->sc_host_dev, ctx->sc_host, 0) != hipSuccess) ctx->sc_host_dev = nullptr;  // (then collect copies)
     *out = ctx;
     return GDCA_OK;
 }
@@ -512,6 +516,10 @@ static gdca_status inverse_job(gdca_ctx *ctx, int n, int n_pad, gdca_inverse_job
     ws.flags_bytes = fbytes;
     ws.item0_dev = (int *)((char *)ctx->Sg.p + 4 * sg + fbytes);
     ws.item0_host = ctx->item0_host;
+    {
+        void *dp = nullptr;
+        ws.item0_host_dev = hipHostGetDevicePointer(&dp, ctx->item0_host, 0) == hipSuccess ? (const int *)dp : nullptr;
+    }
     ws.update_cus = ctx->ncu;
     job->A = (double *)ctx->A.p;
     job->n_pad = n_pad;
@@ -680,7 +688,13 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
     HIPCHK(hipSetDevice(ctx->device));
     ctx->pending = false;
     ctx->rank_pending = false;  // (collected through this entry, a ranked run's ranking is given up: its arrays are scratch of the next run)
-    CHK(fetch_scalars(ctx));
+    if (ctx->sc_published) {
+        // the run's last kernel wrote the scalars to sc_host: no copy of the runtime's -- a kernel -- behind another context's sweep
+        ctx->sc_published = false;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
+        CHK(fetch_scalars(ctx));
+    }
     if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
         (ctx->tune.refine == 1 || cond_bound(*ctx->sc_host, ctx->pend_p.pseudocount, ctx->pend_q, ctx->pend_N) > ctx->tune.refine_cond)) {
         CHK(inverse_norm_stage(ctx, ctx->pend_n, ctx->pend_npad));   // cond(C) may be beyond the threshold: ||X||_1 itself
@@ -937,6 +951,12 @@ static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev, ctx->pend_timed));
     if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->sc_published = false;
+    if (ctx->sc_host_dev) {
+        gdca_launch_publish_scalars(ctx->stream, (const gdca_dev_scalars *)ctx->sc.p, ctx->sc_host_dev);
+        CHK(check_launch(ctx, "publish_scalars"));
+        ctx->sc_published = true;
+    }
     ctx->pending = true;
     return GDCA_OK;
 }
@@ -1025,37 +1045,48 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
     // stream, and the leader's stream waits for all of them before the first inverse (option PHASED_FRONTS=0: one after the other
     // on the leader's stream, as in round 4: 8 x 0.55 ms in front of 8 x 0.43 ms of merged inverses at config B).  The members keep
     // their own workspaces, scalars and timing events; their streams are restored before returning.
-    hipStream_t own[64];
+    hipStream_t own[64], use[64];
     if (K > 64) return fail(lead, GDCA_EINVAL, "at most 64 families per batch%s%s", "", "");
     const bool side_by_side = lead->tune.phased_fronts != 0 && K > 1;
+    // ... on the streams of the first PHASED_STREAMS members, round robin (default 4, the runtime's hardware queues: with one
+    // stream per member the eight front ends of a config-B batch ran two to three wide and started up to 1.4 ms apart,
+    // profiles/r05_B_merged8_timeline.log -- streams that share a hardware queue take turns, and the second of a pair started
+    // hundreds of microseconds after the first had finished)
+    const int W = side_by_side ? std::max(1, std::min((int)K, lead->tune.phased_streams)) : 1;
     for (int k = 0; k < K; ++k) {
         own[k] = ctxs[k]->stream;
         if (k > 0) (void)hipStreamSynchronize(own[k]);  // nothing of an earlier use is still in flight on the member's own stream
-        if (!side_by_side) ctxs[k]->stream = lead->stream;
     }
+    for (int k = 0; k < K; ++k) use[k] = side_by_side ? own[k % W] : lead->stream;
     gdca_status st = GDCA_OK;
     int done_front = 0;
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        ctxs[k]->stream = use[k];
         st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
-        if (st == GDCA_OK && side_by_side && k > 0) {
+        if (st == GDCA_OK && use[k] != lead->stream) {
             // the batch's stream goes on behind this member's front end
-            if (hipEventRecord(ctxs[k]->ev_batch, own[k]) != hipSuccess || hipStreamWaitEvent(lead->stream, ctxs[k]->ev_batch, 0) != hipSuccess)
+            if (hipEventRecord(ctxs[k]->ev_batch, use[k]) != hipSuccess || hipStreamWaitEvent(lead->stream, ctxs[k]->ev_batch, 0) != hipSuccess)
                 st = fail(lead, GDCA_EHIP, "event chain of the batch's front ends%s%s", "", "");
         }
         if (st == GDCA_OK) ++done_front;
     }
-    if (side_by_side)
-        for (int k = 0; k < K; ++k) ctxs[k]->stream = lead->stream;
+    for (int k = 0; k < K; ++k) ctxs[k]->stream = lead->stream;
     if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
     if (st == GDCA_OK && side_by_side) {
-        // ... and the score stages side by side again, each behind the batch's inverses on its member's own stream
+        // ... and the score stages side by side again, each behind the batch's inverses on the stream its front end ran on
         if (hipEventRecord(lead->ev_upload, lead->stream) != hipSuccess) st = fail(lead, GDCA_EHIP, "event chain of the batch's score stages%s%s", "", "");
-        for (int k = 1; k < K && st == GDCA_OK; ++k) {
-            if (hipStreamWaitEvent(own[k], lead->ev_upload, 0) != hipSuccess) st = fail(lead, GDCA_EHIP, "event chain of the batch's score stages%s%s", "", "");
-            ctxs[k]->stream = own[k];
-        }
+        for (int j = 1; j < W && st == GDCA_OK; ++j)
+            if (hipStreamWaitEvent(own[j], lead->ev_upload, 0) != hipSuccess) st = fail(lead, GDCA_EHIP, "event chain of the batch's score stages%s%s", "", "");
     }
-    for (int k = 0; k < done_front && st == GDCA_OK; ++k) st = run_score(ctxs[k], p, S_dev[k]);
+    bool chained = true;  // every member's own stream waits for what was enqueued for it elsewhere
+    for (int k = 0; k < done_front && st == GDCA_OK; ++k) {
+        ctxs[k]->stream = use[k];
+        st = run_score(ctxs[k], p, S_dev[k]);
+        // the members' collects synchronise THEIR stream: make it wait for the stream the member's work went to (one event per member)
+        if (st == GDCA_OK && use[k] != own[k] &&
+            (hipEventRecord(ctxs[k]->ev_batch, use[k]) != hipSuccess || hipStreamWaitEvent(own[k], ctxs[k]->ev_batch, 0) != hipSuccess))
+            chained = false;
+    }
     if (st != GDCA_OK) {
         // a member failed to enqueue (allocation, launch): drain what was enqueued -- the batch's stream AND every member's own
         // stream -- and leave nobody half-pending.  The failing member's message goes to the leader, whose last_error the caller reads.
@@ -1071,16 +1102,12 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
         }
     }
     for (int k = 0; k < K; ++k) ctxs[k]->stream = own[k];
-    // the members' collects synchronise THEIR stream: make it wait for the leader's (one event per member)
-    if (st == GDCA_OK)
-        for (int k = 1; k < K; ++k) {
-            if (hipEventRecord(ctxs[k]->ev_batch, lead->stream) != hipSuccess ||
-                hipStreamWaitEvent(own[k], ctxs[k]->ev_batch, 0) != hipSuccess) {
-                // the chain could not be built: the members' collects would not wait for the batch -- wait for it here instead
-                (void)hipStreamSynchronize(lead->stream);
-                return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
-            }
-        }
+    if (st == GDCA_OK && !chained) {
+        // the chain could not be built: the members' collects would not wait for the batch -- wait for it here instead
+        (void)hipStreamSynchronize(lead->stream);
+        for (int j = 1; j < W; ++j) (void)hipStreamSynchronize(own[j]);
+        return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
+    }
     return st;
 }
 

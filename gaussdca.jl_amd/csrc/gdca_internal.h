@@ -53,6 +53,7 @@ struct gdca_tuning {
     int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
     int phased_fronts;      // GDCA_PHASED_FRONTS: 1 = the front ends of a phase batch run side by side on the members' own streams (default), 0 = one after the other on the leader's
+    int phased_streams;     // GDCA_PHASED_STREAMS: streams the side-by-side front ends and score stages of a phase batch are spread over (the first members' own; default 4 = the hardware queues)
     int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
     double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: the a-priori bound of cond_2(C) first, beyond it kappa_1 = ||C||_1 ||X||_1
     int cholesky;           // GDCA_CHOLESKY: the blocked dpotrf + dpotri fallback: 0 = never, 1 = where the sweep gave up (default), 2 = always
@@ -127,6 +128,8 @@ void gdca_launch_copy_in(hipStream_t s, const double *src, int n, double *dst, i
 void gdca_launch_copy_in_neg(hipStream_t s, const double *src, int n, double *dst, int n_pad);
 // dst (n x n, ld n) = full symmetric  -lower(A)  (A holds -inverse in its lower triangle)
 void gdca_launch_copy_out_neg_sym(hipStream_t s, const double *A, int n_pad, double *dst, int n);
+// *host_mapped (pinned host memory, the device's address of it) = *sc, system-scope visible when the kernel has completed
+void gdca_launch_publish_scalars(hipStream_t s, const gdca_dev_scalars *sc, gdca_dev_scalars *host_mapped);
 // D[i] (s x s, packed) = diagonal block i of C (ld)
 void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int N, int sdim, double *D);
 
@@ -140,6 +143,7 @@ struct gdca_inverse_ws {
     unsigned *flags;   // dependency flags of the sweep (zeroed per inverse by the launcher)
     size_t flags_bytes;
     int *item0_host;   // pinned: first work item of every group's sequence in the main list and in the M list (2 x (n_pad / 128 + 2) entries)
+    const int *item0_host_dev;  // item0_host as the device addresses it (nullptr: the table goes through hipMemcpyAsync)
     int *item0_dev;
     int update_cus;    // compute units of the device
 };

@@ -146,3 +146,20 @@ void gdca_launch_save_diag_blocks(hipStream_t s, const double *C, size_t ld, int
 {
     hipLaunchKernelGGL(k_save_diag_blocks, dim3(N), dim3(256), 0, s, C, ld, N, sdim, D);
 }
+
+// The run's scalars into the context's pinned host copy, as the LAST kernel of an enqueued run: gdca_run_collect then needs a stream
+// synchronisation and nothing else.  (A device-to-host hipMemcpyAsync of these 200 bytes is a blit KERNEL of the runtime's: issued
+// at collect time it queued behind whatever persistent sweep another context of the pipeline had resident -- the collect of batch
+// b-1 returned when the sweep of batch b ended, and only then did the host start to enqueue batch b+1:
+// profiles/r05_B_merged8_timeline.log.)
+__global__ __launch_bounds__(64) void k_publish_scalars(const unsigned *__restrict__ src, unsigned *__restrict__ dst_host, int words)
+{
+    for (int i = threadIdx.x; i < words; i += 64) dst_host[i] = src[i];
+    __threadfence_system();
+}
+
+void gdca_launch_publish_scalars(hipStream_t s, const gdca_dev_scalars *sc, gdca_dev_scalars *host_mapped)
+{
+    static_assert(sizeof(gdca_dev_scalars) % 4 == 0, "copied as 32-bit words");
+    hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, (const unsigned *)sc, (unsigned *)host_mapped, (int)(sizeof(gdca_dev_scalars) / 4));
+}

@@ -2433,7 +2433,30 @@ int gdca_inverse_max_merge(void)
 // Host side: the schedule of one inverse -- group sizes, the item table (written to the job's pinned staging buffer and sent to
 // the device on s0), the flags (zeroed on s0), the descriptor.  `merged`: the inverse is a member of a merged launch of
 // `members` families (single-block groups, chain CUs from the merge rule, no trace).
+// what a launch has to put in place for one inverse before its workgroups start: the flags zeroed, the item table on the device
+struct SweepPrepOne {
+    unsigned *flags;
+    unsigned flag_words;
+    const int *items_host;  // pinned host memory, as the device addresses it
+    int *items_dev;
+    int n_items;
+};
+struct SweepPrep {
+    SweepPrepOne fam[SWEEP_MAX_MERGE];
+    int K;
+};
+// ONE small launch for all members instead of a hipMemcpyAsync and a hipMemsetAsync of the runtime's per member (sixteen operations of
+// ~12 us each in front of a merged launch of eight: 190 us of a 3.6-ms launch, profiles/r05_B_merged8_timeline.log)
+__global__ __launch_bounds__(256) void k_sweep_prep(const SweepPrep P)
+{
+    const SweepPrepOne &f = P.fam[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < f.flag_words; i += gridDim.x * 256u) f.flags[i] = 0u;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < f.n_items; i += 256) f.items_dev[i] = f.items_host[i];
+}
+
 struct SweepPlan {
+    SweepPrepOne prep;
     SweepDesc D;
     int g;
     long long mpos;
@@ -2530,10 +2553,12 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     }
     it[ng] = (int)pos;
     mit[ng] = (int)mpos;
-    (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)3 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
-    (void)hipMemsetAsync(ws.flags, 0, ws.flags_bytes, s0);
-
     SweepPlan P{};
+    P.prep = SweepPrepOne{ws.flags, (unsigned)(ws.flags_bytes / sizeof(unsigned)), ws.item0_host_dev, ws.item0_dev, 3 * (ng + 1)};
+    if (!ws.item0_host_dev) {  // (no device address for the pinned table: the runtime's copy, and the prep kernel only clears)
+        (void)hipMemcpyAsync(ws.item0_dev, it, (size_t)3 * (ng + 1) * sizeof(int), hipMemcpyHostToDevice, s0);
+        P.prep.n_items = 0;
+    }
     SweepDesc &D = P.D;
     D.A = job.A;
     D.ld = (size_t)n_pad;
@@ -2611,6 +2636,12 @@ void gdca_launch_spd_inverse(hipStream_t s0, const gdca_inverse_job &job, hipEve
                              double *upd_flops)
 {
     SweepPlan P = plan_sweep(s0, job, false, 1);
+    {
+        SweepPrep prep{};
+        prep.K = 1;
+        prep.fam[0] = P.prep;
+        hipLaunchKernelGGL(k_sweep_prep, dim3(16, 1), dim3(256), 0, s0, prep);
+    }
     SweepDesc &D = P.D;
     const int ng = D.ng;
     const long long mpos = P.mpos;
@@ -2646,15 +2677,19 @@ void gdca_launch_spd_inverse_merged(hipStream_t s0, const gdca_inverse_job *jobs
 {
     SweepBatch B{};
     B.K = K;
+    SweepPrep prep{};
+    prep.K = K;
     int cus = 0;
     bool multi = false;
     for (int k = 0; k < K; ++k) {
         SweepPlan P = plan_sweep(s0, jobs[k], true, K);
         B.fam[k] = P.D;
+        prep.fam[k] = P.prep;
         multi = multi || P.g > 1;
         if (upd_flops) upd_flops[k] = 2.0 * T * T * KC * P.chunks;
         cus = std::max(cus, jobs[k].ws.update_cus);
     }
+    hipLaunchKernelGGL(k_sweep_prep, dim3(16, (unsigned)K), dim3(256), 0, s0, prep);
     const unsigned grid = (unsigned)(2 * cus);
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);

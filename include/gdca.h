@@ -147,7 +147,7 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
  * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS, PHASED_FRONTS (1: the front ends of a phase batch run side by side on the
- * members' own streams, 0: one after the other); REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
+ * members' streams, 0: one after the other), PHASED_STREAMS (how many of those streams, the first members', they are spread over: default 4); REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
  * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6); CHOLESKY (0 | 1 | 2: the blocked
  * dpotrf + dpotri fallback never / where the sweep gave up [default] / for every inverse).  The schedule switches change results
  * at rounding level at most (another summation order); REFINE improves an ill-conditioned inverse.  GDCA_EINVAL: unknown key

@@ -440,7 +440,8 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
             # the four small members shared ONE merged sweep launch (its first member accounts for it), N = 430 had its own
             assert [st_["inverse_batch"] for st_ in sts] == [4, 4, 4, 1, 4] and sum(st_["update_launches"] for st_ in sts) == 2
         # MERGE_GROUP=1 (single-block groups in merged launches too): bit for bit the launches of their own, for members up to 48 blocks
-        cs[0].set_options(MERGE_GROUP=1)
+        # (... and the front ends on two streams instead of four, then on one per member: the same bits)
+        cs[0].set_options(MERGE_GROUP=1, PHASED_STREAMS=2 if score == 0 else 64)
         outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
         g.run_dev_phased(cs, [zd.data_ptr() for zd in Zd], [z.shape[1] for z in fams], [z.shape[0] for z in fams],
                          [21] * len(fams), pc, -1.0, score, [x.data_ptr() for x in outs])
@@ -448,7 +449,7 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
             c.collect()
         for k in range(len(cs)):
             assert torch.equal(outs[k].cpu(), ref[k]), (score, "group 1", k)
-        cs[0].set_options(MERGE_GROUP=-1)
+        cs[0].set_options(MERGE_GROUP=-1, PHASED_STREAMS=4)
         with pytest.raises(g.ArgumentError):
             g.run_dev_phased([cs[0], cs[0]], [Zd[0].data_ptr()] * 2, [40] * 2, [500] * 2, [21] * 2, pc, -1.0, score,
                              [outs[0].data_ptr()] * 2)               # the same context twice
