@@ -467,13 +467,13 @@ int run_batch(const Options &o)
         // uploaded and enqueued while the previous one computes; they are created when the first small family shows up -- as peers
         // of the pipeline's leader: ONE gate orders every SPD inverse of this GPU, single or merged (two persistent sweep launches
         // that become resident side by side can wait for each other's workgroups until the watchdog ends them).
-        // OFF by default (--merge 1).  Measured on one MI355X (profiles/r04_cli_merge.log): 96 families of config B's size run at
-        // 630-650 families/s in steady state through the slots' pipeline and at 650-660 through merged batches of eight -- the
-        // worker thread's uploads, ~60 launches per family and collects bound both -- while creating the sixteen extra contexts
-        // costs 0.25 s; on the mixed batch of configuration E merged batches lose 2-4 % (the phase-batched front ends are slower
-        // than pipelined ones).  The merged sweep pays where the caller keeps data on the device
-        // (gdca_run_dev_phased: 1.55 -> 1.19 ms per family at config B); here it is an option for batches of tiny families
-        // on hosts with faster cores.
+        // OFF by default (--merge 1): a member of a merged launch sweeps in larger pivot groups than a launch of its own, so its
+        // scores agree with the one-by-one path to rounding (1e-13), not bit for bit.  Measured on one MI355X, round 5
+        // (profiles/r05_cli_merge.log): 96 families of config B's size run at 661-665 families/s in steady state through the slots'
+        // pipeline and at **1231-1243 through merged batches of eight** (round 4: 630-650 against 650-660 -- until the contexts
+        // lost their side streams and the collects their blit kernels, DESIGN.md section 5, the worker thread's launches and collects
+        // bound both); creating the sixteen extra contexts costs ~0.1 s once.  On the mixed batch of configuration E merged batches
+        // neither gain nor lose (72.4-72.8 against 72.8 families/s).  --merge 8 is the setting for batches of small families.
         const int SMALL_BLOCKS = o.merge_blocks;
         struct Set {
             std::vector<Slot> mem;
