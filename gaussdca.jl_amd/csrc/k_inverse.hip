@@ -2481,7 +2481,12 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     // A member of a merged launch: its chain hides behind the other members' tile items, so what counts is the traffic of the C
     // tiles -- groups of four from 24 blocks, of two from 12 (option GDCA_MERGE_GROUP forces a size).
     const int g_merged = tu.merge_group >= 1 ? std::min(tu.merge_group, 4) : (nblk >= 24 ? 4 : (nblk >= 12 ? 2 : 1));
-    int g = merged ? g_merged : (tu.group >= 1 ? std::min(tu.group, 4) : (nblk >= 58 ? 4 : (nblk >= 55 ? 3 : (nblk >= 49 ? 2 : 1))));
+    // Round 5 measured the final kernel again, every block count from 44 to 77, the four sizes alternating inside one process, twice in
+    // opposite order (tools/option_probe.py, profiles/r05_group_rule.log; the two passes agree to 1 %): 1 up to 46 blocks, 2 up to 53, 3 up to
+    // 59 -- but 4 at 57, whose remainder a ramp of 1, 2, 3 absorbs --, 4 from 60 (rounds 3-4: 2 from 49, 3 from 55, 4 from 58; 3-4 % at
+    // 47, 48, 54, 58 and 59 blocks, 2 % at 57).
+    const int g_rule = nblk >= 60 || nblk == 57 ? 4 : (nblk >= 54 ? 3 : (nblk >= 47 ? 2 : 1));
+    int g = merged ? g_merged : (tu.group >= 1 ? std::min(tu.group, 4) : g_rule);
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
     // every workgroup waits ~400 us (2 % of the inverse at n = 10 000) for the first super-block inverse.  So the sweep opens

@@ -341,7 +341,7 @@ def _read_rank(path):
 def test_batch_driver_merges_small_families(g, ctx, tmp_path):
     """`gdca_cli --batch --merge 8 --merge-blocks 57` sends families with a covariance of at most 57 blocks through
     gdca_run_ranked_phased_async, up to eight at a time, their SPD inverses sharing launches of the sweep kernel.  20 small families (1 to 45 blocks, ragged sizes) and two big
-    ones in one directory: (a) with GDCA_MERGE_GROUP=1 (single-block groups: the schedule a launch of its own runs up to 48 blocks)
+    ones in one directory: (a) with GDCA_MERGE_GROUP=1 (single-block groups: the schedule a launch of its own runs up to 46 blocks)
     every ranking file is byte-identical to the unmerged driver's (`--merge 1`); (b) with the default grouping the same pairs come
     out with scores equal to the file's seven digits or one unit of the last one."""
     from gaussdca.jl_amd import synth
