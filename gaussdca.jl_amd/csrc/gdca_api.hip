@@ -110,7 +110,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
     struct { const char *name; int *field; long lo, hi; } ints[] = {
         {"GROUP", &t->group, -1, 4},        {"RAMP", &t->ramp, 0, 1},          {"RAGGED", &t->ragged, 0, 1},
         {"REM_TAIL", &t->rem_tail, -1, 1 << 20}, {"PANEL_HALVES", &t->panel_halves, -1, 1}, {"SLAB", &t->slab, 0, 1},
-        {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 16},        {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
+        {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 32},        {"MCU_SOLO", &t->mcu_solo, -1, 1},       {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
         {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
@@ -155,6 +155,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->slab = 1;
     t->ring = 8;
     t->mcus = -1;
+    t->mcu_solo = -1;
     t->hamming_mode = -1;
     t->merge = 8;
     t->merge_blocks = 57;
@@ -169,7 +170,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_STREAMS"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_STREAMS", "GDCA_MCU_SOLO"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }

@@ -42,6 +42,7 @@ struct gdca_tuning {
     int slab;               // GDCA_SLAB: 0 = panel and tile items between single blocks instead of the fused row slabs
     int ring;               // GDCA_RING: panel / Pg slots between single blocks (2..8)
     int mcus;               // GDCA_MCUS: compute units elected for the pivot chain (1..16)
+    int mcu_solo;           // GDCA_MCU_SOLO: 1 = one chain worker per elected compute unit (its second workgroup leaves; MCUS then counts up to 32), 0 = two, -1 = the measured rule (groups of two and three)
     int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected
     long sweep_timeout_ms;  // GDCA_SWEEP_TIMEOUT_MS: bound of one dependency wait; 0 = scaled with the problem (>= 4 s)
     int tally_tj;           // GDCA_TALLY_TJ: 32 = the wide pair-tally form

@@ -959,7 +959,8 @@ struct SweepDesc {
     int pro;               // main list: the first `pro` items are panel(0); group p's sequence follows at pro + item0[p]
     int rem_tail;          // remainder tiles of update p that are listed AFTER panel(p+1)
     int ppb;               // main-list panel items per pivot block and row: 2 (128 x 64 each) or 1 (128 x 128)
-    int n_mcu;             // compute units to elect for the M list (<= 16)
+    int n_mcu;             // compute units to elect for the M list (<= 16; <= 32 with mcu_solo)
+    int mcu_solo;          // one chain worker per elected compute unit: its second workgroup leaves the launch at once (GDCA_MCU_SOLO)
     int ring;              // Pg / panel buffers per kind: 2 (group parity) or 8 (single-block groups), see ring_panel
     int slab;              // single-block groups: the next pivot row's panel and diagonal tile as SLAB_ITEMS fused row-slab items (0: off)
     unsigned *sl;          // [3 ng] slab items of group p done (row b0 + 1), its xslab items, its slab items of row b0 + 2
@@ -2194,7 +2195,10 @@ __device__ __forceinline__ int sweep_elect(int K)
         if (old == 0u || old == xcc + 1u) {
             for (int k = 0; k < Df.n_mcu; ++k) {
                 const unsigned o2 = atomicCAS(Df.mcu + k, 0u, key);
-                if (o2 == 0u || o2 == key) return f;
+                if (o2 == 0u) return f;
+                // the OTHER workgroup of an elected compute unit: a chain worker too -- or (GDCA_MCU_SOLO) nobody: it leaves, and the
+                // chain's items have the unit's SIMDs, LDS and L1 to themselves
+                if (o2 == key) return Df.mcu_solo ? -2 - f : f;
             }
         }
     }
@@ -2220,6 +2224,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         sw_item = sweep_elect(1);
     }
     __syncthreads();
+    if (sw_item <= -2) return;  // (GDCA_MCU_SOLO: the second workgroup of a chain compute unit)
     const bool m_worker = sw_item >= 0;
     // the clock this launch really ran at (the governor moves it between 1.7 and 2.4 GHz, and not every XCD need run at the
     // same one): every workgroup times itself, the sums give the workgroup-time-weighted average over the chip
@@ -2420,7 +2425,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
 size_t gdca_inverse_flag_bytes(int n_pad)
 {
     const size_t nblk = (size_t)(n_pad / T);
-    // gen, rb (ng <= nblk), mc, done, sl | next, next_m, mcu[16], mxcc | the abort word on a 128-byte line of its own (every wait
+    // gen, rb (ng <= nblk), mc, done, sl | next, next_m, mxcc, arrived, mcu[32] | the abort word on a 128-byte line of its own (every wait
     // of the kernel reads it; the line of the item counters is busy with atomics)
     return (nblk * nblk + nblk * nblk + 5 * nblk + 96) * sizeof(unsigned);
 }
@@ -2483,9 +2488,10 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     const int g_merged = tu.merge_group >= 1 ? std::min(tu.merge_group, 4) : (nblk >= 24 ? 4 : (nblk >= 12 ? 2 : 1));
     // Round 5 measured the final kernel again, every block count from 44 to 77, the four sizes alternating inside one process, twice in
     // opposite order (tools/option_probe.py, profiles/r05_group_rule.log; the two passes agree to 1 %): 1 up to 46 blocks, 2 up to 53, 3 up to
-    // 59 -- but 4 at 57, whose remainder a ramp of 1, 2, 3 absorbs --, 4 from 60 (rounds 3-4: 2 from 49, 3 from 55, 4 from 58; 3-4 % at
-    // 47, 48, 54, 58 and 59 blocks, 2 % at 57).
-    const int g_rule = nblk >= 60 || nblk == 57 ? 4 : (nblk >= 54 ? 3 : (nblk >= 47 ? 2 : 1));
+    // 59, 4 from 60 (rounds 3-4: 2 from 49, 3 from 55, 4 from 58; 3-4 % at 47, 48, 54, 58 and 59 blocks) ...
+    // ... and once more with one chain worker per compute unit for groups of two and three (below, profiles/r05_group_rule.log, second
+    // part): 1 up to 44 blocks, 2 up to 52, 3 up to 60, 4 from 61.
+    const int g_rule = nblk >= 61 ? 4 : (nblk >= 53 ? 3 : (nblk >= 45 ? 2 : 1));
     int g = merged ? g_merged : (tu.group >= 1 ? std::min(tu.group, 4) : g_rule);
     if (nblk < 2 * g) g = 1;
     // group sizes.  Before the first update there is nothing to hide the first chain behind: with full groups from the start
@@ -2591,9 +2597,9 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     f += 3 * ng;
     D.next = f;
     D.next_m = f + 1;
-    D.mcu = f + 2;
     D.mxcc = f + 18;
     D.arrived = f + 19;
+    D.mcu = f + 20;  // 32 slots
     D.abort = f + 64;
     // bound of one dependency wait (GDCA_SWEEP_TIMEOUT_MS; a healthy wait is microseconds).  By default it grows with the work the
     // launch holds: the early workgroups of a launch that starts behind another one (two contexts in flight on one GPU, another
@@ -2621,7 +2627,15 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     const int mcu_rule = g == 1 ? (nblk < 28 ? 12 : 8) : (nblk <= 63 ? 16 : (nblk <= 68 ? 12 : (nblk <= 74 ? 10 : (nblk <= 90 ? 6 : (nblk <= 120 ? 4 : 2)))));
     // a member of a merged launch: its own rule unless that would hand more than an eighth of the chip to the chains
     const int mcu_merged = tu.merge_mcus >= 1 ? tu.merge_mcus : std::min(mcu_rule, std::max(2, ws.update_cus / (8 * std::max(1, members))));
-    D.n_mcu = merged ? std::min(mcu_merged, 16) : (tu.mcus >= 1 ? std::min(tu.mcus, 16) : mcu_rule);
+    // One chain worker per elected compute unit (its second workgroup leaves the launch at once) for groups of two and three: there a
+    // pivot shared its SIMDs with a K = 256 / 384 panel or tile item of the M list on the unit's other workgroup.  Round 5, every block
+    // count from 47 to 76 with alternating settings (profiles/r05_mcu_solo.log): 12 such units for groups of two (47-53 blocks: 2-12 %
+    // faster than 16 units with two workers each), 16 for groups of three (54-56 blocks 3-8 %, 58-59 1 %); groups of four and the
+    // fused slab items between single blocks gain nothing (and lose workers), a merged launch's members keep both.
+    const bool solo = !merged && (tu.mcu_solo >= 0 ? tu.mcu_solo != 0 : (g == 2 || g == 3));
+    D.mcu_solo = solo ? 1 : 0;
+    const int mcu_solo_rule = g == 2 ? 12 : 16;
+    D.n_mcu = merged ? std::min(mcu_merged, 16) : (tu.mcus >= 1 ? std::min(tu.mcus, solo ? 32 : 16) : (solo && tu.mcu_solo < 0 ? mcu_solo_rule : mcu_rule));
     D.n_real = n_real;
     D.rl = rl;
     D.sc = job.sc;

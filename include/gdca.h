@@ -142,7 +142,7 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
 /* Tuning switch of THIS context (no process-global state: a context reads the GDCA_* environment variables once, when it is
  * created; afterwards only this call changes them, and two contexts of one process may differ).  key = the variable's name with
  * or without the GDCA_ prefix, any case; value = what the variable would hold.  Schedule of the SPD inverse: GROUP (1..4, -1 = the
- * measured rule), RAMP, RAGGED, REM_TAIL, PANEL_HALVES, SLAB, RING, MCUS; SWEEP_TIMEOUT_MS (bound of one dependency wait inside
+ * measured rule), RAMP, RAGGED, REM_TAIL, PANEL_HALVES, SLAB, RING, MCUS, MCU_SOLO; SWEEP_TIMEOUT_MS (bound of one dependency wait inside
  * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
  * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in

@@ -439,7 +439,7 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
                 assert sts[k]["ms_inverse"] > 0 and sts[k]["sweep_ghz"] > 1.0
             # the four small members shared ONE merged sweep launch (its first member accounts for it), N = 430 had its own
             assert [st_["inverse_batch"] for st_ in sts] == [4, 4, 4, 1, 4] and sum(st_["update_launches"] for st_ in sts) == 2
-        # MERGE_GROUP=1 (single-block groups in merged launches too): bit for bit the launches of their own, for members up to 46 blocks
+        # MERGE_GROUP=1 (single-block groups in merged launches too): bit for bit the launches of their own, for members up to 44 blocks
         # (... and the front ends on two streams instead of four, then on one per member: the same bits)
         cs[0].set_options(MERGE_GROUP=1, PHASED_STREAMS=2 if score == 0 else 64)
         outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]

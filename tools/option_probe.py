@@ -11,7 +11,7 @@ from gaussdca.jl_amd import synth
 Ns = [int(x) for x in sys.argv[1].split(",")]
 combos = [dict(kv.split("=") for kv in c.split(",") if kv) for c in sys.argv[2].split(";")]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-DEFAULTS = {"GROUP": "-1", "MCUS": "-1", "REM_TAIL": "-1", "PANEL_HALVES": "-1", "RAMP": "1", "RING": "8", "RAGGED": "1"}
+DEFAULTS = {"GROUP": "-1", "MCUS": "-1", "REM_TAIL": "-1", "PANEL_HALVES": "-1", "RAMP": "1", "RING": "8", "RAGGED": "1", "MCU_SOLO": "-1"}
 ctx = g.Context(0)
 print("ms_inverse min / median; combos: " + " | ".join(",".join("%s=%s" % kv for kv in c.items()) or "default" for c in combos))
 for N in Ns:
