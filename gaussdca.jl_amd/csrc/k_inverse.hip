@@ -2632,6 +2632,7 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     // count from 47 to 76 with alternating settings (profiles/r05_mcu_solo.log): 12 such units for groups of two (47-53 blocks: 2-12 %
     // faster than 16 units with two workers each), 16 for groups of three (54-56 blocks 3-8 %, 58-59 1 %); groups of four and the
     // fused slab items between single blocks gain nothing (and lose workers), a merged launch's members keep both.
+    // (a merged launch's members: tried, no effect -- config B eight to a launch 0.444 against 0.448 ms per family)
     const bool solo = !merged && (tu.mcu_solo >= 0 ? tu.mcu_solo != 0 : (g == 2 || g == 3));
     D.mcu_solo = solo ? 1 : 0;
     const int mcu_solo_rule = g == 2 ? 12 : 16;
