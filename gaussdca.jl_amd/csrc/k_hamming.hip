@@ -418,6 +418,9 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int
     // the context option GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a
     // sample of tiles
     const int nprobe = (int)std::min<long long>(ntile, 192);
+    // (alignments of at most 64 columns -- two words per plane -- go to the exact form unprobed: the bound saves two instructions per
+    // word and costs a list and a second kernel; N = 64, M = 20 000: 0.136 ms against 0.200, profiles/r05_option_probes.log)
+    if (force < 0 && NW <= 2) force = 0;
     if (force < 0 && ntile >= 64) {
         hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
         hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1);

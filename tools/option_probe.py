@@ -1,6 +1,6 @@
 """Inverse-stage time over alignment lengths N for combinations of context options, ONE process and context (the options of a
 context take effect at its next call), alternating the combinations inside every repetition so that clock drift hits them alike.
-usage: option_probe.py N,N,... "KEY=V,KEY=V;KEY=V;..." [reps]   (an empty combination = the defaults)
+usage: option_probe.py N,N,... "KEY=V,KEY=V;KEY=V;..." [reps [stat [M]]]   (an empty combination = the defaults)
 Prints min and median ms_inverse per (N, combination) and whether the scores are bit-identical with the first combination's."""
 import os, sys
 import numpy as np
@@ -11,11 +11,14 @@ from gaussdca.jl_amd import synth
 Ns = [int(x) for x in sys.argv[1].split(",")]
 combos = [dict(kv.split("=") for kv in c.split(",") if kv) for c in sys.argv[2].split(";")]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-DEFAULTS = {"GROUP": "-1", "MCUS": "-1", "REM_TAIL": "-1", "PANEL_HALVES": "-1", "RAMP": "1", "RING": "8", "RAGGED": "1", "MCU_SOLO": "-1"}
+stat = sys.argv[4] if len(sys.argv) > 4 else "ms_inverse"     # the stage time to report (ms_weights, ms_covariance, ms_total ...)
+Mseq = int(sys.argv[5]) if len(sys.argv) > 5 else 3000        # sequences per family
+DEFAULTS = {"GROUP": "-1", "MCUS": "-1", "REM_TAIL": "-1", "PANEL_HALVES": "-1", "RAMP": "1", "RING": "8", "RAGGED": "1", "MCU_SOLO": "-1",
+            "TALLY_TJ": "0", "HAMMING_MODE": "auto"}
 ctx = g.Context(0)
-print("ms_inverse min / median; combos: " + " | ".join(",".join("%s=%s" % kv for kv in c.items()) or "default" for c in combos))
+print(stat + " min / median; combos: " + " | ".join(",".join("%s=%s" % kv for kv in c.items()) or "default" for c in combos))
 for N in Ns:
-    Z = np.asfortranarray(synth.synth_family(N, 3000, 21, 7 + N).T)
+    Z = np.asfortranarray(synth.synth_family(N, Mseq, 21, 7 + N).T)
     t = [[] for _ in combos]
     ref, same = None, []
     for rep in range(reps + 1):
@@ -28,6 +31,6 @@ for N in Ns:
                     ref = S.copy()
                 same.append(bool(np.array_equal(S, ref)) or float(np.max(np.abs(S - ref))))
             else:
-                t[ci].append(st["ms_inverse"])
+                t[ci].append(st[stat])
     nblk = -(-N * 20 // 128)
     print("N %4d nblk %3d " % (N, nblk) + "  ".join("%7.3f/%7.3f" % (min(x), float(np.median(x))) for x in t) + "   same: %s" % same, flush=True)
