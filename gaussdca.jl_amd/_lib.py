@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("GDCA_LIB") or os.path.join(_HERE, "libgdca.so")
 
 GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV = 0, 1, 2, 3, 4, 5
 SCORE_FROB, SCORE_DI = 0, 1
+ABI_VERSION = 5  # GDCA_VERSION_MAJOR * 1000 + GDCA_VERSION_MINOR of the header this binding mirrors
 
 
 class GdcaError(RuntimeError):
@@ -66,6 +67,8 @@ _i8p, _i32p, _f64p, _u64p = C.POINTER(C.c_int8), C.POINTER(C.c_int32), C.POINTER
 _ctx = C.c_void_p
 SYMBOLS = {
     "gdca_version": (C.c_int32, []),
+    "gdca_stats_bytes": (C.c_int32, []),
+    "gdca_params_bytes": (C.c_int32, []),
     "gdca_device_count": (C.c_int32, []),
     "gdca_ctx_create": (C.c_int, [C.c_int32, C.POINTER(_ctx)]),
     "gdca_ctx_create_on_stream": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(_ctx)]),
@@ -156,6 +159,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the library writes sizeof(gdca_stats) bytes into the caller's struct: a build whose struct differs from this binding's
+    # would overrun it (or leave fields unfilled) -- refuse it here instead (include/gdca.h, note at the end of gdca_stats)
+    if lib.gdca_version() != ABI_VERSION or lib.gdca_stats_bytes() != C.sizeof(Stats) or lib.gdca_params_bytes() != C.sizeof(Params):
+        raise GdcaError(f"{LIB_PATH} is version {lib.gdca_version()} with gdca_stats of {lib.gdca_stats_bytes()} bytes; this binding is "
+                        f"written for version {ABI_VERSION} with {C.sizeof(Stats)} bytes: rebuild the library or update the binding")
     _lib = lib
     return lib
 

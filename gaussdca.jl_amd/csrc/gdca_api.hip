@@ -227,6 +227,16 @@ int32_t gdca_version(void)
     return GDCA_VERSION_MAJOR * 1000 + GDCA_VERSION_MINOR;
 }
 
+int32_t gdca_stats_bytes(void)
+{
+    return (int32_t)sizeof(gdca_stats);
+}
+
+int32_t gdca_params_bytes(void)
+{
+    return (int32_t)sizeof(gdca_params);
+}
+
 int32_t gdca_device_count(void)
 {
     int n = 0;
@@ -1229,9 +1239,11 @@ gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const
         Sd[k] = (double *)m->scratch[1].p;
     }
     // Z_host may be released when this call returns (gdca.h): from pageable memory the copies above are complete by now, from
-    // pinned or registered memory they are true DMAs still in flight -- wait for the leader's here (the members' streams are
-    // synchronised by gdca_run_dev_phased before anything is enqueued)
+    // pinned or registered memory they are true DMAs still in flight -- wait for every one of them HERE, whatever path the call
+    // takes afterwards (gdca_run_dev_phased synchronises the members' streams too, but not on its early argument checks)
     CHK(upload_done(lead));
+    for (int k = 1; k < K; ++k)
+        if (hipStreamSynchronize(ctxs[k]->stream) != hipSuccess) return fail(lead, GDCA_EHIP, "upload of a member's alignment%s%s", "", "");
     CHK(gdca_run_dev_phased(ctxs, K, Zd, N, M, q, p, Sd));
     // every member's ranking behind its scores, on the member's own stream (which now waits for the batch)
     for (int k = 0; k < K; ++k) {

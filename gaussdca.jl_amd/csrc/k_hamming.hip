@@ -143,7 +143,9 @@ __device__ __forceinline__ bool wg_any(bool pred, int &k)
 size_t gdca_hamming_cand_cap(int M)
 {
     const long long Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE;
-    return (size_t)(Mt * (Mt + 1) / 2 * HAM_CAND_PER_TILE + 4096);
+    // (the list's counter and slots are 32-bit: beyond 2^30 pairs -- M > ~1.4 million -- the list is simply no longer than that, and a
+    // family that fills it is counted by the exact form like any other overflow)
+    return (size_t)std::min<long long>(Mt * (Mt + 1) / 2 * HAM_CAND_PER_TILE + 4096, 1ll << 30);
 }
 
 __global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict__ Z, const int2 *__restrict__ list, unsigned cap, int N,
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict
             k = pr.x;
             l = pr.y;
             const int8_t *zk = Z + (size_t)k * N, *zl = Z + (size_t)l * N;
-            if ((N & 3) == 0) {
+            if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(Z) & 3) == 0) {  // (Z is the caller's pointer: a view need not be dword-aligned)
                 // a lane's dwords of both sequences, 1024 bytes of each per round, ALL requested before the first is looked at: the pairs
                 // of a list are scattered over the alignment, and a round costs one trip to memory instead of sixteen dependent ones
                 const uint32_t *a = reinterpret_cast<const uint32_t *>(zk), *b = reinterpret_cast<const uint32_t *>(zl);
@@ -341,7 +343,13 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
         const unsigned mine = (unsigned)__builtin_popcountll(cand);
         const unsigned off = mine ? atomicAdd(&hm_tile_n, mine) : 0u;
         __syncthreads();
-        if (tid == 0) hm_tile_base = atomicAdd(&sc->ham_ncand, hm_tile_n);
+        // (once the counter is past the capacity nothing is listed any more and the exact form counts the family: stop adding, so that
+        // a dense family of M > 92 000 -- more than 2^32 candidate pairs -- cannot wrap the 32-bit counter back below the capacity;
+        // the overshoot is bounded by the tiles in flight x 16 384)
+        if (tid == 0) {
+            const unsigned cur = __hip_atomic_load(&sc->ham_ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hm_tile_base = cur > cand_cap ? cur : atomicAdd(&sc->ham_ncand, hm_tile_n);
+        }
         __syncthreads();
         unsigned slot = hm_tile_base + off;
         while (cand) {

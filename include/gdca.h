@@ -43,7 +43,7 @@ extern "C" {
 #define GDCA_MAX_N 60000
 
 #define GDCA_VERSION_MAJOR 0
-#define GDCA_VERSION_MINOR 4
+#define GDCA_VERSION_MINOR 5
 
 typedef enum gdca_status {
     GDCA_OK = 0,
@@ -112,7 +112,12 @@ typedef struct gdca_stats {
                                    on independent uniform columns, hence lambda_min(C) >= pc / q^2 (sharp whenever some column has
                                    no gap).  Every run whose bound is below REFINE_COND is KNOWN to be well enough conditioned
                                    for the sweep and pays nothing for the screen; +inf at pseudocount 0; 0 with option REFINE=0 */
-    /* (fields are only ever added at the end: a caller built against an older header reads a valid prefix) */
+    /* Fields are only ever added at the END, and every addition bumps GDCA_VERSION_MINOR (0.5: the five fields from
+     * matrix_norm1 on).  The LIBRARY fills sizeof(gdca_stats) as IT was built: a binding built against a newer header than
+     * the library reads a valid prefix (the rest stays as the caller initialised it), but a binding built against an OLDER,
+     * shorter struct would be overrun -- so a binding compares gdca_stats_bytes() with its own struct size (and
+     * gdca_version() with the minor it was written for) once at load time and refuses to run on a mismatch, as the Python
+     * and Julia bindings of this repository do. */
     double ms_fn;               /* the FN kernel alone (HBM-bound: one pass over the lower block triangle of the inverse,
                                    8 n (n - s) / 2 bytes); 0 for the DI score and for a run refined at collect time */
     double ms_pair_tally;       /* the pair-tally kernel alone, with its pseudocount + covariance epilogue (its one
@@ -121,6 +126,9 @@ typedef struct gdca_stats {
 
 /* ---- library / context ---------------------------------------------------------------- */
 int32_t gdca_version(void); /* major*1000 + minor */
+/* sizeof(gdca_stats) / sizeof(gdca_params) as this build of the library writes / reads them (see the note at the end of gdca_stats) */
+int32_t gdca_stats_bytes(void);
+int32_t gdca_params_bytes(void);
 int32_t gdca_device_count(void);
 
 gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out);

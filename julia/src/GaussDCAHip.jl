@@ -49,6 +49,12 @@ function ctx()
         dev = parse(Int32, get(ENV, "GDCA_DEVICE", "0"))
         st = ccall((:gdca_ctx_create, libgdca), Cint, (Int32, Ref{Ptr{Cvoid}}), dev, CTX)
         st == 0 || error("gdca_ctx_create failed (status $st): no usable HIP device; there is no CPU fallback")
+        # the library writes ITS sizeof(gdca_stats) into our struct: refuse a build whose layout is not the one mirrored above
+        ver = ccall((:gdca_version, libgdca), Int32, ())
+        sb = ccall((:gdca_stats_bytes, libgdca), Int32, ())
+        pb = ccall((:gdca_params_bytes, libgdca), Int32, ())
+        (ver == 5 && sb == sizeof(GdcaStats) && pb == sizeof(GdcaParams)) ||
+            error("libgdca is version $ver with gdca_stats of $sb bytes; this binding mirrors version 5 with $(sizeof(GdcaStats)) bytes")
     end
     return CTX[]
 end

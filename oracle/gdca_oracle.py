@@ -240,6 +240,35 @@ def weights_from_counts(n: np.ndarray) -> Tuple[np.ndarray, float]:
     return W, Meff
 
 
+def meff_three_ways(W: np.ndarray) -> dict:
+    """The three candidate values of ``Meff = sum(W)`` (compute_weights, call site src/GaussDCA.jl:28), recorded side by side in
+    tests/golden/intermediates.json so that a box WITH Julia can tell which one DCAUtils returns (VERDICT r05 weak #1a):
+      exact          the sum in exact arithmetic rounded once (math.fsum) -- what this oracle and the HIP path (k_meff) return;
+      left_to_right  ((W[0] + W[1]) + W[2]) + ... in f64 -- rounds 1-4 of this repository;
+      pairwise_1024  the recursion of Julia's Base.mapreduce_impl (what ``sum(::Vector{Float64})`` runs): a range of at most 1024
+                     elements is summed in a loop, a longer one is split at ``mid = (first + last) >> 1`` and the halves' sums are added.
+                     Julia's base-case loop is ``@simd`` -- the compiler may keep several partial sums, how many depends on the
+                     machine's vector width -- so even this form pins the reference's last bit only up to that; the base case
+                     here is the plain left-to-right loop."""
+    w = [float(x) for x in np.asarray(W, dtype=np.float64)]
+    seq = 0.0
+    for x in w:
+        seq += x
+
+    def pw(first, last):  # inclusive, as Base.mapreduce_impl
+        if first == last:
+            return w[first]
+        if first + 1024 > last:
+            v = w[first] + w[first + 1]
+            for i in range(first + 2, last + 1):
+                v += w[i]
+            return v
+        mid = (first + last) >> 1
+        return pw(first, mid) + pw(mid + 1, last)
+
+    return {"exact": math.fsum(w), "left_to_right": seq, "pairwise_1024": pw(0, len(w) - 1) if w else 0.0}
+
+
 def compute_weights(Z: np.ndarray, theta) -> Tuple[np.ndarray, float, float, int]:
     """-> (W, Meff, theta_used, thresh).  theta may be 'auto' or a real in [0, 1]."""
     M, N = Z.shape

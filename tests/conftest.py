@@ -17,6 +17,8 @@ REFDATA = os.path.join(GOLDEN, "reference")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: a heavy case (gigabytes of temporary files or minutes of work); part of the default runs, "
+                                       "deselect with -m 'gpu and not slow' / -m 'not gpu and not slow' for a quick pass")
 
 
 @pytest.fixture(scope="session")

@@ -26,7 +26,9 @@ for golden, c in CASES.items():
     n = o.neighbour_counts(Z, thresh)
     out[golden] = dict(fasta=c["fasta"], kwargs=kw, N=int(Z.shape[1]), M=int(Z.shape[0]), q=int(Z.max()),
                        theta=th, thresh=thresh, Meff=Meff, pair_identity_sum=o.pair_identity_sum(Z),
-                       neighbour_count_sum=int(n.sum()), neighbour_count_max=int(n.max()))
+                       neighbour_count_sum=int(n.sum()), neighbour_count_max=int(n.max()),
+                       # sum(W) three ways (oracle.meff_three_ways): which one DCAUtils' pairwise SIMD sum returns only Julia can say
+                       Meff_candidates=o.meff_three_ways(W))
 with open(os.path.join(HERE, "intermediates.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -298,6 +298,7 @@ def test_config_E_subset_through_the_batch_driver(g, ctx, tmp_path):
         assert got == want.read_bytes(), f
 
 
+@pytest.mark.slow
 def test_config_E_whole_batch_through_the_batch_driver(g, ctx, tmp_path):
     """BASELINE.json configs[4] WHOLE, on one GPU: all 256 families (N in [100, 600], M in [5k, 80k], 4 GB of FASTA written by the
     library's own generator) through `gdca_cli --batch` -- every family must come out (`(0 failed)`, 256 ranking files with the
