@@ -10,6 +10,7 @@
 #include <strings.h>
 
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 #define MAX_EV 1024
 #define N_SCRATCH 10
@@ -61,6 +62,10 @@ struct gdca_ctx {
     hipEvent_t ev_batch, ev_upload;
     bool pending;
     bool pend_timed;
+    bool stamped;              // the run being enqueued marks its stages with device time stamps (sc->stamp) instead of HIP events: a member of a batch issued as batched grids
+    bool pend_inv_stamped;     // the enqueued run's inverse was a merged launch bracketed by stamps (slots 6 / 16 before, 17 / 4 behind) instead of events
+    bool pend_stamped;         // ... and the enqueued run did so: its collect reads the stamps
+    int pend_front_batch;      // members that shared this run's batched front-end / score grids (1: grids of its own); their stage times are the grids' divided by it
     bool pend_fn_timed, pend_tally_timed;  // events 7 / 8 around k_fn, 9 / 10 around k_pair_tally were recorded by this run
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
     int pend_batch;            // families that shared this run's SPD-inverse launch (1: a launch of its own)
@@ -71,6 +76,118 @@ struct gdca_ctx {
     hipEvent_t pend_upd_ev[2]; // the two events around that launch (this context's own, also for a merged launch)
     double pend_upd_flops;
 };
+
+// ---- batched grids: the recorder of gdca_launch.h, and the two stream operations of this file in recordable form ------------------
+gdca_recorder *&gdca_recorder::active()
+{
+    static thread_local gdca_recorder *r = nullptr;
+    return r;
+}
+
+void gdca_recorder::begin(hipStream_t s, int members)
+{
+    stream = s;
+    lists.assign((size_t)members, {});
+    cur = -1;
+    active() = this;
+}
+
+void gdca_recorder::add(const gdca_op &op)
+{
+    lists[(size_t)cur].push_back(op);
+    ++ops;
+}
+
+hipError_t gdca_recorder::flush()
+{
+    const int K = (int)lists.size();
+    std::vector<size_t> at((size_t)K, 0);
+    hipError_t err = hipSuccess;
+    const int keep = cur;
+    cur = -1;  // (the launchers below go out at once)
+    for (;;) {
+        int k0 = -1;
+        for (int k = 0; k < K; ++k)
+            if (at[k] < lists[k].size() && (k0 < 0 || at[k] < at[k0])) k0 = k;
+        if (k0 < 0) break;
+        // the kind at the head of the list of the member that has got least far, and every member whose head is of that kind
+        const gdca_op &h = lists[k0][at[k0]];
+        const gdca_op *grp[GDCA_MAXB];
+        int n = 0;
+        for (int k = 0; k < K && n < GDCA_MAXB; ++k) {
+            if (at[k] >= lists[k].size()) continue;
+            const gdca_op &o = lists[k][at[k]];
+            if (o.launch != h.launch || o.block.x != h.block.x || o.block.y != h.block.y || o.block.z != h.block.z) continue;
+            grp[n++] = &o;
+            ++at[k];
+        }
+        h.launch(stream, grp, n);
+        ++launches;
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    }
+    for (auto &l : lists) l.clear();
+    cur = keep;
+    return err;
+}
+
+hipError_t gdca_recorder::end()
+{
+    const hipError_t e = flush();
+    active() = nullptr;
+    cur = -1;
+    return e;
+}
+
+struct k_fill32_args {
+    unsigned *p;
+    unsigned v;
+    size_t words;
+};
+template <int CAP>
+__global__ __launch_bounds__(256) void k_fill32(const BatchArgs<k_fill32_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    unsigned *__restrict__ p = a_.p;
+    const unsigned v = a_.v;
+    const size_t words = a_.words;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+
+// hipMemsetAsync for buffers of whole 32-bit words; while the calling thread records a batch, a kernel of the batch
+void gdca_fill_async(hipStream_t s, void *p, int byte_value, size_t bytes)
+{
+    gdca_recorder *r = gdca_recorder::active();
+    if (!r || r->cur < 0 || s != r->stream || (bytes & 3) || ((uintptr_t)p & 3)) {
+        GDCA_FLUSH_RECORDED();
+        (void)hipMemsetAsync(p, byte_value, bytes, s);
+        return;
+    }
+    const size_t words = bytes / 4;
+    const unsigned v = (unsigned)(byte_value & 0xff) * 0x01010101u;
+    const unsigned grid = (unsigned)std::min<size_t>((words + 255) / 256, 1024);
+    if (grid) gdca_launch<k_fill32_args, k_fill32<1>, k_fill32<GDCA_MAXB>>(dim3(grid), dim3(256), 0, s, k_fill32_args{(unsigned *)p, v, words});
+}
+
+struct k_stamp_args {
+    gdca_dev_scalars *sc;
+    int slot, slot2;
+};
+template <int CAP>
+__global__ __launch_bounds__(64) void k_stamp(const BatchArgs<k_stamp_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    if (threadIdx.x == 0) {
+        const unsigned long long t = wall_clock64();
+        a_.sc->stamp[a_.slot] = t;
+        if (a_.slot2 >= 0) a_.sc->stamp[a_.slot2] = t;
+    }
+}
+
+void gdca_launch_stamp(hipStream_t s, gdca_dev_scalars *sc, int slot, int slot2)
+{
+    gdca_launch<k_stamp_args, k_stamp<1>, k_stamp<GDCA_MAXB>>(dim3(1), dim3(64), 0, s, k_stamp_args{sc, slot, slot2});
+}
 
 // ---- tuning switches: environment at context creation, gdca_ctx_set_option afterwards -----------------------------------------
 static bool parse_long(const char *v, long *out)
@@ -113,7 +230,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 32},        {"MCU_SOLO", &t->mcu_solo, -1, 1},       {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
-        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
+        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_GRIDS", &t->phased_grids, 0, 1}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -163,6 +280,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_group = -1;
     t->merge_tiles = 2300;
     t->phased_fronts = 1;
+    t->phased_grids = 1;
     t->phased_streams = 4;
     t->refine = -1;
     t->refine_cond = 1e6;
@@ -170,7 +288,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
                                         "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
-                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_STREAMS", "GDCA_MCU_SOLO"};
+                                        "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_GRIDS", "GDCA_PHASED_STREAMS", "GDCA_MCU_SOLO"};
     for (const char *nm : names)
         if (const char *v = getenv(nm)) (void)gdca_tuning_set(t, nm, v);  // an unusable value leaves the default
 }
@@ -385,6 +503,18 @@ static gdca_status need_events(gdca_ctx *ctx, int n)
     return GDCA_OK;
 }
 
+// A stage boundary of the run being enqueued: a HIP event of the context -- or, for a member of a batch whose kernels go out as
+// batched grids, a device time stamp written by a kernel of the batch (slot = the event's index: one launch stamps all members)
+static gdca_status mark(gdca_ctx *ctx, int slot)
+{
+    if (ctx->stamped) {
+        gdca_launch_stamp(ctx->stream, (gdca_dev_scalars *)ctx->sc.p, slot, -1);
+        return GDCA_OK;
+    }
+    HIPCHK(hipEventRecord(ctx->ev[slot], ctx->stream));
+    return GDCA_OK;
+}
+
 // a member's failure as the LEADER's last error (the caller of a batch entry reads the leader's)
 static gdca_status member_error(gdca_ctx *lead, gdca_ctx *m, int k, gdca_status st)
 {
@@ -418,7 +548,7 @@ static int round_up(int x, int m)
 
 // stage 1+2: theta, threshold, neighbour counts, W, Wfix, Meff  (all on device)
 static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, int q, double theta_in, int fixed_thresh,
-                                 bool want_theta_only, hipEvent_t ev_after_theta)
+                                 bool want_theta_only, int mark_after_theta)
 {
     hipStream_t s = ctx->stream;
     gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
@@ -427,13 +557,13 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
         gdca_launch_set_thresh(s, sc, fixed_thresh);
     } else {
         if (theta_in < 0.0) {
-            HIPCHK(hipMemsetAsync(ctx->hist.p, 0, (size_t)N * 32 * sizeof(uint32_t), s));
+            gdca_fill_async(s, ctx->hist.p, 0, (size_t)N * 32 * sizeof(uint32_t));
             gdca_launch_column_hist(s, Zd, (uint32_t *)ctx->hist.p, N, M);
         }
         gdca_launch_theta_finalize(s, (const uint32_t *)ctx->hist.p, N, M, theta_in, sc);
     }
     CHK(check_launch(ctx, "theta"));
-    if (ev_after_theta) HIPCHK(hipEventRecord(ev_after_theta, s));
+    if (mark_after_theta >= 0) CHK(mark(ctx, mark_after_theta));
     if (want_theta_only) return GDCA_OK;
 
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE;
@@ -443,7 +573,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     CHK(ensure(ctx, ctx->nk, (size_t)M * sizeof(int32_t)));
     CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t), s));
+    gdca_fill_async(s, ctx->hcnt.p, 0, (size_t)Mt * GDCA_HTILE * sizeof(int32_t));
     gdca_launch_bitplane_pack(s, Zd, (uint32_t *)ctx->Zb.p, N, M, q, sc);  // (also the symbol-range check)
     // option GDCA_FORCE_FALLBACK: the independent byte-compare kernel instead of the bit-sliced one -- the analogue of
     // DCAUTILS_FORCE_FALLBACK in the reference's tests (test/runtests.jl:78-86)
@@ -474,17 +604,17 @@ static gdca_status tally_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, in
     CHK(ensure(ctx, ctx->Pipc, (size_t)n * sizeof(double)));
     gdca_launch_transpose_i8(s, Zd, (int8_t *)ctx->Zt.p, N, M);
     gdca_launch_colblock(s, Zd, (int8_t *)ctx->Zp.p, N, M, TJ);
-    HIPCHK(hipMemsetAsync(ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long), s));
+    gdca_fill_async(s, ctx->Pifix.p, 0, (size_t)N * 32 * sizeof(unsigned long long));
     gdca_launch_pi_tally(s, Zd, (const unsigned long long *)ctx->Wfix.p, (unsigned long long *)ctx->Pifix.p, N, M, q,
                          (gdca_dev_scalars *)ctx->sc.p);
     gdca_launch_pi_finalize(s, (const unsigned long long *)ctx->Pifix.p, N, q, shift, Meff_dev, pc, Pi_true_out,
                             (double *)ctx->Pipc.p, want_norm1 ? &((gdca_dev_scalars *)ctx->sc.p)->pi_max : nullptr);
     const bool tm = want_norm1 && ctx->timing && ctx->n_ev >= 18;  // (the fused path's first build: its own device time, gdca_stats.ms_pair_tally)
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[9], s));
+    if (tm) CHK(mark(ctx, 9));
     gdca_launch_pair_tally(s, (const int8_t *)ctx->Zp.p, (const int8_t *)ctx->Zt.p,
                            (const unsigned long long *)ctx->Wfix.p, N, M, q, shift, Meff_dev, pc,
                            (const double *)ctx->Pipc.p, mode, out, ld, TJ);
-    if (tm) HIPCHK(hipEventRecord(ctx->ev[10], s));
+    if (tm) CHK(mark(ctx, 10));
     // ||C||_1 for the refinement screen, where the bound that costs nothing (2 N pi_max) does not settle it (k_cov_norm1)
     // (not even launched where the answer is known on the host: pi_max <= (1 - pc) + pc / q whatever the alignment)
     const double pi_cap = (1.0 - pc) + pc / (double)q;
@@ -584,9 +714,9 @@ static gdca_status score_stage(gdca_ctx *ctx, int N, int sdim, int n_pad, int sc
                        (double *)ctx->Tws.p, (gdca_dev_scalars *)ctx->sc.p);
     } else {
         const bool tm = time_fn && ctx->n_ev >= 18;  // (a timed fused run: gdca_stats.ms_fn)
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[7], s));
+        if (tm) CHK(mark(ctx, 7));
         gdca_launch_fn(s, (const double *)ctx->A.p, (size_t)n_pad, N, sdim, S_dev, ctx->ncu);
-        if (tm) HIPCHK(hipEventRecord(ctx->ev[8], s));
+        if (tm) CHK(mark(ctx, 8));
         if (time_fn) ctx->pend_fn_timed = tm;
     }
     if (apc) {
@@ -686,7 +816,7 @@ static gdca_status begin(gdca_ctx *ctx)
     CHK(not_pending(ctx));
     HIPCHK(hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->sc, sizeof(gdca_dev_scalars)));
-    HIPCHK(hipMemsetAsync(ctx->sc.p, 0, sizeof(gdca_dev_scalars), ctx->stream));
+    gdca_fill_async(ctx->stream, ctx->sc.p, 0, sizeof(gdca_dev_scalars));
     return GDCA_OK;
 }
 
@@ -774,32 +904,38 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->update_flops = ctx->pend_upd_flops;
         st->sweep_ghz = h.sweep_ticks ? (double)h.sweep_cycles / (double)h.sweep_ticks * 0.1 : 0.0;
         if (ctx->pend_timed) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[5]));
-            st->ms_total = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-            st->ms_theta = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2]));
-            st->ms_weights = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3]));
-            st->ms_covariance = ms;
+            // device time between two stage boundaries: HIP events of this context, or -- a run whose kernels went out as batched grids --
+            // the 100 MHz time stamps kernels of the batch wrote into its scalars (slot = the event's index)
+            bool tfail = false;
+            auto between = [&](int a, int b) -> double {
+                if (ctx->pend_stamped) return (double)(long long)(h.stamp[b] - h.stamp[a]) * 1e-5;
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) tfail = true;
+                return ms;
+            };
+            // (stages issued as batched grids carry the whole batch: a member reports its share, as for a merged inverse)
+            const double fshare = 1.0 / (double)(ctx->pend_front_batch > 0 ? ctx->pend_front_batch : 1);
+            st->ms_total = between(0, 5);
+            st->ms_theta = between(0, 1) * fshare;
+            st->ms_weights = between(1, 2) * fshare;
+            st->ms_covariance = between(2, 3) * fshare;
             // (a family whose inverse shared a merged launch with others reports its share of that launch: the launch's time
             // divided by the families it carried -- the sum over the members is the launch)
             const double share = 1.0 / (double)(ctx->pend_batch > 0 ? ctx->pend_batch : 1);
-            HIPCHK(hipEventElapsedTime(&ms, ev[6], ev[4]));  // from the start of its turn (after any pipeline gate)
-            st->ms_inverse = ms * share;
-            HIPCHK(hipEventElapsedTime(&ms, ev[11], ev[5]));
-            st->ms_score = ms;
-            HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
-            st->ms_inverse_update = ms * share;
-            if (ctx->pend_fn_timed && ctx->pend_refined == 0) {
-                HIPCHK(hipEventElapsedTime(&ms, ev[7], ev[8]));
-                st->ms_fn = ms;
+            st->ms_score = between(11, 5) * fshare;
+            if (ctx->pend_inv_stamped) {
+                st->ms_inverse = (double)(long long)(h.stamp[4] - h.stamp[6]) * 1e-5 * share;
+                st->ms_inverse_update = (double)(long long)(h.stamp[17] - h.stamp[16]) * 1e-5 * share;
+            } else {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, ev[6], ev[4]));  // from the start of its turn (after any pipeline gate)
+                st->ms_inverse = ms * share;
+                HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
+                st->ms_inverse_update = ms * share;
             }
-            if (ctx->pend_tally_timed && ctx->pend_refined == 0) {
-                HIPCHK(hipEventElapsedTime(&ms, ev[9], ev[10]));
-                st->ms_pair_tally = ms;
-            }
+            if (ctx->pend_fn_timed && ctx->pend_refined == 0) st->ms_fn = between(7, 8) * fshare;
+            if (ctx->pend_tally_timed && ctx->pend_refined == 0) st->ms_pair_tally = between(9, 10) * fshare;
+            if (tfail) return fail(ctx, GDCA_EHIP, "hipEventElapsedTime%s%s", "", "");
         }
     }
     if (h.bad_symbol) return fail(ctx, GDCA_EINVAL, "alignment holds a symbol outside 1..q%s%s", "", "");
@@ -837,12 +973,11 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
     const int sdim = q - 1, n = N * sdim, n_pad = round_up(n, GDCA_TILE);
     const bool timed = ctx->timing;
     if (timed) CHK(need_events(ctx, 18));
-    hipEvent_t *ev = ctx->ev;
     gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
 
-    if (timed) HIPCHK(hipEventRecord(ev[0], s));
-    CHK(weights_stage(ctx, Z_dev, N, M, q, p->theta, -1, false, timed ? ev[1] : nullptr));
-    if (timed) HIPCHK(hipEventRecord(ev[2], s));
+    if (timed) CHK(mark(ctx, 0));
+    CHK(weights_stage(ctx, Z_dev, N, M, q, p->theta, -1, false, timed ? 1 : -1));
+    if (timed) CHK(mark(ctx, 2));
 
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
     CHK(tally_stage(ctx, Z_dev, N, M, q, &sc->Meff, p->pseudocount, 1, nullptr, (double *)ctx->A.p, (size_t)n_pad, ctx->tune.refine != 0));
@@ -854,8 +989,10 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
         gdca_launch_diag_chol(s, (const double *)ctx->Dblk.p, N, sdim, (double *)ctx->Ld.p);
     }
     CHK(check_launch(ctx, "covariance"));
-    if (timed) HIPCHK(hipEventRecord(ev[3], s));
+    if (timed) CHK(mark(ctx, 3));
     ctx->pend_timed = timed;
+    ctx->pend_stamped = ctx->stamped;
+    ctx->pend_front_batch = 1;
     ctx->pend_tally_timed = timed && ctx->tune.refine != 0;
     ctx->pend_fn_timed = false;
     ctx->pend_Z = Z_dev;
@@ -890,11 +1027,28 @@ static gdca_status run_inverse(gdca_ctx *ctx)
     ctx->pend_nupd = n_upd;
     ctx->pend_upd_flops = upd_flops;
     ctx->pend_batch = 1;
+    ctx->pend_inv_stamped = false;
     if (timed) {
         ctx->pend_upd_ev[0] = ev[16];
         ctx->pend_upd_ev[1] = ev[17];
     }
     return GDCA_OK;
+}
+
+// one launch that stamps slot a (and b, if >= 0) of every given context's scalars (the batched k_stamp)
+static void stamp_members(hipStream_t s, gdca_ctx *const *mem, int K, int a, int b)
+{
+    gdca_recorder *&act = gdca_recorder::active();
+    gdca_recorder *outer = act;
+    if (outer) (void)outer->flush();
+    gdca_recorder rec;
+    rec.begin(s, K);
+    for (int k = 0; k < K; ++k) {
+        rec.member(k);
+        gdca_launch_stamp(s, (gdca_dev_scalars *)mem[k]->sc.p, a, b);
+    }
+    (void)rec.end();
+    act = outer;
 }
 
 // The inverses of K members of a phase batch as ONE merged launch on the batch's stream (k_sweep_merged: small matrices, which
@@ -907,13 +1061,24 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
     gdca_tuning tun[8];  // a member's schedule switches are its own context's, the switches of the merged launch the leader's
     double flops[8];
     if (K > gdca_inverse_max_merge() || K > 8) return fail(ctx, GDCA_EINVAL, "too many members in a merged inverse%s%s", "", "");
-    bool timed = true;
+    bool timed = true, stamped = true;
+    // (the members of a batch are normally peers of ONE pipeline: one wait and one record per distinct gate, not per member)
+    gdca_gate *gates[8];
+    int n_gates = 0;
     for (int k = 0; k < K; ++k) {
         timed = timed && mem[k]->pend_timed;
-        if (mem[k]->gate && mem[k]->gate->armed) HIPCHK(hipStreamWaitEvent(s, mem[k]->gate->ev[mem[k]->gate->last], 0));
+        stamped = stamped && mem[k]->pend_stamped;
+        gdca_gate *g = mem[k]->gate;
+        bool seen = !g;
+        for (int j = 0; j < n_gates && !seen; ++j) seen = gates[j] == g;
+        if (!seen) {
+            gates[n_gates++] = g;
+            if (g->armed) HIPCHK(hipStreamWaitEvent(s, g->ev[g->last], 0));
+        }
     }
+    stamped = stamped && timed;
     for (int k = 0; k < K; ++k) {
-        if (mem[k]->pend_timed) HIPCHK(hipEventRecord(mem[k]->ev[6], s));
+        if (mem[k]->pend_timed && !stamped) HIPCHK(hipEventRecord(mem[k]->ev[6], s));
         CHK(inverse_job(mem[k], mem[k]->pend_n, mem[k]->pend_npad, &jobs[k]));
         tun[k] = mem[k]->tune;
         tun[k].merge_group = lead->tune.merge_group;
@@ -922,32 +1087,38 @@ static gdca_status run_inverse_merged(gdca_ctx *lead, gdca_ctx *const *mem, int 
         if (lead->tune.sweep_debug & 16) CHK(poison_inverse_ws(mem[k], s));
     }
     // every timed member brackets the launch with events of ITS OWN: members may be collected, enqueued again or destroyed in any
-    // order, and a collect must never read another context's events
-    if (timed)
+    // order, and a collect must never read another context's events -- or, members of a batch issued as batched grids,
+    // with two launches that stamp every member's scalars (2 launches instead of 4 K event records)
+    if (stamped)
+        stamp_members(s, mem, K, 6, 16);
+    else if (timed)
         for (int k = 0; k < K; ++k) {
             CHK(need_events(mem[k], 18));
             HIPCHK(hipEventRecord(mem[k]->ev[16], s));
         }
     gdca_launch_spd_inverse_merged(s, jobs, K, nullptr, 0, flops);
     CHK(check_launch(ctx, "spd_inverse_merged"));
-    if (timed)
+    if (stamped)
+        stamp_members(s, mem, K, 17, 4);
+    else if (timed)
         for (int k = 0; k < K; ++k) HIPCHK(hipEventRecord(mem[k]->ev[17], s));
+    for (int j = 0; j < n_gates; ++j) {
+        gdca_gate *g = gates[j];
+        HIPCHK(hipEventRecord(g->ev[g->next], s));
+        g->last = g->next;
+        g->next = (g->next + 1) & 3;
+        g->armed = 1;
+    }
     for (int k = 0; k < K; ++k) {
         gdca_ctx *m = mem[k];
-        if (m->pend_timed) HIPCHK(hipEventRecord(m->ev[4], s));
-        if (m->gate) {
-            gdca_gate *g = m->gate;
-            HIPCHK(hipEventRecord(g->ev[g->next], s));
-            g->last = g->next;
-            g->next = (g->next + 1) & 3;
-            g->armed = 1;
-        }
+        if (m->pend_timed && !stamped) HIPCHK(hipEventRecord(m->ev[4], s));
         m->pend_nupd = k == 0 ? 1 : 0;
         m->pend_upd_flops = flops[k];
         m->pend_batch = K;
         // (a member without timing of its own still gets valid events to read: the launch's, or none -- collect reads them only if timed)
         m->pend_timed = m->pend_timed && timed;
-        if (timed) {
+        m->pend_inv_stamped = stamped;
+        if (timed && !stamped) {
             m->pend_upd_ev[0] = m->ev[16];
             m->pend_upd_ev[1] = m->ev[17];
         }
@@ -959,9 +1130,9 @@ static gdca_status run_score(gdca_ctx *ctx, const gdca_params *p, double *S_dev)
 {
     ctx->pend_S = S_dev;
     // (the start of THIS run's score stage: in a phase batch the members' stages follow one another behind the shared inverse)
-    if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[11], ctx->stream));
+    if (ctx->pend_timed) CHK(mark(ctx, 11));
     CHK(score_stage(ctx, ctx->pend_N, ctx->pend_q - 1, ctx->pend_npad, p->score, p->apc, S_dev, ctx->pend_timed));
-    if (ctx->pend_timed) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+    if (ctx->pend_timed) CHK(mark(ctx, 5));
     ctx->sc_published = false;
     if (ctx->sc_host_dev) {
         gdca_launch_publish_scalars(ctx->stream, (const gdca_dev_scalars *)ctx->sc.p, ctx->sc_host_dev);
@@ -1028,9 +1199,12 @@ gdca_status gdca_run_dev_async(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, in
     return run_score(ctx, p, S_dev);
 }
 
-gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_dev, const int32_t *N,
-                                const int32_t *M, const int32_t *q, const gdca_params *p, double *const *S_dev)
+static gdca_status ranking_stage(gdca_ctx *ctx, const double *S_dev, int N, int sep, long long len, int32_t **ii, int32_t **jj, double **sc);
+
+static gdca_status run_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_dev, const int32_t *N, const int32_t *M, const int32_t *q,
+                              const gdca_params *p, double *const *S_dev, int rank_sep, bool *ranked)
 {
+    if (ranked) *ranked = false;
     if (!ctxs || K < 1 || !Z_dev || !N || !M || !q || !p || !S_dev) return GDCA_EINVAL;
     gdca_ctx *lead = ctxs[0];
     if (!lead) return GDCA_EINVAL;
@@ -1058,6 +1232,72 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
     // their own workspaces, scalars and timing events; their streams are restored before returning.
     hipStream_t own[64], use[64];
     if (K > 64) return fail(lead, GDCA_EINVAL, "at most 64 families per batch%s%s", "", "");
+    // Round 6, the default (option PHASED_GRIDS=1): the members' kernels of a KIND as ONE grid (gdca_launch.h).  The front ends are
+    // recorded member by member, then issued in lockstep on the leader's stream -- ~25 launches per batch instead of ~25 per member,
+    // every one with all members' workgroups on the chip at once --, then the inverses, then the score stages (and, for the ranked
+    // entry, the rankings) the same way.  Stage boundaries are time stamps written by kernels of the batch, not events.  Bit for bit
+    // the results of the other schedules: a kernel body cannot tell which launch form runs it.
+    if (lead->tune.phased_grids != 0 && K > 1) {
+        for (int k = 0; k < K; ++k) {
+            own[k] = ctxs[k]->stream;
+            if (k > 0) (void)hipStreamSynchronize(own[k]);  // nothing of an earlier use is still in flight on the member's own stream
+        }
+        gdca_status st = GDCA_OK;
+        int done_front = 0, failed = -1;
+        gdca_recorder rec;
+        rec.begin(lead->stream, K);
+        for (int k = 0; k < K && st == GDCA_OK; ++k) {
+            ctxs[k]->stream = lead->stream;
+            ctxs[k]->stamped = true;
+            rec.member(k);
+            st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
+            if (st == GDCA_OK) ++done_front; else failed = k;
+        }
+        rec.member(-1);
+        if (rec.flush() != hipSuccess && st == GDCA_OK) st = fail(lead, GDCA_EHIP, "a batched front-end launch failed%s%s", "", "");
+        for (int k = 0; k < done_front; ++k) ctxs[k]->pend_front_batch = done_front;
+        if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
+        for (int k = 0; k < done_front && st == GDCA_OK; ++k) {
+            rec.member(k);
+            st = run_score(ctxs[k], p, S_dev[k]);
+            if (st == GDCA_OK && rank_sep > 0) {
+                gdca_ctx *m = ctxs[k];
+                m->rank_len = gdca_ranking_length(N[k], rank_sep);
+                m->rank_sep = rank_sep;
+                m->rank_status = m->rank_len > 0 ? ranking_stage(m, S_dev[k], N[k], rank_sep, m->rank_len, &m->rank_i, &m->rank_j, &m->rank_s) : GDCA_OK;
+                m->rank_pending = true;
+            }
+            if (st != GDCA_OK) failed = k;
+        }
+        rec.member(-1);
+        if (rec.end() != hipSuccess && st == GDCA_OK) st = fail(lead, GDCA_EHIP, "a batched score launch failed%s%s", "", "");
+        if (ranked && st == GDCA_OK && rank_sep > 0) *ranked = true;
+        // the members' collects synchronise THEIR stream: every one of them waits for the batch (one event on the batch's stream)
+        bool chained = st == GDCA_OK && hipEventRecord(lead->ev_batch, lead->stream) == hipSuccess;
+        for (int k = 1; k < K && chained; ++k) chained = hipStreamWaitEvent(own[k], lead->ev_batch, 0) == hipSuccess;
+        for (int k = 0; k < K; ++k) {
+            ctxs[k]->stream = own[k];
+            ctxs[k]->stamped = false;
+        }
+        if (st != GDCA_OK) {
+            (void)hipStreamSynchronize(lead->stream);
+            for (int k = 0; k < K; ++k) {
+                ctxs[k]->pending = false;
+                ctxs[k]->rank_pending = false;
+            }
+            if (failed > 0 && ctxs[failed]->err[0]) {
+                char msg[sizeof(lead->err)];
+                snprintf(msg, sizeof(msg), "member %d: %.400s", failed, ctxs[failed]->err);
+                memcpy(lead->err, msg, sizeof(msg));
+            }
+            return st;
+        }
+        if (!chained) {
+            (void)hipStreamSynchronize(lead->stream);
+            return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
+        }
+        return GDCA_OK;
+    }
     const bool side_by_side = lead->tune.phased_fronts != 0 && K > 1;
     // ... on the streams of the first PHASED_STREAMS members, round robin (default 4, the runtime's hardware queues: with one
     // stream per member the eight front ends of a config-B batch ran two to three wide and started up to 1.4 ms apart,
@@ -1120,6 +1360,12 @@ gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *
         return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
     }
     return st;
+}
+
+gdca_status gdca_run_dev_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *const *Z_dev, const int32_t *N,
+                                const int32_t *M, const int32_t *q, const gdca_params *p, double *const *S_dev)
+{
+    return run_phased(ctxs, K, Z_dev, N, M, q, p, S_dev, 0, nullptr);
 }
 
 gdca_status gdca_run_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int32_t M, int32_t q, const gdca_params *p,
@@ -1244,9 +1490,10 @@ gdca_status gdca_run_ranked_phased_async(gdca_ctx *const *ctxs, int32_t K, const
     CHK(upload_done(lead));
     for (int k = 1; k < K; ++k)
         if (hipStreamSynchronize(ctxs[k]->stream) != hipSuccess) return fail(lead, GDCA_EHIP, "upload of a member's alignment%s%s", "", "");
-    CHK(gdca_run_dev_phased(ctxs, K, Zd, N, M, q, p, Sd));
+    bool ranked = false;  // (issued as batched grids, the rankings are part of the batch)
+    CHK(run_phased(ctxs, K, Zd, N, M, q, p, Sd, min_separation, &ranked));
     // every member's ranking behind its scores, on the member's own stream (which now waits for the batch)
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < K && !ranked; ++k) {
         gdca_ctx *m = ctxs[k];
         m->rank_len = gdca_ranking_length(N[k], min_separation);
         m->rank_sep = min_separation;
@@ -1366,7 +1613,7 @@ gdca_status gdca_pair_identity_sum_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32
     CHK(validate(ctx, N, M, 2));
     if (!Z_dev || !out) return GDCA_EINVAL;
     CHK(begin(ctx));
-    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, -1));
     CHK(fetch_scalars(ctx));
     *out = ctx->sc_host->pair_sum;
     return GDCA_OK;
@@ -1377,7 +1624,7 @@ gdca_status gdca_compute_theta_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N
     CHK(validate(ctx, N, M, 2));
     if (!Z_dev || !theta) return GDCA_EINVAL;
     CHK(begin(ctx));
-    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, -1.0, -1, true, -1));
     CHK(fetch_scalars(ctx));
     *theta = ctx->sc_host->theta;
     return GDCA_OK;
@@ -1389,7 +1636,7 @@ gdca_status gdca_neighbour_counts_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_
     CHK(validate(ctx, N, M, 2));
     if (!Z_dev || !n_dev || thresh < 0) return GDCA_EINVAL;
     CHK(begin(ctx));
-    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, 0.0, thresh, false, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, 0.0, thresh, false, -1));
     HIPCHK(hipMemcpyAsync(n_dev, ctx->nk.p, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     CHK(fetch_scalars(ctx));
     return symbols_ok(ctx);
@@ -1401,7 +1648,7 @@ gdca_status gdca_compute_weights_dev(gdca_ctx *ctx, const int8_t *Z_dev, int32_t
     CHK(validate(ctx, N, M, 2));
     if (!Z_dev || !W_dev || !Meff || !(theta <= 1.0)) return GDCA_EINVAL;
     CHK(begin(ctx));
-    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, theta, -1, false, nullptr));
+    CHK(weights_stage(ctx, Z_dev, N, M, GDCA_MAXQ, theta, -1, false, -1));
     HIPCHK(hipMemcpyAsync(W_dev, ctx->W.p, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     CHK(fetch_scalars(ctx));
     *Meff = ctx->sc_host->Meff;

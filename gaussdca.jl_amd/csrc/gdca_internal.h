@@ -9,6 +9,7 @@
 #define GDCA_TILE 128     // tile edge of the SPD-inverse kernels (f64 elements)
 #define GDCA_HTILE 128    // sequences per side of a Hamming tile
 #define GDCA_MAXQ 31
+#define GDCA_STAMPS 20
 
 // Scalars that live in HBM so the whole pipeline can be enqueued without a host round trip.
 struct gdca_dev_scalars {
@@ -28,6 +29,10 @@ struct gdca_dev_scalars {
     double mat_norm1;  // ||C||_1: measured on the covariance before the sweep where the cheap bound leaves the question open (fused path), or on the
                        // caller's matrix (operator-level inverse); 0: not measured
     double pi_max;     // max over the n single-site frequencies with pseudocount (k_pi_finalize): ||C||_1 <= 2 N pi_max
+    // device time stamps (100 MHz wall clock) of a run whose kernels were issued as batched grids (gdca_run_dev_phased: no HIP events
+    // between them -- an event per member and stage was most of the host's work for a batch): slot = the index of the event a
+    // launch of its own would have recorded (gdca_api.hip: EV_*)
+    unsigned long long stamp[GDCA_STAMPS];
 };
 
 // Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
@@ -54,6 +59,7 @@ struct gdca_tuning {
     int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
     int phased_fronts;      // GDCA_PHASED_FRONTS: 1 = the front ends of a phase batch run side by side on the members' own streams (default), 0 = one after the other on the leader's
+    int phased_grids;       // GDCA_PHASED_GRIDS: 1 = the kernels of a phase batch's front ends and score stages go out as ONE grid per kernel kind carrying all members (default), 0 = one launch per member and kernel
     int phased_streams;     // GDCA_PHASED_STREAMS: streams the side-by-side front ends and score stages of a phase batch are spread over (the first members' own; default 4 = the hardware queues)
     int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
     double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: the a-priori bound of cond_2(C) first, beyond it kappa_1 = ||C||_1 ||X||_1

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 #define NPLANES 5
 #define WCHUNK 8
@@ -33,9 +34,30 @@ size_t gdca_bitplane_bytes(int N, int M)
 
 // ---- Z [M][N] bytes -> bit planes [Mt][5][NW][128] -------------------------------------------
 // thread <-> sequence, blockIdx.y <-> dword of 32 positions: 128 contiguous dwords per store.
-__global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict__ Z, uint32_t *__restrict__ Zb,
-                                                        int N, int M, int NW, int q, gdca_dev_scalars *sc)
+struct k_bitplane_pack_args {
+    const int8_t *Z;
+    uint32_t *Zb;
+    int N;
+    int M;
+    int NW;
+    int q;
+    gdca_dev_scalars *sc;
+};
+static inline k_bitplane_pack_args k_bitplane_pack_mk(const int8_t *Z, uint32_t *Zb, int N, int M, int NW, int q, gdca_dev_scalars *sc)
 {
+    return k_bitplane_pack_args{Z, Zb, N, M, NW, q, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(128) void k_bitplane_pack(const BatchArgs<k_bitplane_pack_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    uint32_t *__restrict__ Zb = a_.Zb;
+    int N = a_.N;
+    int M = a_.M;
+    int NW = a_.NW;
+    int q = a_.q;
+    gdca_dev_scalars *sc = a_.sc;
     uint32_t bad = 0;  // any byte outside 1..q (checked here because every weights computation passes through)
     const uint32_t over = (0x7fu - (uint32_t)q) * 0x01010101u;
     const int tile = blockIdx.x, w = blockIdx.y, kl = threadIdx.x;
@@ -83,7 +105,7 @@ __global__ __launch_bounds__(128) void k_bitplane_pack(const int8_t *__restrict_
 void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int N, int M, int q, gdca_dev_scalars *sc)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
-    hipLaunchKernelGGL(k_bitplane_pack, dim3(Mt, NW), dim3(128), 0, s, Z, Zb, N, M, NW, q, sc);
+    (gdca_launch<k_bitplane_pack_args, k_bitplane_pack<1>, k_bitplane_pack<GDCA_MAXB>>(dim3(Mt, NW), dim3(128), 0, s, k_bitplane_pack_mk(Z, Zb, N, M, NW, q, sc)));
 }
 
 // ---- all-pairs distances, thresholded neighbour counts ----------------------------------------
@@ -148,9 +170,28 @@ size_t gdca_hamming_cand_cap(int M)
     return (size_t)std::min<long long>(Mt * (Mt + 1) / 2 * HAM_CAND_PER_TILE + 4096, 1ll << 30);
 }
 
-__global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict__ Z, const int2 *__restrict__ list, unsigned cap, int N,
-                                                         int32_t *__restrict__ cnt, const gdca_dev_scalars *__restrict__ sc)
+struct k_hamming_refine_args {
+    const int8_t *Z;
+    const int2 *list;
+    unsigned cap;
+    int N;
+    int32_t *cnt;
+    const gdca_dev_scalars *sc;
+};
+static inline k_hamming_refine_args k_hamming_refine_mk(const int8_t *Z, const int2 *list, unsigned cap, int N, int32_t *cnt, const gdca_dev_scalars *sc)
 {
+    return k_hamming_refine_args{Z, list, cap, N, cnt, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_hamming_refine(const BatchArgs<k_hamming_refine_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    const int2 *__restrict__ list = a_.list;
+    unsigned cap = a_.cap;
+    int N = a_.N;
+    int32_t *__restrict__ cnt = a_.cnt;
+    const gdca_dev_scalars *__restrict__ sc = a_.sc;
     if (sc->ham_mode != 1) return;
     const unsigned total = sc->ham_ncand;
     if (total > cap) return;  // the list overflowed: the exact form counts this family
@@ -203,10 +244,32 @@ __global__ __launch_bounds__(256) void k_hamming_refine(const int8_t *__restrict
     }
 }
 
-template <int NP, bool PROBE>
-__global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__ Zb, int32_t *__restrict__ cnt,
-                                                  int NW, int M, int Mt, gdca_dev_scalars *__restrict__ sc, int2 *__restrict__ cand_list, unsigned cand_cap)
+struct k_hamming_args {
+    const uint32_t *Zb;
+    int32_t *cnt;
+    int NW;
+    int M;
+    int Mt;
+    gdca_dev_scalars *sc;
+    int2 *cand_list;
+    unsigned cand_cap;
+};
+static inline k_hamming_args k_hamming_mk(const uint32_t *Zb, int32_t *cnt, int NW, int M, int Mt, gdca_dev_scalars *sc, int2 *cand_list, unsigned cand_cap)
 {
+    return k_hamming_args{Zb, cnt, NW, M, Mt, sc, cand_list, cand_cap};
+}
+template <int CAP, int NP, bool PROBE>
+__global__ __launch_bounds__(256, 3) void k_hamming(const BatchArgs<k_hamming_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const uint32_t *__restrict__ Zb = a_.Zb;
+    int32_t *__restrict__ cnt = a_.cnt;
+    int NW = a_.NW;
+    int M = a_.M;
+    int Mt = a_.Mt;
+    gdca_dev_scalars *__restrict__ sc = a_.sc;
+    int2 *__restrict__ cand_list = a_.cand_list;
+    unsigned cand_cap = a_.cand_cap;
     const int thresh = sc->thresh;
     if (thresh <= 0) return;  // theta == 0 (or floor(theta N) == 0): every n_k = 1
     if constexpr (!PROBE) {
@@ -407,8 +470,22 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const uint32_t *__restrict__
 
 // sc->ham_mode from the sample: 1 (lower bound first) if fewer than 1 pair in 1000 of the sampled tiles is a candidate -- beyond
 // that the refinement costs more than the two instructions per word the bound saves
-__global__ void k_hamming_decide(gdca_dev_scalars *sc, long long sampled_pairs, int force)
+struct k_hamming_decide_args {
+    gdca_dev_scalars *sc;
+    long long sampled_pairs;
+    int force;
+};
+static inline k_hamming_decide_args k_hamming_decide_mk(gdca_dev_scalars *sc, long long sampled_pairs, int force)
 {
+    return k_hamming_decide_args{sc, sampled_pairs, force};
+}
+template <int CAP>
+__global__ void k_hamming_decide(const BatchArgs<k_hamming_decide_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    gdca_dev_scalars *sc = a_.sc;
+    long long sampled_pairs = a_.sampled_pairs;
+    int force = a_.force;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         sc->ham_mode = force >= 0 ? force : ((double)sc->ham_cand < 1e-3 * (double)sampled_pairs ? 1 : 0);
         sc->ham_ncand = 0u;
@@ -430,20 +507,20 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int
     // word and costs a list and a second kernel; N = 64, M = 20 000: 0.136 ms against 0.200, profiles/r05_option_probes.log)
     if (force < 0 && NW <= 2) force = 0;
     if (force < 0 && ntile >= 64) {
-        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, true>), dim3((unsigned)nprobe), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
-        hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1);
+        (gdca_launch<k_hamming_args, k_hamming<1, HAM_BOUND_PLANES, true>, k_hamming<GDCA_MAXB, HAM_BOUND_PLANES, true>>(dim3((unsigned)nprobe), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
+        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1)));
     } else {
-        hipLaunchKernelGGL(k_hamming_decide, dim3(1), dim3(1), 0, s, sc, 1ll, force < 0 ? 0 : force);  // tiny families: the exact form
+        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, 1ll, force < 0 ? 0 : force)));  // tiny families: the exact form
     }
     // both forms are launched wherever the bound form may run: where the device decides between them, and behind a forced bound form,
     // whose list may overflow (the form that has nothing to do exits on sc->ham_mode / sc->ham_ncand: Mt (Mt + 1) / 2 empty workgroups)
     const bool decided = !(force < 0 && ntile >= 64);
     const int form = decided ? (force < 0 ? 0 : force) : -1;
     if (form != 0) {
-        hipLaunchKernelGGL((k_hamming<HAM_BOUND_PLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
-        hipLaunchKernelGGL(k_hamming_refine, dim3(2048), dim3(256), 0, s, Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc);
+        (gdca_launch<k_hamming_args, k_hamming<1, HAM_BOUND_PLANES, false>, k_hamming<GDCA_MAXB, HAM_BOUND_PLANES, false>>(dim3((unsigned)ntile), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
+        (gdca_launch<k_hamming_refine_args, k_hamming_refine<1>, k_hamming_refine<GDCA_MAXB>>(dim3(2048), dim3(256), 0, s, k_hamming_refine_mk(Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc)));
     }
-    hipLaunchKernelGGL((k_hamming<NPLANES, false>), dim3((unsigned)ntile), dim3(256), 0, s, Zb, cnt, NW, M, Mt, sc, list, cap);
+    (gdca_launch<k_hamming_args, k_hamming<1, NPLANES, false>, k_hamming<GDCA_MAXB, NPLANES, false>>(dim3((unsigned)ntile), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
 }
 
 // ---- the second, independent implementation (GDCA_FORCE_FALLBACK) -------------------------------------------------------------
@@ -452,9 +529,26 @@ void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int
 // here: a plain byte-compare kernel that shares nothing with the bit-sliced one -- no bit planes, no pair tiles, no symmetry, no
 // atomics: workgroup <-> sequence k (its N bytes in LDS), thread <-> sequences l = tid, tid + 256, ..., every distance counted
 // position by position, one tree reduction per k.  M^2 N byte compares instead of M^2 N / 2 x 0.19 instructions: for tests only.
-__global__ __launch_bounds__(256) void k_hamming_bytes(const int8_t *__restrict__ Z, int32_t *__restrict__ cnt, int N, int M,
-                                                        const gdca_dev_scalars *sc)
+struct k_hamming_bytes_args {
+    const int8_t *Z;
+    int32_t *cnt;
+    int N;
+    int M;
+    const gdca_dev_scalars *sc;
+};
+static inline k_hamming_bytes_args k_hamming_bytes_mk(const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc)
 {
+    return k_hamming_bytes_args{Z, cnt, N, M, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_hamming_bytes(const BatchArgs<k_hamming_bytes_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    int32_t *__restrict__ cnt = a_.cnt;
+    int N = a_.N;
+    int M = a_.M;
+    const gdca_dev_scalars *sc = a_.sc;
     extern __shared__ int8_t zk[];
     __shared__ int red[256];
     const int k = blockIdx.x, tid = threadIdx.x, thresh = sc->thresh;
@@ -479,7 +573,7 @@ __global__ __launch_bounds__(256) void k_hamming_bytes(const int8_t *__restrict_
 
 void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_hamming_bytes, dim3((unsigned)M), dim3(256), (size_t)N, s, Z, cnt, N, M, sc);
+    (gdca_launch<k_hamming_bytes_args, k_hamming_bytes<1>, k_hamming_bytes<GDCA_MAXB>>(dim3((unsigned)M), dim3(256), (size_t)N, s, k_hamming_bytes_mk(Z, cnt, N, M, sc)));
 }
 
 // ---- weights ------------------------------------------------------------------------------------
@@ -493,10 +587,28 @@ int gdca_fix_shift(int M)
     return sh < 58 ? sh : 58;
 }
 
-__global__ __launch_bounds__(256) void k_weights(const int32_t *__restrict__ cnt, int M, int fix_shift,
-                                                  int32_t *__restrict__ n_out, double *__restrict__ W,
-                                                  unsigned long long *__restrict__ Wfix)
+struct k_weights_args {
+    const int32_t *cnt;
+    int M;
+    int fix_shift;
+    int32_t *n_out;
+    double *W;
+    unsigned long long *Wfix;
+};
+static inline k_weights_args k_weights_mk(const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W, unsigned long long *Wfix)
 {
+    return k_weights_args{cnt, M, fix_shift, n_out, W, Wfix};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_weights(const BatchArgs<k_weights_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int32_t *__restrict__ cnt = a_.cnt;
+    int M = a_.M;
+    int fix_shift = a_.fix_shift;
+    int32_t *__restrict__ n_out = a_.n_out;
+    double *__restrict__ W = a_.W;
+    unsigned long long *__restrict__ Wfix = a_.Wfix;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= M) return;
     const int n = 1 + cnt[k];
@@ -509,12 +621,29 @@ __global__ __launch_bounds__(256) void k_weights(const int32_t *__restrict__ cnt
 void gdca_launch_weights(hipStream_t s, const int32_t *cnt, int M, int fix_shift, int32_t *n_out, double *W,
                          unsigned long long *Wfix)
 {
-    hipLaunchKernelGGL(k_weights, dim3((M + 255) / 256), dim3(256), 0, s, cnt, M, fix_shift, n_out, W, Wfix);
+    (gdca_launch<k_weights_args, k_weights<1>, k_weights<GDCA_MAXB>>(dim3((M + 255) / 256), dim3(256), 0, s, k_weights_mk(cnt, M, fix_shift, n_out, W, Wfix)));
 }
 
-__global__ __launch_bounds__(256) void k_fix_weights(const double *__restrict__ W, int M, int fix_shift,
-                                                      unsigned long long *__restrict__ Wfix, gdca_dev_scalars *sc)
+struct k_fix_weights_args {
+    const double *W;
+    int M;
+    int fix_shift;
+    unsigned long long *Wfix;
+    gdca_dev_scalars *sc;
+};
+static inline k_fix_weights_args k_fix_weights_mk(const double *W, int M, int fix_shift, unsigned long long *Wfix, gdca_dev_scalars *sc)
 {
+    return k_fix_weights_args{W, M, fix_shift, Wfix, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_fix_weights(const BatchArgs<k_fix_weights_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ W = a_.W;
+    int M = a_.M;
+    int fix_shift = a_.fix_shift;
+    unsigned long long *__restrict__ Wfix = a_.Wfix;
+    gdca_dev_scalars *sc = a_.sc;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= M) return;
     const double w = W[k];
@@ -528,7 +657,7 @@ __global__ __launch_bounds__(256) void k_fix_weights(const double *__restrict__ 
 void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shift, unsigned long long *Wfix,
                              gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_fix_weights, dim3((M + 255) / 256), dim3(256), 0, s, W, M, fix_shift, Wfix, sc);
+    (gdca_launch<k_fix_weights_args, k_fix_weights<1>, k_fix_weights<GDCA_MAXB>>(dim3((M + 255) / 256), dim3(256), 0, s, k_fix_weights_mk(W, M, fix_shift, Wfix, sc)));
 }
 
 // Meff = the sum of the weights, EXACT and rounded once (round to nearest even): what Python's math.fsum returns, whatever the
@@ -539,8 +668,22 @@ void gdca_launch_fix_weights(hipStream_t s, const double *W, int M, int fix_shif
 // 85 bits.  A thread adds the three 32-bit limbs of its terms into 64-bit counters (no carries: < 2^24 terms per thread), the
 // workgroup adds those into LDS, and thread 0 resolves the carries into one 128-bit integer and rounds it to 53 bits.
 #define MEFF_FRAC 84
-__global__ __launch_bounds__(1024) void k_meff(const double *__restrict__ W, int M, gdca_dev_scalars *sc)
+struct k_meff_args {
+    const double *W;
+    int M;
+    gdca_dev_scalars *sc;
+};
+static inline k_meff_args k_meff_mk(const double *W, int M, gdca_dev_scalars *sc)
 {
+    return k_meff_args{W, M, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(1024) void k_meff(const BatchArgs<k_meff_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ W = a_.W;
+    int M = a_.M;
+    gdca_dev_scalars *sc = a_.sc;
     __shared__ unsigned long long limb[3];
     const int tid = threadIdx.x;
     if (tid < 3) limb[tid] = 0ull;
@@ -626,5 +769,5 @@ __global__ __launch_bounds__(1024) void k_meff(const double *__restrict__ W, int
 
 void gdca_launch_meff(hipStream_t s, const double *W, int M, gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_meff, dim3(1), dim3(1024), 0, s, W, M, sc);
+    (gdca_launch<k_meff_args, k_meff<1>, k_meff<GDCA_MAXB>>(dim3(1), dim3(1024), 0, s, k_meff_mk(W, M, sc)));
 }

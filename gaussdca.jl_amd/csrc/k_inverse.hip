@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -2660,7 +2661,7 @@ void gdca_launch_spd_inverse(hipStream_t s0, const gdca_inverse_job &job, hipEve
         SweepPrep prep{};
         prep.K = 1;
         prep.fam[0] = P.prep;
-        hipLaunchKernelGGL(k_sweep_prep, dim3(16, 1), dim3(256), 0, s0, prep);
+        GDCA_LAUNCH_DIRECT(k_sweep_prep, dim3(16, 1), dim3(256), 0, s0, prep);
     }
     SweepDesc &D = P.D;
     const int ng = D.ng;
@@ -2678,9 +2679,9 @@ void gdca_launch_spd_inverse(hipStream_t s0, const gdca_inverse_job &job, hipEve
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
     if (P.g > 1)
-        hipLaunchKernelGGL((k_sweep<true>), dim3(grid), dim3(256), 0, s0, D);
+        GDCA_LAUNCH_DIRECT((k_sweep<true>), dim3(grid), dim3(256), 0, s0, D);
     else
-        hipLaunchKernelGGL((k_sweep<false>), dim3(grid), dim3(256), 0, s0, D);
+        GDCA_LAUNCH_DIRECT((k_sweep<false>), dim3(grid), dim3(256), 0, s0, D);
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
     if (dbg) {
         (void)hipStreamSynchronize(s0);
@@ -2709,14 +2710,14 @@ void gdca_launch_spd_inverse_merged(hipStream_t s0, const gdca_inverse_job *jobs
         if (upd_flops) upd_flops[k] = 2.0 * T * T * KC * P.chunks;
         cus = std::max(cus, jobs[k].ws.update_cus);
     }
-    hipLaunchKernelGGL(k_sweep_prep, dim3(16, (unsigned)K), dim3(256), 0, s0, prep);
+    GDCA_LAUNCH_DIRECT(k_sweep_prep, dim3(16, (unsigned)K), dim3(256), 0, s0, prep);
     const unsigned grid = (unsigned)(2 * cus);
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
     if (multi)
-        hipLaunchKernelGGL(k_sweep_merged<true>, dim3(grid), dim3(256), 0, s0, B);
+        GDCA_LAUNCH_DIRECT(k_sweep_merged<true>, dim3(grid), dim3(256), 0, s0, B);
     else
-        hipLaunchKernelGGL(k_sweep_merged<false>, dim3(grid), dim3(256), 0, s0, B);
+        GDCA_LAUNCH_DIRECT(k_sweep_merged<false>, dim3(grid), dim3(256), 0, s0, B);
     if (tm) (void)hipEventRecord(upd_ev[1], s0);
 }
 
@@ -2859,14 +2860,14 @@ void gdca_launch_inverse_norm1(hipStream_t s, const double *A, int n_pad, int n,
 {
     (void)hipMemsetAsync(colsum_ws, 0, (size_t)n_pad * sizeof(double), s);
     const int nblk = n_pad / T;
-    hipLaunchKernelGGL(k_sym_colabs, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, A, (size_t)n_pad, nblk, colsum_ws);
-    hipLaunchKernelGGL(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);   // (the padding's unit columns stay out of it)
+    GDCA_LAUNCH_DIRECT(k_sym_colabs, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, A, (size_t)n_pad, nblk, colsum_ws);
+    GDCA_LAUNCH_DIRECT(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);   // (the padding's unit columns stay out of it)
 }
 
 void gdca_launch_matrix_norm1(hipStream_t s, const double *C, size_t ld, int n, double *colsum_ws, double *out)
 {
-    hipLaunchKernelGGL(k_colabs_full, dim3((unsigned)n), dim3(256), 0, s, C, ld, n, colsum_ws);
-    hipLaunchKernelGGL(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);
+    GDCA_LAUNCH_DIRECT(k_colabs_full, dim3((unsigned)n), dim3(256), 0, s, C, ld, n, colsum_ws);
+    GDCA_LAUNCH_DIRECT(k_vec_max, dim3(1), dim3(256), 0, s, colsum_ws, n, out);
 }
 
 // One 128 x 128 tile of  G H^T  over the whole inner dimension (nblk blocks of 128), G(r, k) = G[r + k ld], H(c, k) = H[c + k ld]
@@ -2935,8 +2936,8 @@ void gdca_launch_newton_schulz(hipStream_t s, double *A, const double *C2, doubl
     const int nblk = n_pad / T;
     if (resid) (void)hipMemsetAsync(resid, 0, sizeof(double), s);
     gdca_launch_copy_out_neg_sym(s, A, n_pad, B0, n_pad);                                      // B0 = X0, full symmetric
-    hipLaunchKernelGGL(k_ns_gemm<0>, dim3((unsigned)(nblk * nblk)), dim3(256), 0, s, B0, C2, (size_t)n_pad, nblk, Rt, nullptr, resid);
-    hipLaunchKernelGGL(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0, nullptr);
+    GDCA_LAUNCH_DIRECT(k_ns_gemm<0>, dim3((unsigned)(nblk * nblk)), dim3(256), 0, s, B0, C2, (size_t)n_pad, nblk, Rt, nullptr, resid);
+    GDCA_LAUNCH_DIRECT(k_ns_gemm<1>, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, B0, Rt, (size_t)n_pad, nblk, A, B0, nullptr);
 }
 
 // =====================================================================================================================
@@ -3115,18 +3116,18 @@ void gdca_launch_cholesky_inverse(hipStream_t s, double *C2, double *U, double *
     const size_t ld = (size_t)n_pad;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize, T * T * (int)sizeof(double));
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), T * T * sizeof(double), s, C2, ld, k, Wd + (size_t)k * T * T, U, n_real, sc);
+        GDCA_LAUNCH_DIRECT(k_chol_diag, dim3(1), dim3(256), T * T * sizeof(double), s, C2, ld, k, Wd + (size_t)k * T * T, U, n_real, sc);
         const int below = nblk - k - 1;
         if (below > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((unsigned)below), dim3(256), 0, s, C2, ld, k, Wd + (size_t)k * T * T);
-            hipLaunchKernelGGL(k_chol_trail, dim3((unsigned)(below * (below + 1) / 2)), dim3(256), 0, s, C2, ld, k);
+            GDCA_LAUNCH_DIRECT(k_chol_panel, dim3((unsigned)below), dim3(256), 0, s, C2, ld, k, Wd + (size_t)k * T * T);
+            GDCA_LAUNCH_DIRECT(k_chol_trail, dim3((unsigned)(below * (below + 1) / 2)), dim3(256), 0, s, C2, ld, k);
         }
     }
     for (int i = 1; i < nblk; ++i) {
-        hipLaunchKernelGGL(k_chol_fwd_t, dim3((unsigned)i), dim3(256), 0, s, C2, U, Tm, ld, i);
-        hipLaunchKernelGGL(k_chol_fwd_u, dim3((unsigned)i), dim3(256), 0, s, Tm, Wd + (size_t)i * T * T, U, ld, i);
+        GDCA_LAUNCH_DIRECT(k_chol_fwd_t, dim3((unsigned)i), dim3(256), 0, s, C2, U, Tm, ld, i);
+        GDCA_LAUNCH_DIRECT(k_chol_fwd_u, dim3((unsigned)i), dim3(256), 0, s, Tm, Wd + (size_t)i * T * T, U, ld, i);
     }
-    hipLaunchKernelGGL(k_chol_uut, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, U, Aout, ld, nblk);
+    GDCA_LAUNCH_DIRECT(k_chol_uut, dim3((unsigned)(nblk * (nblk + 1) / 2)), dim3(256), 0, s, U, Aout, ld, nblk);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -3161,5 +3162,5 @@ __global__ __launch_bounds__(256, 2) void k_probe_mfma_f64(double *out, int iter
 
 void gdca_launch_probe_mfma_f64(hipStream_t s, double *out, int iters, int blocks)
 {
-    hipLaunchKernelGGL(k_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, out, iters);
+    GDCA_LAUNCH_DIRECT(k_probe_mfma_f64, dim3(blocks), dim3(256), 0, s, out, iters);
 }

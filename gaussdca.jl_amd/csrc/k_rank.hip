@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 namespace {
 
@@ -29,8 +30,26 @@ __device__ __forceinline__ uint64_t rank_key(double x)
 }
 
 // row i = blockIdx.x + 1 of the enumeration: entries (i, j), j = i + sep .. N, at offset (i-1)(N-sep) - (i-1)(i-2)/2
-__global__ __launch_bounds__(256) void k_rank_keys(const double *__restrict__ S, int N, int sep, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+struct k_rank_keys_args {
+    const double *S;
+    int N;
+    int sep;
+    uint64_t *key;
+    uint32_t *val;
+};
+static inline k_rank_keys_args k_rank_keys_mk(const double *S, int N, int sep, uint64_t *key, uint32_t *val)
 {
+    return k_rank_keys_args{S, N, sep, key, val};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_rank_keys(const BatchArgs<k_rank_keys_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ S = a_.S;
+    int N = a_.N;
+    int sep = a_.sep;
+    uint64_t *__restrict__ key = a_.key;
+    uint32_t *__restrict__ val = a_.val;
     const int i = (int)blockIdx.x + 1;
     const long long d = N - sep;
     const long long off = (long long)(i - 1) * d - (long long)(i - 1) * (i - 2) / 2;
@@ -41,8 +60,26 @@ __global__ __launch_bounds__(256) void k_rank_keys(const double *__restrict__ S,
     }
 }
 
-__global__ __launch_bounds__(256) void k_rank_hist(const uint64_t *__restrict__ key, size_t n, int shift, uint32_t *__restrict__ hist, int nchunk)
+struct k_rank_hist_args {
+    const uint64_t *key;
+    size_t n;
+    int shift;
+    uint32_t *hist;
+    int nchunk;
+};
+static inline k_rank_hist_args k_rank_hist_mk(const uint64_t *key, size_t n, int shift, uint32_t *hist, int nchunk)
 {
+    return k_rank_hist_args{key, n, shift, hist, nchunk};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_rank_hist(const BatchArgs<k_rank_hist_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const uint64_t *__restrict__ key = a_.key;
+    size_t n = a_.n;
+    int shift = a_.shift;
+    uint32_t *__restrict__ hist = a_.hist;
+    int nchunk = a_.nchunk;
     __shared__ uint32_t h[256];
     const int tid = (int)threadIdx.x;
     h[tid] = 0;
@@ -58,8 +95,20 @@ __global__ __launch_bounds__(256) void k_rank_hist(const uint64_t *__restrict__ 
 }
 
 // one workgroup; thread d owns digit d's row
-__global__ __launch_bounds__(256) void k_rank_scan(uint32_t *__restrict__ hist, int nchunk)
+struct k_rank_scan_args {
+    uint32_t *hist;
+    int nchunk;
+};
+static inline k_rank_scan_args k_rank_scan_mk(uint32_t *hist, int nchunk)
 {
+    return k_rank_scan_args{hist, nchunk};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_rank_scan(const BatchArgs<k_rank_scan_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    uint32_t *__restrict__ hist = a_.hist;
+    int nchunk = a_.nchunk;
     __shared__ uint32_t tot[256];
     const int d = (int)threadIdx.x;
     uint32_t *row = hist + (size_t)d * nchunk;
@@ -85,9 +134,32 @@ __global__ __launch_bounds__(256) void k_rank_scan(uint32_t *__restrict__ hist, 
         for (int b = 0; b < nchunk; ++b) row[b] += g;
 }
 
-__global__ __launch_bounds__(256) void k_rank_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
-                                                      uint32_t *__restrict__ vout, size_t n, int shift, const uint32_t *__restrict__ hist, int nchunk)
+struct k_rank_scatter_args {
+    const uint64_t *kin;
+    const uint32_t *vin;
+    uint64_t *kout;
+    uint32_t *vout;
+    size_t n;
+    int shift;
+    const uint32_t *hist;
+    int nchunk;
+};
+static inline k_rank_scatter_args k_rank_scatter_mk(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n, int shift, const uint32_t *hist, int nchunk)
 {
+    return k_rank_scatter_args{kin, vin, kout, vout, n, shift, hist, nchunk};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_rank_scatter(const BatchArgs<k_rank_scatter_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const uint64_t *__restrict__ kin = a_.kin;
+    const uint32_t *__restrict__ vin = a_.vin;
+    uint64_t *__restrict__ kout = a_.kout;
+    uint32_t *__restrict__ vout = a_.vout;
+    size_t n = a_.n;
+    int shift = a_.shift;
+    const uint32_t *__restrict__ hist = a_.hist;
+    int nchunk = a_.nchunk;
     extern __shared__ __attribute__((aligned(16))) uint16_t cnt[];  // [thread][RK_ROW]
     __shared__ uint32_t start[256];
     const int tid = (int)threadIdx.x;
@@ -134,9 +206,30 @@ __global__ __launch_bounds__(256) void k_rank_scatter(const uint64_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ val, size_t n, const double *__restrict__ S, int N, int32_t *__restrict__ ii,
-                                                   int32_t *__restrict__ jj, double *__restrict__ sc)
+struct k_rank_emit_args {
+    const uint32_t *val;
+    size_t n;
+    const double *S;
+    int N;
+    int32_t *ii;
+    int32_t *jj;
+    double *sc;
+};
+static inline k_rank_emit_args k_rank_emit_mk(const uint32_t *val, size_t n, const double *S, int N, int32_t *ii, int32_t *jj, double *sc)
 {
+    return k_rank_emit_args{val, n, S, N, ii, jj, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_rank_emit(const BatchArgs<k_rank_emit_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const uint32_t *__restrict__ val = a_.val;
+    size_t n = a_.n;
+    const double *__restrict__ S = a_.S;
+    int N = a_.N;
+    int32_t *__restrict__ ii = a_.ii;
+    int32_t *__restrict__ jj = a_.jj;
+    double *__restrict__ sc = a_.sc;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     const uint32_t v = val[e];
@@ -173,13 +266,13 @@ void gdca_launch_ranking(hipStream_t s, const double *S_dev, int N, int sep, lon
     *jj = (int32_t *)p, p += up256(n * 4);
     *sc = (double *)p;
     const size_t lds = (size_t)RK_THREADS * RK_ROW * sizeof(uint16_t);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_rank_keys, dim3((unsigned)(N - sep)), dim3(256), 0, s, S_dev, N, sep, key[0], val[0]);
+    // (dynamic LDS beyond 48 KB: the launcher raises the kernel's limit, gdca_launch.h)
+    (gdca_launch<k_rank_keys_args, k_rank_keys<1>, k_rank_keys<GDCA_MAXB>>(dim3((unsigned)(N - sep)), dim3(256), 0, s, k_rank_keys_mk(S_dev, N, sep, key[0], val[0])));
     for (int pass = 0; pass < 8; ++pass) {
         const int a = pass & 1, b = a ^ 1, shift = 8 * pass;
-        hipLaunchKernelGGL(k_rank_hist, dim3((unsigned)nchunk), dim3(256), 0, s, key[a], n, shift, hist, nchunk);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(256), 0, s, hist, nchunk);
-        hipLaunchKernelGGL(k_rank_scatter, dim3((unsigned)nchunk), dim3(256), lds, s, key[a], val[a], key[b], val[b], n, shift, hist, nchunk);
+        (gdca_launch<k_rank_hist_args, k_rank_hist<1>, k_rank_hist<GDCA_MAXB>>(dim3((unsigned)nchunk), dim3(256), 0, s, k_rank_hist_mk(key[a], n, shift, hist, nchunk)));
+        (gdca_launch<k_rank_scan_args, k_rank_scan<1>, k_rank_scan<GDCA_MAXB>>(dim3(1), dim3(256), 0, s, k_rank_scan_mk(hist, nchunk)));
+        (gdca_launch<k_rank_scatter_args, k_rank_scatter<1>, k_rank_scatter<GDCA_MAXB>>(dim3((unsigned)nchunk), dim3(256), lds, s, k_rank_scatter_mk(key[a], val[a], key[b], val[b], n, shift, hist, nchunk)));
     }
-    hipLaunchKernelGGL(k_rank_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, val[0], n, S_dev, N, *ii, *jj, *sc);
+    (gdca_launch<k_rank_emit_args, k_rank_emit<1>, k_rank_emit<GDCA_MAXB>>(dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k_rank_emit_mk(val[0], n, S_dev, N, *ii, *jj, *sc)));
 }

@@ -12,6 +12,7 @@
 // tridiagonalisation per pair (one wave each, LDS-resident), then implicit QL on the
 // tridiagonals, one lane per pair -- latency/VALU-bound, no HBM traffic to speak of.
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 __device__ __forceinline__ void pair_decode(long long p, int &i, int &j)
 {
@@ -43,9 +44,26 @@ __device__ __forceinline__ double wave_sum(double v)
 // FN_MAXU: 16-byte loads per thread that hold a workgroup's image, ceil(s (FN_PG s / 2) / 256).  SDIM: s as a compile-time
 // constant (20 = the q = 21 alphabet: the loops over a block unroll, their LDS reads are issued back to back instead of one
 // round trip per addition) or 0 = run-time s.
-template <int FN_MAXU, int SDIM>
-__global__ __launch_bounds__(256) void k_fn(const double *__restrict__ A, size_t ld, int N, int sdim_rt, double *__restrict__ S)
+struct k_fn_args {
+    const double *A;
+    size_t ld;
+    int N;
+    int sdim_rt;
+    double *S;
+};
+static inline k_fn_args k_fn_mk(const double *A, size_t ld, int N, int sdim_rt, double *S)
 {
+    return k_fn_args{A, ld, N, sdim_rt, S};
+}
+template <int CAP, int FN_MAXU, int SDIM>
+__global__ __launch_bounds__(256) void k_fn(const BatchArgs<k_fn_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ A = a_.A;
+    size_t ld = a_.ld;
+    int N = a_.N;
+    int sdim_rt = a_.sdim_rt;
+    double *__restrict__ S = a_.S;
     const int sdim = SDIM ? SDIM : sdim_rt;
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -188,8 +206,26 @@ __device__ __forceinline__ void fn20_unit_load(Fn20Unit &q, int u, int tid, int 
     q.v = *reinterpret_cast<const double2 *>(src + (size_t)c * ld + 2 * r2);
 }
 
-__global__ __launch_bounds__(FN20_THREADS) void k_fn20(const double *__restrict__ A, size_t ld, int N, int total, double *__restrict__ S)
+struct k_fn20_args {
+    const double *A;
+    size_t ld;
+    int N;
+    int total;
+    double *S;
+};
+static inline k_fn20_args k_fn20_mk(const double *A, size_t ld, int N, int total, double *S)
 {
+    return k_fn20_args{A, ld, N, total, S};
+}
+template <int CAP>
+__global__ __launch_bounds__(FN20_THREADS) void k_fn20(const BatchArgs<k_fn20_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ A = a_.A;
+    size_t ld = a_.ld;
+    int N = a_.N;
+    int total = a_.total;
+    double *__restrict__ S = a_.S;
     constexpr int s = 20, Lp = FN20_LP;
     static_assert(FN20_MAXU == 10, "FN20_UNITS lists ten units");
     __shared__ __attribute__((aligned(16))) double img[s * Lp];   // img[c * Lp + (row of the run)]
@@ -293,20 +329,34 @@ void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, 
     if (sdim == 20 && (ld & 1) == 0) {
         const int total = fn20_first(N - 1, N);
         const int grid = std::min(total, FN20_WG * (ncu > 0 ? ncu : 256));
-        hipLaunchKernelGGL(k_fn20, dim3((unsigned)grid), dim3(FN20_THREADS), 0, s, A, ld, N, total, S);
+        (gdca_launch<k_fn20_args, k_fn20<1>, k_fn20<GDCA_MAXB>>(dim3((unsigned)grid), dim3(FN20_THREADS), 0, s, k_fn20_mk(A, ld, N, total, S)));
     } else if (sdim == 20)
-        hipLaunchKernelGGL((k_fn<units20, 20>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+        (gdca_launch<k_fn_args, k_fn<1, units20, 20>, k_fn<GDCA_MAXB, units20, 20>>(nwg, dim3(256), lds, s, k_fn_mk(A, ld, N, sdim, S)));
     else if (units <= 4)
-        hipLaunchKernelGGL((k_fn<4, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+        (gdca_launch<k_fn_args, k_fn<1, 4, 0>, k_fn<GDCA_MAXB, 4, 0>>(nwg, dim3(256), lds, s, k_fn_mk(A, ld, N, sdim, S)));
     else if (units <= 7)
-        hipLaunchKernelGGL((k_fn<7, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+        (gdca_launch<k_fn_args, k_fn<1, 7, 0>, k_fn<GDCA_MAXB, 7, 0>>(nwg, dim3(256), lds, s, k_fn_mk(A, ld, N, sdim, S)));
     else
-        hipLaunchKernelGGL((k_fn<16, 0>), nwg, dim3(256), lds, s, A, ld, N, sdim, S);
+        (gdca_launch<k_fn_args, k_fn<1, 16, 0>, k_fn<GDCA_MAXB, 16, 0>>(nwg, dim3(256), lds, s, k_fn_mk(A, ld, N, sdim, S)));
 }
 
 // ---- Cholesky factors of the diagonal blocks of C ------------------------------------------------------
-__global__ __launch_bounds__(64) void k_diag_chol(const double *__restrict__ D, int sdim, double *__restrict__ Ld)
+struct k_diag_chol_args {
+    const double *D;
+    int sdim;
+    double *Ld;
+};
+static inline k_diag_chol_args k_diag_chol_mk(const double *D, int sdim, double *Ld)
 {
+    return k_diag_chol_args{D, sdim, Ld};
+}
+template <int CAP>
+__global__ __launch_bounds__(64) void k_diag_chol(const BatchArgs<k_diag_chol_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ D = a_.D;
+    int sdim = a_.sdim;
+    double *__restrict__ Ld = a_.Ld;
     __shared__ double m[32 * 32];
     const int i = blockIdx.x, t = threadIdx.x;
     const int ss = sdim * sdim;
@@ -332,7 +382,7 @@ __global__ __launch_bounds__(64) void k_diag_chol(const double *__restrict__ D, 
 
 void gdca_launch_diag_chol(hipStream_t s, const double *D, int N, int sdim, double *Ld)
 {
-    hipLaunchKernelGGL(k_diag_chol, dim3(N), dim3(64), 0, s, D, sdim, Ld);
+    (gdca_launch<k_diag_chol_args, k_diag_chol<1>, k_diag_chol<GDCA_MAXB>>(dim3(N), dim3(64), 0, s, k_diag_chol_mk(D, sdim, Ld)));
 }
 
 // ---- DI ---------------------------------------------------------------------------------------------
@@ -443,11 +493,32 @@ __device__ __forceinline__ double half_sum(double v)
 // Householder reduction of both V side by side, 32 lanes each (lane r of a half owns row r: the reduction keeps at most 31 lanes
 // busy, so two pairs per wave halve its instruction count per pair).  Branch-free in the pair: a column that is already reduced
 // gets the zero reflector.
-__global__ __launch_bounds__(64) void k_di_tridiag(const double *__restrict__ A, size_t ld,
-                                                    const double *__restrict__ Ld, int sdim, long long npairs,
-                                                    long long tstride, double *__restrict__ Td,
-                                                    double *__restrict__ Te)
+struct k_di_tridiag_args {
+    const double *A;
+    size_t ld;
+    const double *Ld;
+    int sdim;
+    long long npairs;
+    long long tstride;
+    double *Td;
+    double *Te;
+};
+static inline k_di_tridiag_args k_di_tridiag_mk(const double *A, size_t ld, const double *Ld, int sdim, long long npairs, long long tstride, double *Td, double *Te)
 {
+    return k_di_tridiag_args{A, ld, Ld, sdim, npairs, tstride, Td, Te};
+}
+template <int CAP>
+__global__ __launch_bounds__(64) void k_di_tridiag(const BatchArgs<k_di_tridiag_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ A = a_.A;
+    size_t ld = a_.ld;
+    const double *__restrict__ Ld = a_.Ld;
+    int sdim = a_.sdim;
+    long long npairs = a_.npairs;
+    long long tstride = a_.tstride;
+    double *__restrict__ Td = a_.Td;
+    double *__restrict__ Te = a_.Te;
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int ss = sdim * sdim;
@@ -513,10 +584,32 @@ __device__ __forceinline__ double pythag(double a, double b)
     return sqrt(a * a + b * b);
 }
 
-__global__ __launch_bounds__(64) void k_di_ql(const double *__restrict__ Td, const double *__restrict__ Te,
-                                               long long tstride, long long npairs, int N, int sdim,
-                                               double *__restrict__ S, gdca_dev_scalars *sc)
+struct k_di_ql_args {
+    const double *Td;
+    const double *Te;
+    long long tstride;
+    long long npairs;
+    int N;
+    int sdim;
+    double *S;
+    gdca_dev_scalars *sc;
+};
+static inline k_di_ql_args k_di_ql_mk(const double *Td, const double *Te, long long tstride, long long npairs, int N, int sdim, double *S, gdca_dev_scalars *sc)
 {
+    return k_di_ql_args{Td, Te, tstride, npairs, N, sdim, S, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(64) void k_di_ql(const BatchArgs<k_di_ql_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ Td = a_.Td;
+    const double *__restrict__ Te = a_.Te;
+    long long tstride = a_.tstride;
+    long long npairs = a_.npairs;
+    int N = a_.N;
+    int sdim = a_.sdim;
+    double *__restrict__ S = a_.S;
+    gdca_dev_scalars *sc = a_.sc;
     bool noconv = false;
     extern __shared__ __attribute__((aligned(16))) double qsm[];
     const int lane = threadIdx.x;
@@ -612,9 +705,9 @@ void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld,
     const long long tstride = (npairs + 63) / 64 * 64;
     double *Td = Tws, *Te = Tws + (size_t)sdim * tstride;
     const size_t lds1 = (size_t)2 * (sdim * sdim + 64) * sizeof(double);
-    hipLaunchKernelGGL(k_di_tridiag, dim3((unsigned)((npairs + 1) / 2)), dim3(64), lds1, s, A, ld, Ld, sdim, npairs, tstride, Td, Te);
+    (gdca_launch<k_di_tridiag_args, k_di_tridiag<1>, k_di_tridiag<GDCA_MAXB>>(dim3((unsigned)((npairs + 1) / 2)), dim3(64), lds1, s, k_di_tridiag_mk(A, ld, Ld, sdim, npairs, tstride, Td, Te)));
     const size_t lds2 = (size_t)2 * sdim * 64 * sizeof(double);
-    hipLaunchKernelGGL(k_di_ql, dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, Td, Te, tstride, npairs, N, sdim, S, sc);
+    (gdca_launch<k_di_ql_args, k_di_ql<1>, k_di_ql<GDCA_MAXB>>(dim3((unsigned)(tstride / 64)), dim3(64), lds2, s, k_di_ql_mk(Td, Te, tstride, npairs, N, sdim, S, sc)));
 }
 
 size_t gdca_di_ws_bytes(int N, int sdim)
@@ -625,8 +718,22 @@ size_t gdca_di_ws_bytes(int N, int sdim)
 }
 
 // ---- APC --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colsum(const double *__restrict__ S, int N, double *__restrict__ cs)
+struct k_colsum_args {
+    const double *S;
+    int N;
+    double *cs;
+};
+static inline k_colsum_args k_colsum_mk(const double *S, int N, double *cs)
 {
+    return k_colsum_args{S, N, cs};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_colsum(const BatchArgs<k_colsum_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ S = a_.S;
+    int N = a_.N;
+    double *__restrict__ cs = a_.cs;
     __shared__ double red[256];
     const int c = blockIdx.x;
     double a = 0.0;
@@ -641,8 +748,22 @@ __global__ __launch_bounds__(256) void k_colsum(const double *__restrict__ S, in
 }
 
 // S <- S - (Sj * Si) / Sa,  Sa = sum(S) (1 - 1/N)   (src/GaussDCA.jl:78-86; S symmetric: Si = Sj^T)
-__global__ __launch_bounds__(256) void k_apc_apply(double *__restrict__ S, int N, const double *__restrict__ cs)
+struct k_apc_apply_args {
+    double *S;
+    int N;
+    const double *cs;
+};
+static inline k_apc_apply_args k_apc_apply_mk(double *S, int N, const double *cs)
 {
+    return k_apc_apply_args{S, N, cs};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_apc_apply(const BatchArgs<k_apc_apply_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    double *__restrict__ S = a_.S;
+    int N = a_.N;
+    const double *__restrict__ cs = a_.cs;
     __shared__ double red[256];
     double a = 0.0;
     for (int r = threadIdx.x; r < N; r += 256) a += cs[r];
@@ -663,6 +784,6 @@ __global__ __launch_bounds__(256) void k_apc_apply(double *__restrict__ S, int N
 
 void gdca_launch_apc(hipStream_t s, double *S, int N, double *colsum_ws)
 {
-    hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, s, S, N, colsum_ws);
-    hipLaunchKernelGGL(k_apc_apply, dim3(N), dim3(256), 0, s, S, N, colsum_ws);
+    (gdca_launch<k_colsum_args, k_colsum<1>, k_colsum<GDCA_MAXB>>(dim3(N), dim3(256), 0, s, k_colsum_mk(S, N, colsum_ws)));
+    (gdca_launch<k_apc_apply_args, k_apc_apply<1>, k_apc_apply<GDCA_MAXB>>(dim3(N), dim3(256), 0, s, k_apc_apply_mk(S, N, colsum_ws)));
 }

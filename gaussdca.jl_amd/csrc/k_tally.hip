@@ -20,15 +20,38 @@
 // diagonal only, off-diagonal blocks pc/q^2 everywhere) and subtracts Pi'Pi'^T, so the n x n
 // covariance is written to HBM exactly once (8 n^2 bytes) and Pij never exists in memory.
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 #include <cstdlib>
 
 typedef unsigned long long u64;
 
 // ---- single-site sums -----------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_pi_tally(const int8_t *__restrict__ Z, const u64 *__restrict__ Wfix,
-                                                   u64 *__restrict__ Pifix, int N, int M, int seq_per_block, int q,
-                                                   gdca_dev_scalars *sc)
+struct k_pi_tally_args {
+    const int8_t *Z;
+    const u64 *Wfix;
+    u64 *Pifix;
+    int N;
+    int M;
+    int seq_per_block;
+    int q;
+    gdca_dev_scalars *sc;
+};
+static inline k_pi_tally_args k_pi_tally_mk(const int8_t *Z, const u64 *Wfix, u64 *Pifix, int N, int M, int seq_per_block, int q, gdca_dev_scalars *sc)
 {
+    return k_pi_tally_args{Z, Wfix, Pifix, N, M, seq_per_block, q, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(128) void k_pi_tally(const BatchArgs<k_pi_tally_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    const u64 *__restrict__ Wfix = a_.Wfix;
+    u64 *__restrict__ Pifix = a_.Pifix;
+    int N = a_.N;
+    int M = a_.M;
+    int seq_per_block = a_.seq_per_block;
+    int q = a_.q;
+    gdca_dev_scalars *sc = a_.sc;
     __shared__ u64 h[32][128];
     unsigned bad = 0;  // any byte outside 1..q
     const int t = threadIdx.x;
@@ -75,13 +98,37 @@ void gdca_launch_pi_tally(hipStream_t s, const int8_t *Z, const u64 *Wfix, u64 *
     int spb = (M + chunks - 1) / chunks;
     if (spb < 64) spb = 64;
     chunks = (M + spb - 1) / spb;
-    hipLaunchKernelGGL(k_pi_tally, dim3(cb, chunks), dim3(128), 0, s, Z, Wfix, Pifix, N, M, spb, q, sc);
+    (gdca_launch<k_pi_tally_args, k_pi_tally<1>, k_pi_tally<GDCA_MAXB>>(dim3(cb, chunks), dim3(128), 0, s, k_pi_tally_mk(Z, Wfix, Pifix, N, M, spb, q, sc)));
 }
 
-__global__ __launch_bounds__(256) void k_pi_finalize(const u64 *__restrict__ Pifix, int N, int q, int fix_shift,
-                                                      const double *__restrict__ Meff_dev, double pc,
-                                                      double *__restrict__ Pi_true, double *__restrict__ Pi_pc, double *__restrict__ pi_max)
+struct k_pi_finalize_args {
+    const u64 *Pifix;
+    int N;
+    int q;
+    int fix_shift;
+    const double *Meff_dev;
+    double pc;
+    double *Pi_true;
+    double *Pi_pc;
+    double *pi_max;
+};
+static inline k_pi_finalize_args k_pi_finalize_mk(const u64 *Pifix, int N, int q, int fix_shift, const double *Meff_dev, double pc, double *Pi_true, double *Pi_pc, double *pi_max)
 {
+    return k_pi_finalize_args{Pifix, N, q, fix_shift, Meff_dev, pc, Pi_true, Pi_pc, pi_max};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_pi_finalize(const BatchArgs<k_pi_finalize_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const u64 *__restrict__ Pifix = a_.Pifix;
+    int N = a_.N;
+    int q = a_.q;
+    int fix_shift = a_.fix_shift;
+    const double *__restrict__ Meff_dev = a_.Meff_dev;
+    double pc = a_.pc;
+    double *__restrict__ Pi_true = a_.Pi_true;
+    double *__restrict__ Pi_pc = a_.Pi_pc;
+    double *__restrict__ pi_max = a_.pi_max;
     const int s = q - 1;
     const int e = blockIdx.x * 256 + threadIdx.x;
     double mine = 0.0;
@@ -106,9 +153,34 @@ __global__ __launch_bounds__(256) void k_pi_finalize(const u64 *__restrict__ Pif
 // nothing (a column of C sums, in absolute value, to at most  sum_j sum_b [Pij(jb, ia) + Pi(jb) Pi(ia)] <= 2 N Pi(ia)).  At the
 // pseudocounts gDCA is used with that cheap bound already settles the question and every workgroup leaves at once; where it does
 // not (pc = 0.2 with a conserved column; small pc), the columns are summed -- one pass over C before the sweep overwrites it.
-__global__ __launch_bounds__(256) void k_cov_norm1(const double *__restrict__ C, size_t ld, int n, int N, int q, double pc, double cond_limit,
-                                                    gdca_dev_scalars *__restrict__ sc, int always)
+struct k_cov_norm1_args {
+    const double *C;
+    size_t ld;
+    int n;
+    int N;
+    int q;
+    double pc;
+    double cond_limit;
+    gdca_dev_scalars *sc;
+    int always;
+};
+static inline k_cov_norm1_args k_cov_norm1_mk(const double *C, size_t ld, int n, int N, int q, double pc, double cond_limit, gdca_dev_scalars *sc, int always)
 {
+    return k_cov_norm1_args{C, ld, n, N, q, pc, cond_limit, sc, always};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_cov_norm1(const BatchArgs<k_cov_norm1_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const double *__restrict__ C = a_.C;
+    size_t ld = a_.ld;
+    int n = a_.n;
+    int N = a_.N;
+    int q = a_.q;
+    double pc = a_.pc;
+    double cond_limit = a_.cond_limit;
+    gdca_dev_scalars *__restrict__ sc = a_.sc;
+    int always = a_.always;
     const double cheap = pc > 0.0 ? 2.0 * (double)N * sc->pi_max * (double)q * (double)q / pc : HUGE_VAL;
     if (!always && cheap <= cond_limit) return;
     __shared__ double red[256];
@@ -130,15 +202,14 @@ __global__ __launch_bounds__(256) void k_cov_norm1(const double *__restrict__ C,
 
 void gdca_launch_cov_norm1(hipStream_t s, const double *C, size_t ld, int N, int q, double pc, double cond_limit, gdca_dev_scalars *sc, int always)
 {
-    hipLaunchKernelGGL(k_cov_norm1, dim3(512), dim3(256), 0, s, C, ld, N * (q - 1), N, q, pc, cond_limit, sc, always);
+    (gdca_launch<k_cov_norm1_args, k_cov_norm1<1>, k_cov_norm1<GDCA_MAXB>>(dim3(512), dim3(256), 0, s, k_cov_norm1_mk(C, ld, N * (q - 1), N, q, pc, cond_limit, sc, always)));
 }
 
 void gdca_launch_pi_finalize(hipStream_t s, const u64 *Pifix, int N, int q, int fix_shift, const double *Meff_dev,
                              double pc, double *Pi_true, double *Pi_pc, double *pi_max)
 {
     const int n = N * (q - 1);
-    hipLaunchKernelGGL(k_pi_finalize, dim3((n + 255) / 256), dim3(256), 0, s, Pifix, N, q, fix_shift, Meff_dev, pc,
-                       Pi_true, Pi_pc, pi_max);
+    (gdca_launch<k_pi_finalize_args, k_pi_finalize<1>, k_pi_finalize<GDCA_MAXB>>(dim3((n + 255) / 256), dim3(256), 0, s, k_pi_finalize_mk(Pifix, N, q, fix_shift, Meff_dev, pc, Pi_true, Pi_pc, pi_max)));
 }
 
 // ---- pair tallies -----------------------------------------------------------------------------------
@@ -148,9 +219,26 @@ void gdca_launch_pi_finalize(hipStream_t s, const u64 *Pifix, int N, int q, int 
 // Z [M][N] -> Zc [ceil(N/TJ)][M][TJ] (zero padded): for one column block the TJ bytes of
 // consecutive sequences are consecutive in memory, so a workgroup's staging loads are fully
 // coalesced 16-byte accesses with no over-fetch.  Tile transpose through LDS.
-__global__ __launch_bounds__(256) void k_colblock(const int8_t *__restrict__ Z, int8_t *__restrict__ Zc, int N, int M,
-                                                   int TJ)
+struct k_colblock_args {
+    const int8_t *Z;
+    int8_t *Zc;
+    int N;
+    int M;
+    int TJ;
+};
+static inline k_colblock_args k_colblock_mk(const int8_t *Z, int8_t *Zc, int N, int M, int TJ)
 {
+    return k_colblock_args{Z, Zc, N, M, TJ};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_colblock(const BatchArgs<k_colblock_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    int8_t *__restrict__ Zc = a_.Zc;
+    int N = a_.N;
+    int M = a_.M;
+    int TJ = a_.TJ;
     __shared__ int8_t tile[64][64 + 4];
     const int k0 = blockIdx.y * 64, c0 = blockIdx.x * 64;  // 64 sequences x 64 columns
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -175,7 +263,7 @@ __global__ __launch_bounds__(256) void k_colblock(const int8_t *__restrict__ Z, 
 void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int M, int TJ)
 {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(k_colblock, grid, dim3(256), 0, s, Z, Zc, N, M, TJ);
+    (gdca_launch<k_colblock_args, k_colblock<1>, k_colblock<GDCA_MAXB>>(grid, dim3(256), 0, s, k_colblock_mk(Z, Zc, N, M, TJ)));
 }
 
 // Workgroup = (column i) x (block of TJ columns j >= i's block), 1024 threads = 16 waves (the
@@ -189,12 +277,42 @@ void gdca_launch_colblock(hipStream_t s, const int8_t *Z, int8_t *Zc, int N, int
 // The histogram has s+2 columns per row (b = 0 and b = q are junk columns for padding / gaps) so
 // the inner loop needs no validity test at all: an invalid Z[i,k] is staged as weight 0, lanes left
 // of the diagonal tally into columns the epilogue never reads.
-template <int TJ>
-__global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(
-    const int8_t *__restrict__ Zc, const int8_t *__restrict__ Zt, const u64 *__restrict__ Wfix, int N, int M,
-    int q, int fix_shift, const double *__restrict__ Meff_dev, double pc, const double *__restrict__ Pi_pc, int mode,
-    double *__restrict__ out, size_t ld)
+struct k_pair_tally_args {
+    const int8_t *Zc;
+    const int8_t *Zt;
+    const u64 *Wfix;
+    int N;
+    int M;
+    int q;
+    int fix_shift;
+    const double *Meff_dev;
+    double pc;
+    const double *Pi_pc;
+    int mode;
+    double *out;
+    size_t ld;
+};
+static inline k_pair_tally_args k_pair_tally_mk(const int8_t *Zc, const int8_t *Zt, const u64 *Wfix, int N, int M, int q, int fix_shift, const double *Meff_dev, double pc, const double *Pi_pc, int mode, double *out, size_t ld)
 {
+    return k_pair_tally_args{Zc, Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld};
+}
+template <int CAP, int TJ>
+__global__ __launch_bounds__(TALLY_THREADS) void k_pair_tally(const BatchArgs<k_pair_tally_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Zc = a_.Zc;
+    const int8_t *__restrict__ Zt = a_.Zt;
+    const u64 *__restrict__ Wfix = a_.Wfix;
+    int N = a_.N;
+    int M = a_.M;
+    int q = a_.q;
+    int fix_shift = a_.fix_shift;
+    const double *__restrict__ Meff_dev = a_.Meff_dev;
+    double pc = a_.pc;
+    const double *__restrict__ Pi_pc = a_.Pi_pc;
+    int mode = a_.mode;
+    double *__restrict__ out = a_.out;
+    size_t ld = a_.ld;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = q - 1;
     const int i = blockIdx.y;
@@ -341,14 +459,8 @@ void gdca_launch_pair_tally(hipStream_t st, const int8_t *Zc, const int8_t *Zt, 
 {
     const int s = q - 1;
     if (TJ == 32) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_pair_tally<32>, dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+        (gdca_launch<k_pair_tally_args, k_pair_tally<1, 32>, k_pair_tally<GDCA_MAXB, 32>>(dim3((N + 31) / 32, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 32), st, k_pair_tally_mk(Zc, Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld)));
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_tally<16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_pair_tally<16>, dim3((N + 15) / 16, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 16), st, Zc,
-                           Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld);
+        (gdca_launch<k_pair_tally_args, k_pair_tally<1, 16>, k_pair_tally<GDCA_MAXB, 16>>(dim3((N + 15) / 16, N), dim3(TALLY_THREADS), tally_lds_bytes(s, 16), st, k_pair_tally_mk(Zc, Zt, Wfix, N, M, q, fix_shift, Meff_dev, pc, Pi_pc, mode, out, ld)));
     }
 }

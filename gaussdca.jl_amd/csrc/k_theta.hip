@@ -6,11 +6,27 @@
 // follows from the per-column symbol counts c_ia, so this stage is one O(N*M) streaming
 // pass (HBM-bound, N*M bytes) instead of M^2 N / 2 compares.  All integer, exact.
 #include "gdca_internal.h"
+#include "gdca_launch.h"
 
 // ---- Z [M][N] -> Zt [N][M] (byte transpose through LDS, 64 x 64 tiles) ---------------------
-__global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__ Z, int8_t *__restrict__ Zt,
-                                                       int N, int M)
+struct k_transpose_i8_args {
+    const int8_t *Z;
+    int8_t *Zt;
+    int N;
+    int M;
+};
+static inline k_transpose_i8_args k_transpose_i8_mk(const int8_t *Z, int8_t *Zt, int N, int M)
 {
+    return k_transpose_i8_args{Z, Zt, N, M};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_transpose_i8(const BatchArgs<k_transpose_i8_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    int8_t *__restrict__ Zt = a_.Zt;
+    int N = a_.N;
+    int M = a_.M;
     __shared__ int8_t tile[64][65];
     const int k0 = blockIdx.y * 64, i0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -30,16 +46,33 @@ __global__ __launch_bounds__(256) void k_transpose_i8(const int8_t *__restrict__
 void gdca_launch_transpose_i8(hipStream_t s, const int8_t *Z, int8_t *Zt, int N, int M)
 {
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(k_transpose_i8, grid, dim3(256), 0, s, Z, Zt, N, M);
+    (gdca_launch<k_transpose_i8_args, k_transpose_i8<1>, k_transpose_i8<GDCA_MAXB>>(grid, dim3(256), 0, s, k_transpose_i8_mk(Z, Zt, N, M)));
 }
 
 // ---- per-column symbol counts ---------------------------------------------------------------
 // One thread owns one alignment column; its 32 counters sit in LDS as h[z][thread] so that a
 // wave's 64 lanes always hit 64 different banks whatever the symbols are.  No atomics inside
 // the workgroup (each counter has one owner); one global integer atomic per non-zero counter.
-__global__ __launch_bounds__(256) void k_column_hist(const int8_t *__restrict__ Z, uint32_t *__restrict__ cnt,
-                                                      int N, int M, int seq_per_block)
+struct k_column_hist_args {
+    const int8_t *Z;
+    uint32_t *cnt;
+    int N;
+    int M;
+    int seq_per_block;
+};
+static inline k_column_hist_args k_column_hist_mk(const int8_t *Z, uint32_t *cnt, int N, int M, int seq_per_block)
 {
+    return k_column_hist_args{Z, cnt, N, M, seq_per_block};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_column_hist(const BatchArgs<k_column_hist_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const int8_t *__restrict__ Z = a_.Z;
+    uint32_t *__restrict__ cnt = a_.cnt;
+    int N = a_.N;
+    int M = a_.M;
+    int seq_per_block = a_.seq_per_block;
     __shared__ uint32_t h[32][256];
     const int t = threadIdx.x;
     const int i = blockIdx.x * 256 + t;
@@ -79,13 +112,30 @@ void gdca_launch_column_hist(hipStream_t s, const int8_t *Z, uint32_t *cnt, int 
     int spb = (M + chunks - 1) / chunks;
     if (spb < 64) spb = 64;
     chunks = (M + spb - 1) / spb;
-    hipLaunchKernelGGL(k_column_hist, dim3(cb, chunks), dim3(256), 0, s, Z, cnt, N, M, spb);
+    (gdca_launch<k_column_hist_args, k_column_hist<1>, k_column_hist<GDCA_MAXB>>(dim3(cb, chunks), dim3(256), 0, s, k_column_hist_mk(Z, cnt, N, M, spb)));
 }
 
 // ---- theta, threshold -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_theta_finalize(const uint32_t *__restrict__ cnt, int N, int M,
-                                                         double theta_in, gdca_dev_scalars *sc)
+struct k_theta_finalize_args {
+    const uint32_t *cnt;
+    int N;
+    int M;
+    double theta_in;
+    gdca_dev_scalars *sc;
+};
+static inline k_theta_finalize_args k_theta_finalize_mk(const uint32_t *cnt, int N, int M, double theta_in, gdca_dev_scalars *sc)
 {
+    return k_theta_finalize_args{cnt, N, M, theta_in, sc};
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void k_theta_finalize(const BatchArgs<k_theta_finalize_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    const uint32_t *__restrict__ cnt = a_.cnt;
+    int N = a_.N;
+    int M = a_.M;
+    double theta_in = a_.theta_in;
+    gdca_dev_scalars *sc = a_.sc;
     __shared__ unsigned long long red[256];
     double theta = theta_in;
     if (theta_in < 0.0) {
@@ -125,15 +175,27 @@ __global__ __launch_bounds__(256) void k_theta_finalize(const uint32_t *__restri
 void gdca_launch_theta_finalize(hipStream_t s, const uint32_t *cnt, int N, int M, double theta_in,
                                 gdca_dev_scalars *sc)
 {
-    hipLaunchKernelGGL(k_theta_finalize, dim3(1), dim3(256), 0, s, cnt, N, M, theta_in, sc);
+    (gdca_launch<k_theta_finalize_args, k_theta_finalize<1>, k_theta_finalize<GDCA_MAXB>>(dim3(1), dim3(256), 0, s, k_theta_finalize_mk(cnt, N, M, theta_in, sc)));
 }
 
-__global__ void k_set_thresh(gdca_dev_scalars *sc, int thresh)
+struct k_set_thresh_args {
+    gdca_dev_scalars *sc;
+    int thresh;
+};
+static inline k_set_thresh_args k_set_thresh_mk(gdca_dev_scalars *sc, int thresh)
 {
+    return k_set_thresh_args{sc, thresh};
+}
+template <int CAP>
+__global__ void k_set_thresh(const BatchArgs<k_set_thresh_args, CAP> B_)
+{
+    GDCA_MEMBER(B_);
+    gdca_dev_scalars *sc = a_.sc;
+    int thresh = a_.thresh;
     sc->thresh = thresh;
 }
 
 void gdca_launch_set_thresh(hipStream_t s, gdca_dev_scalars *sc, int thresh)
 {
-    hipLaunchKernelGGL(k_set_thresh, dim3(1), dim3(1), 0, s, sc, thresh);
+    (gdca_launch<k_set_thresh_args, k_set_thresh<1>, k_set_thresh<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_set_thresh_mk(sc, thresh)));
 }
