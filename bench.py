@@ -469,7 +469,10 @@ def main():
             plan = (("C_DI", "C", "DI", 20, 3, 1, False, 256), ("B", "B", "frob", 40, 5, 1, False, 256),
                     ("B_merged8", "B", "frob", 80, 8, 8, True, 256), ("D", "D", "frob", 5, 1, 1, False, 256),
                     ("E32", "E", "frob", 2, 1, 1, False, 32), ("E32_p2", "E", "frob", 2, 1, 2, False, 32),
-                    ("E32_phased8", "E", "frob", 2, 1, 8, True, 32))
+                    ("E32_phased8", "E", "frob", 2, 1, 8, True, 32),
+                    # the WHOLE batch of BASELINE.json configs[4] on this one GPU, best schedule (phase batches of sixteen, the small
+                    # inverses merged, the batch's kernels as batched grids): one warm-up pass and one timed pass, ~7 s
+                    ("E256", "E", "frob", 1, 1, 16, True, 256))
             for key, cname, sc, st_, wu, P_, ph_, nf in plan:
                 try:
                     a2 = argparse.Namespace(**vars(args))
@@ -542,12 +545,14 @@ def measure(args, config, score_name, steps, warmup, rank, world, local, dev, di
     nmax = max(f[1] for f in fams)
     Sd = [torch.empty((nmax, nmax), dtype=torch.float64, device=dev) for _ in range(P)]  # stay in HBM
     ctxs = [g.Context(local)]
+    # (phase batches: every context of both alternating sets is a peer of ONE pipeline -- its batches are then one in-order sequence
+    # on the pipeline's stream: no hand-over between two streams that may share a hardware queue, 400 us at config B)
     for _ in range(P - 1):
-        ctxs.append(ctxs[0].peer() if args.gate else g.Context(local))
+        ctxs.append(ctxs[0].peer() if (args.gate or phased) else g.Context(local))
     busy = [False] * P
     ctxs2, Sd2 = [], []
     if phased:
-        ctxs2 = [g.Context(local) for _ in range(P)]
+        ctxs2 = [ctxs[0].peer() for _ in range(P)]
         Sd2 = [torch.empty((nmax, nmax), dtype=torch.float64, device=dev) for _ in range(P)]
 
     def run_steps_phased(count, sink):

@@ -26,6 +26,11 @@ struct gdca_buf {
 struct gdca_gate {
     hipEvent_t ev[4];
     int next, last, armed, refs;
+    // the pipeline's own stream: every phase batch issued as batched grids by a member of the pipeline goes here, so that the batches
+    // of two alternating context sets are ONE in-order sequence -- two streams that share a hardware queue take turns with hundreds
+    // of microseconds between them (400 us measured between one set's score stage and the other's front end at config B), and on
+    // different hardware queues the next batch's small kernels become resident beside the running persistent sweep
+    hipStream_t batch_stream;
 };
 
 struct gdca_ctx {
@@ -65,6 +70,7 @@ struct gdca_ctx {
     bool stamped;              // the run being enqueued marks its stages with device time stamps (sc->stamp) instead of HIP events: a member of a batch issued as batched grids
     bool pend_inv_stamped;     // the enqueued run's inverse was a merged launch bracketed by stamps (slots 6 / 16 before, 17 / 4 behind) instead of events
     bool pend_stamped;         // ... and the enqueued run did so: its collect reads the stamps
+    int pend_score_batch;      // ... and of its score grids
     int pend_front_batch;      // members that shared this run's batched front-end / score grids (1: grids of its own); their stage times are the grids' divided by it
     bool pend_fn_timed, pend_tally_timed;  // events 7 / 8 around k_fn, 9 / 10 around k_pair_tally were recorded by this run
     int pend_N, pend_M, pend_q, pend_n, pend_npad, pend_nupd;
@@ -230,7 +236,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
         {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 32},        {"MCU_SOLO", &t->mcu_solo, -1, 1},       {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
-        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_GRIDS", &t->phased_grids, 0, 1}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
+        {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_GRIDS", &t->phased_grids, -1, 8}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
     };
     for (auto &e : ints)
         if (!strcmp(k, e.name)) {
@@ -280,7 +286,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->merge_group = -1;
     t->merge_tiles = 2300;
     t->phased_fronts = 1;
-    t->phased_grids = 1;
+    t->phased_grids = -1;
     t->phased_streams = 4;
     t->refine = -1;
     t->refine_cond = 1e6;
@@ -428,6 +434,9 @@ gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
         if (!g) return GDCA_ENOMEM;
         for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming));
         g->refs = 1;
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&g->batch_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) g->batch_stream = nullptr;
         leader->gate = g;
     }
     gdca_status st = gdca_ctx_create(leader->device, out);
@@ -451,6 +460,10 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
         if (ctx->scratch[i].p) (void)hipFree(ctx->scratch[i].p);
     if (ctx->gate && --ctx->gate->refs == 0) {
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->gate->ev[i]);
+        if (ctx->gate->batch_stream) {
+            (void)hipStreamSynchronize(ctx->gate->batch_stream);
+            (void)hipStreamDestroy(ctx->gate->batch_stream);
+        }
         free(ctx->gate);
     }
     for (int i = 0; i < ctx->n_ev; ++i) (void)hipEventDestroy(ctx->ev[i]);
@@ -922,7 +935,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
             // (a family whose inverse shared a merged launch with others reports its share of that launch: the launch's time
             // divided by the families it carried -- the sum over the members is the launch)
             const double share = 1.0 / (double)(ctx->pend_batch > 0 ? ctx->pend_batch : 1);
-            st->ms_score = between(11, 5) * fshare;
+            st->ms_score = between(11, 5) / (double)(ctx->pend_score_batch > 0 ? ctx->pend_score_batch : 1);
             if (ctx->pend_inv_stamped) {
                 st->ms_inverse = (double)(long long)(h.stamp[4] - h.stamp[6]) * 1e-5 * share;
                 st->ms_inverse_update = (double)(long long)(h.stamp[17] - h.stamp[16]) * 1e-5 * share;
@@ -933,7 +946,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
                 HIPCHK(hipEventElapsedTime(&ms, ctx->pend_upd_ev[0], ctx->pend_upd_ev[1]));
                 st->ms_inverse_update = ms * share;
             }
-            if (ctx->pend_fn_timed && ctx->pend_refined == 0) st->ms_fn = between(7, 8) * fshare;
+            if (ctx->pend_fn_timed && ctx->pend_refined == 0) st->ms_fn = between(7, 8) / (double)(ctx->pend_score_batch > 0 ? ctx->pend_score_batch : 1);
             if (ctx->pend_tally_timed && ctx->pend_refined == 0) st->ms_pair_tally = between(9, 10) * fshare;
             if (tfail) return fail(ctx, GDCA_EHIP, "hipEventElapsedTime%s%s", "", "");
         }
@@ -993,6 +1006,7 @@ static gdca_status run_front(gdca_ctx *ctx, const int8_t *Z_dev, int32_t N, int3
     ctx->pend_timed = timed;
     ctx->pend_stamped = ctx->stamped;
     ctx->pend_front_batch = 1;
+    ctx->pend_score_batch = 1;
     ctx->pend_tally_timed = timed && ctx->tune.refine != 0;
     ctx->pend_fn_timed = false;
     ctx->pend_Z = Z_dev;
@@ -1232,12 +1246,12 @@ static gdca_status run_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *co
     // their own workspaces, scalars and timing events; their streams are restored before returning.
     hipStream_t own[64], use[64];
     if (K > 64) return fail(lead, GDCA_EINVAL, "at most 64 families per batch%s%s", "", "");
-    // Round 6, the default (option PHASED_GRIDS=1): the members' kernels of a KIND as ONE grid (gdca_launch.h).  The front ends are
+    // Round 6, the default (option PHASED_GRIDS != 0): the members' kernels of a KIND as ONE grid (gdca_launch.h).  The front ends are
     // recorded member by member, then issued in lockstep on the leader's stream -- ~25 launches per batch instead of ~25 per member,
     // every one with all members' workgroups on the chip at once --, then the inverses, then the score stages (and, for the ranked
     // entry, the rankings) the same way.  Stage boundaries are time stamps written by kernels of the batch, not events.  Bit for bit
     // the results of the other schedules: a kernel body cannot tell which launch form runs it.
-    if (lead->tune.phased_grids != 0 && K > 1) {
+    if (lead->tune.phased_grids != 0 && K > 1) {  // (-1: the rule below; 1 .. 8: that many groups)
         for (int k = 0; k < K; ++k) {
             own[k] = ctxs[k]->stream;
             if (k > 0) (void)hipStreamSynchronize(own[k]);  // nothing of an earlier use is still in flight on the member's own stream
@@ -1245,20 +1259,54 @@ static gdca_status run_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *co
         gdca_status st = GDCA_OK;
         int done_front = 0, failed = -1;
         gdca_recorder rec;
-        rec.begin(lead->stream, K);
-        for (int k = 0; k < K && st == GDCA_OK; ++k) {
-            ctxs[k]->stream = lead->stream;
-            ctxs[k]->stamped = true;
-            rec.member(k);
-            st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
-            if (st == GDCA_OK) ++done_front; else failed = k;
+        // the batch's stream: the pipeline's (gdca_gate) where the leader belongs to one, behind whatever its own stream holds
+        hipStream_t bs = lead->gate && lead->gate->batch_stream ? lead->gate->batch_stream : lead->stream;
+        if (bs != lead->stream && (hipEventRecord(lead->ev_upload, lead->stream) != hipSuccess || hipStreamWaitEvent(bs, lead->ev_upload, 0) != hipSuccess))
+            return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
+        // G groups of members (member k in group k mod G), each group's front ends as batched grids on a stream of its own -- the
+        // leader's and the next members' --, the groups side by side: a VALU-bound reweighting of one group runs beside the
+        // LDS-atomic-bound pair tallies of another.  One group (everything in lockstep) where the members are small: their kernels
+        // are launch-bound and two groups would be twice the launches.
+        int G = lead->tune.phased_grids;
+        if (G < 0) {
+            double work = 0.0;  // symbol compares + tallies of the batch's front ends
+            for (int k = 0; k < K; ++k) work += 0.5 * (double)M[k] * (double)M[k] * (double)N[k] + 0.5 * (double)N[k] * (double)N[k] * (double)M[k];
+            G = work / K > 2e10 ? 4 : 1;
         }
-        rec.member(-1);
-        if (rec.flush() != hipSuccess && st == GDCA_OK) st = fail(lead, GDCA_EHIP, "a batched front-end launch failed%s%s", "", "");
-        for (int k = 0; k < done_front; ++k) ctxs[k]->pend_front_batch = done_front;
+        G = std::max(1, std::min(std::min(G, (int)K), 8));
+        int in_group[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int gi = 0; gi < G && st == GDCA_OK; ++gi) {
+            hipStream_t sg = gi == 0 ? bs : own[gi];
+            rec.begin(sg, K);
+            for (int k = gi; k < K && st == GDCA_OK; k += G) {
+                ctxs[k]->stream = sg;
+                ctxs[k]->stamped = true;
+                rec.member(k);
+                st = run_front(ctxs[k], Z_dev[k], N[k], M[k], q[k], p);
+                if (st == GDCA_OK) {
+                    ++done_front;
+                    ++in_group[gi];
+                } else {
+                    failed = k;
+                }
+            }
+            rec.member(-1);
+            if (rec.flush() != hipSuccess && st == GDCA_OK) st = fail(lead, GDCA_EHIP, "a batched front-end launch failed%s%s", "", "");
+            // the batch's stream goes on behind this group's front ends
+            if (st == GDCA_OK && gi > 0 &&
+                (hipEventRecord(ctxs[gi]->ev_batch, sg) != hipSuccess || hipStreamWaitEvent(bs, ctxs[gi]->ev_batch, 0) != hipSuccess))
+                st = fail(lead, GDCA_EHIP, "event chain of the batch's front ends%s%s", "", "");
+        }
+        if (st != GDCA_OK) done_front = 0;  // (nothing of a batch that failed to enqueue is run any further; it is drained below)
+        for (int k = 0; k < K; ++k) {
+            ctxs[k]->stream = bs;
+            if (st == GDCA_OK) ctxs[k]->pend_front_batch = in_group[k % G];
+        }
+        rec.begin(bs, K);
         if (st == GDCA_OK) st = run_inverses(lead, ctxs, done_front);
         for (int k = 0; k < done_front && st == GDCA_OK; ++k) {
             rec.member(k);
+            ctxs[k]->pend_score_batch = done_front;
             st = run_score(ctxs[k], p, S_dev[k]);
             if (st == GDCA_OK && rank_sep > 0) {
                 gdca_ctx *m = ctxs[k];
@@ -1273,15 +1321,16 @@ static gdca_status run_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *co
         if (rec.end() != hipSuccess && st == GDCA_OK) st = fail(lead, GDCA_EHIP, "a batched score launch failed%s%s", "", "");
         if (ranked && st == GDCA_OK && rank_sep > 0) *ranked = true;
         // the members' collects synchronise THEIR stream: every one of them waits for the batch (one event on the batch's stream)
-        bool chained = st == GDCA_OK && hipEventRecord(lead->ev_batch, lead->stream) == hipSuccess;
-        for (int k = 1; k < K && chained; ++k) chained = hipStreamWaitEvent(own[k], lead->ev_batch, 0) == hipSuccess;
+        bool chained = st == GDCA_OK && hipEventRecord(lead->ev_batch, bs) == hipSuccess;
+        for (int k = bs == own[0] ? 1 : 0; k < K && chained; ++k) chained = hipStreamWaitEvent(own[k], lead->ev_batch, 0) == hipSuccess;
         for (int k = 0; k < K; ++k) {
             ctxs[k]->stream = own[k];
             ctxs[k]->stamped = false;
         }
         if (st != GDCA_OK) {
-            (void)hipStreamSynchronize(lead->stream);
+            (void)hipStreamSynchronize(bs);
             for (int k = 0; k < K; ++k) {
+                (void)hipStreamSynchronize(own[k]);  // (a group's front ends)
                 ctxs[k]->pending = false;
                 ctxs[k]->rank_pending = false;
             }
@@ -1293,7 +1342,7 @@ static gdca_status run_phased(gdca_ctx *const *ctxs, int32_t K, const int8_t *co
             return st;
         }
         if (!chained) {
-            (void)hipStreamSynchronize(lead->stream);
+            (void)hipStreamSynchronize(bs);
             return fail(lead, GDCA_EHIP, "event chain of the batch%s%s", "", "");
         }
         return GDCA_OK;

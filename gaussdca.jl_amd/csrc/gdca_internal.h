@@ -22,7 +22,7 @@ struct gdca_dev_scalars {
     int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
     int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement
     int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
-    unsigned ham_ncand;  // pairs the bound form has put (or tried to put) into its candidate list: beyond the list's capacity the exact form counts
+    unsigned long long ham_ncand;  // pairs the bound form has put (or tried to put) into its candidate list: beyond the list's capacity the exact form counts
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
     double inv_norm1;  // ||inverse||_1 as the sweep left it (0: not measured)
     double ns_resid;     // max |I - X0 C| seen by the Newton-Schulz step (0: no step)
@@ -59,7 +59,7 @@ struct gdca_tuning {
     int merge_group;        // GDCA_MERGE_GROUP: pivot blocks per group of a member of a merged launch, 1..4
     int merge_tiles;        // GDCA_MERGE_TILES: a merged launch is closed once its members hold this many tiles per update step
     int phased_fronts;      // GDCA_PHASED_FRONTS: 1 = the front ends of a phase batch run side by side on the members' own streams (default), 0 = one after the other on the leader's
-    int phased_grids;       // GDCA_PHASED_GRIDS: 1 = the kernels of a phase batch's front ends and score stages go out as ONE grid per kernel kind carrying all members (default), 0 = one launch per member and kernel
+    int phased_grids;       // GDCA_PHASED_GRIDS: the kernels of a phase batch's front ends and score stages go out as ONE grid per kernel kind carrying all members of a group: 1 .. 8 = that many groups of members side by side (front ends; the score stages are always one group), -1 = by the batch's work (default: one group for small families, four for big ones), 0 = one launch per member and kernel
     int phased_streams;     // GDCA_PHASED_STREAMS: streams the side-by-side front ends and score stages of a phase batch are spread over (the first members' own; default 4 = the hardware queues)
     int refine;             // GDCA_REFINE: -1 = one Newton-Schulz step where the inverse looks ill-conditioned (auto), 0 = never, 1 = always
     double refine_cond;     // GDCA_REFINE_COND: the threshold of auto: the a-priori bound of cond_2(C) first, beyond it kappa_1 = ||C||_1 ||X||_1

@@ -108,7 +108,7 @@ inline void gdca_issue(hipStream_t s, const gdca_op *const *ops, int n)
     if (n == 1) {
         BatchArgs<Args, 1> B;
         memcpy(&B.m[0], ops[0]->args, sizeof(Args));
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(K1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(K1, ops[0]->grid, ops[0]->block, lds, s, B);
         return;
     }
@@ -128,7 +128,7 @@ inline void gdca_issue(hipStream_t s, const gdca_op *const *ops, int n)
     }
     for (int i = n; i <= GDCA_MAXB; ++i) B.first[i] = total;
     B.n = n;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KB), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(KB), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(KB, dim3(total), ops[0]->block, lds, s, B);
 }
 

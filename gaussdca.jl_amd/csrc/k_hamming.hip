@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256) void k_hamming_refine(const BatchArgs<k_hammin
     int32_t *__restrict__ cnt = a_.cnt;
     const gdca_dev_scalars *__restrict__ sc = a_.sc;
     if (sc->ham_mode != 1) return;
-    const unsigned total = sc->ham_ncand;
-    if (total > cap) return;  // the list overflowed: the exact form counts this family
+    if (sc->ham_ncand > (unsigned long long)cap) return;  // the list overflowed: the exact form counts this family
+    const unsigned total = (unsigned)sc->ham_ncand;
     const int thresh = sc->thresh;
     const int tid = threadIdx.x, sub = tid & 15, grp = (tid & 63) >> 4;
     const unsigned wave = blockIdx.x * 4u + (unsigned)(tid >> 6), nwave = gridDim.x * 4u;
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(256, 3) void k_hamming(const BatchArgs<k_hamming_ar
         const unsigned mine = (unsigned)__builtin_popcountll(cand);
         const unsigned off = mine ? atomicAdd(&hm_tile_n, mine) : 0u;
         __syncthreads();
-        // (once the counter is past the capacity nothing is listed any more and the exact form counts the family: stop adding, so that
-        // a dense family of M > 92 000 -- more than 2^32 candidate pairs -- cannot wrap the 32-bit counter back below the capacity;
-        // the overshoot is bounded by the tiles in flight x 16 384)
+        // (a 64-bit counter: a dense family of M > 92 000 has more than 2^32 candidate pairs, and a 32-bit count of them could wrap back
+        // below the capacity.  ONE returning atomic per tile -- a load of the counter in front of it, to stop adding once it is past the
+        // capacity, cost config C 1.2 ms: loads of a line that is busy with atomics queue up behind them)
         if (tid == 0) {
-            const unsigned cur = __hip_atomic_load(&sc->ham_ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hm_tile_base = cur > cand_cap ? cur : atomicAdd(&sc->ham_ncand, hm_tile_n);
+            const unsigned long long base = atomicAdd(&sc->ham_ncand, (unsigned long long)hm_tile_n);
+            hm_tile_base = base > (unsigned long long)cand_cap ? cand_cap : (unsigned)base;  // (beyond the capacity nothing is written)
         }
         __syncthreads();
         unsigned slot = hm_tile_base + off;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(FN20_THREADS) void k_fn20(const BatchArgs<k_fn20_ar
 // ncu: compute units of the device (the s = 20 form is a persistent grid)
 void gdca_launch_fn(hipStream_t s, const double *A, size_t ld, int N, int sdim, double *S, int ncu)
 {
-    (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
+    gdca_fill_async(s, S, 0, (size_t)N * N * sizeof(double));
     if (N < 2) return;
     const int nJ = (N + FN_PG - 1) / FN_PG;   // row chunks (a column site's workgroups past its last chunk leave at once)
     const dim3 nwg((unsigned)nJ, (unsigned)(N - 1));
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64) void k_di_ql(const BatchArgs<k_di_ql_args, CAP>
 void gdca_launch_di(hipStream_t s, const double *A, size_t ld, const double *Ld, int N, int sdim, double *S,
                     double *Tws, gdca_dev_scalars *sc)
 {
-    (void)hipMemsetAsync(S, 0, (size_t)N * N * sizeof(double), s);
+    gdca_fill_async(s, S, 0, (size_t)N * N * sizeof(double));
     const long long npairs = (long long)N * (N - 1) / 2;
     if (npairs <= 0) return;
     const long long tstride = (npairs + 63) / 64 * 64;

@@ -449,7 +449,23 @@ def test_phase_batched_runs_equal_single_runs(g, ctx, o):
             c.collect()
         for k in range(len(cs)):
             assert torch.equal(outs[k].cpu(), ref[k]), (score, "group 1", k)
-        cs[0].set_options(MERGE_GROUP=-1, PHASED_STREAMS=4)
+        # Round 6: the members' kernels of a kind as ONE grid (PHASED_GRIDS: 1, 2, 4 groups side by side, -1 the rule; 0 = a launch
+        # per member and kernel) -- the same bits in every form, from independent contexts and from the peers of one pipeline
+        # (whose batches all go to the pipeline's stream); stage times come from device time stamps and are sane
+        peers = [cs[0]] + [cs[0].peer() for _ in fams[1:]]
+        for grids, cset in ((0, cs), (1, cs), (2, cs), (4, peers), (-1, peers), (1, peers)):
+            cset[0].set_options(PHASED_GRIDS=grids)
+            outs = [torch.zeros((z.shape[1], z.shape[1]), dtype=torch.float64, device="cuda") for z in fams]
+            g.run_dev_phased(cset, [zd.data_ptr() for zd in Zd], [z.shape[1] for z in fams], [z.shape[0] for z in fams],
+                             [21] * len(fams), pc, -1.0, score, [x.data_ptr() for x in outs])
+            sts = [c.collect() for c in cset]
+            for k in range(len(cset)):
+                assert torch.equal(outs[k].cpu(), ref[k]), (score, "grids", grids, k)
+                assert sts[k]["Meff"] == ref_st[k]["Meff"] and sts[k]["info"] == 0
+                for key in ("ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update", "ms_score"):
+                    assert 0.0 < sts[k][key] < 1e3, (grids, k, key, sts[k][key])
+                assert sts[k]["ms_total"] >= sts[k]["ms_inverse"]
+        cs[0].set_options(MERGE_GROUP=-1, PHASED_STREAMS=4, PHASED_GRIDS=-1)
         with pytest.raises(g.ArgumentError):
             g.run_dev_phased([cs[0], cs[0]], [Zd[0].data_ptr()] * 2, [40] * 2, [500] * 2, [21] * 2, pc, -1.0, score,
                              [outs[0].data_ptr()] * 2)               # the same context twice
