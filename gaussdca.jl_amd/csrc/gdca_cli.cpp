@@ -39,7 +39,7 @@ struct Options {
     int score = GDCA_SCORE_FROB, min_separation = 5;
     bool remove_dups = false;
     std::string batch_dir, out_dir;
-    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1, merge = 1 /* small families per merged batch (--merge K, up to 8); 1 = off: see the worker */, merge_blocks = 24 /* largest covariance of a "small" family, in 128-blocks */;
+    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1, merge = 1 /* families per phase batch (--merge K, up to 32); 1 = off: see the worker */, merge_blocks = 24 /* largest covariance of a "small" family, in 128-blocks */;
     bool parse_only = false;
     std::vector<std::string> positional;
 };
@@ -399,7 +399,8 @@ int run_batch(const Options &o)
     const double t0 = now();
     std::vector<double> busy((size_t)G, 0.0);
     std::vector<int> count((size_t)G, 0);
-    double first_done = 0.0, last_done = 0.0;  // completion times of the first and the last family (steady-state rate, start-up excluded)
+    std::vector<double> done_at;  // completion time of every family, in order (steady-state rate: start-up -- process start, HIP initialisation,
+                                  // the first parses, the first batch -- excluded)
     int completed = 0;
     // One worker thread per GPU drives a PIPELINE of --inflight contexts (the leader and its peers, gdca_ctx_create_peer): family k+1
     // is uploaded and enqueued while family k computes, and family k is collected only when its context is needed again -- the GPU
@@ -441,8 +442,8 @@ int run_batch(const Options &o)
             ++done;
             {
                 std::lock_guard<std::mutex> lk(omu);
-                last_done = now();
-                if (completed++ == 0) first_done = last_done;
+                done_at.push_back(now());
+                ++completed;
             }
             if (rc != GDCA_OK) {
                 if (rc == GDCA_ENOTPD)
@@ -474,6 +475,11 @@ int run_batch(const Options &o)
         // lost their side streams and the collects their blit kernels, DESIGN.md section 5, the worker thread's launches and collects
         // bound both); creating the sixteen extra contexts costs ~0.1 s once.  On the mixed batch of configuration E merged batches
         // neither gain nor lose (72.4-72.8 against 72.8 families/s).  --merge 8 is the setting for batches of small families.
+        // Round 6 (the batch's kernels as batched grids, every family of a mixed directory through phase batches: --merge 16
+        // --merge-blocks 100000; profiles/r06_cli_batch.log): all 256 families of configuration E, files to files, 3.73-3.81 s
+        // against 3.66-3.75 s through the slots' pipeline with three contexts (device-resident: 3.29 s phase-batched, 3.43 s on two
+        // streams) -- the 4 % the phase batches win on the device are lost again to the first batch (sixteen parses before anything
+        // runs) and to the worker's sixteen uploads and collects per batch: the pipeline stays the default for mixed directories.
         const int SMALL_BLOCKS = o.merge_blocks;
         struct Set {
             std::vector<Slot> mem;
@@ -643,9 +649,16 @@ int run_batch(const Options &o)
     if (abort_parsers) fprintf(stderr, "ERROR: no GPU worker could start; %zu families not processed\n", jobs.size());
     fprintf(stderr, "batch: %zu families on %d GPU(s) in %.3f s = %.2f families/s (%d failed)\n", jobs.size(), G, wall,
             (double)jobs.size() / wall, failures.load());
-    if (completed > 1 && last_done > first_done)
-        fprintf(stderr, "  steady state (first to last completed family; process start, HIP initialisation and the first parse excluded): %.2f families/s\n",
-                (double)(completed - 1) / (last_done - first_done));
+    {
+        // the families that completed after the first `skip` did (one pipeline's worth: the contexts in flight, or the first phase batch --
+        // its members all complete at once, which as "first to last" would count fifteen families at no time at all)
+        const size_t skip = (size_t)std::max(1, o.inflight) * (size_t)G;
+        if (o.merge > 1)
+            fprintf(stderr, "  (phase batches complete %d families at a time, the biggest families first: no steady-state figure -- compare whole runs)\n", o.merge);
+        else if (done_at.size() > skip + 1 && done_at.back() > done_at[skip - 1])
+            fprintf(stderr, "  steady state (after the first %zu completed families; process start, HIP initialisation and the first parses excluded): %.2f families/s\n",
+                    skip, (double)(done_at.size() - skip) / (done_at.back() - done_at[skip - 1]));
+    }
     for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", devs[(size_t)g], count[(size_t)g], busy[(size_t)g]);
     return failures.load() ? 1 : 0;
 }
@@ -679,8 +692,8 @@ int main(int argc, char **argv)
         else if (s == "--gpus") o.gpus = atoi(val());
         else if (s == "--parsers") o.parsers = atoi(val());
         else if (s == "--inflight") o.inflight = atoi(val());
-        else if (s == "--merge") o.merge = std::min(8, std::max(1, atoi(val())));
-        else if (s == "--merge-blocks") o.merge_blocks = std::min(57, std::max(1, atoi(val())));
+        else if (s == "--merge") o.merge = std::min(32, std::max(1, atoi(val())));
+        else if (s == "--merge-blocks") o.merge_blocks = std::min(1 << 20, std::max(1, atoi(val())));  // (0 or less: 1; "all": any number beyond the largest family)
         else if (s == "--parse-only") o.parse_only = true;
         else if (s == "--passes") o.passes = atoi(val());
         else if (s == "--synth") {
