@@ -45,7 +45,8 @@ struct gdca_ctx {
     gdca_buf Zt, Zp, hist, Zb, hcnt, nk, W, Wfix, Pifix, Pipc, A, G, H, P, Sg, Dblk, Ld, Tws, colsum, sc;
     gdca_buf normws, C2, B0, Rt;  // ||X||_1 workspace; Newton-Schulz refinement (allocated when a run first needs it): C again, X0 in full, I - X0 C
     gdca_buf Wd;                  // Cholesky fallback: the inverses of the diagonal tiles of the factor
-    gdca_buf hcand;               // reweighting, bound form: the list of candidate pairs
+    gdca_buf hcand;               // reweighting, bound forms: the list of candidate pairs
+    gdca_buf himg;                // reweighting, fp4 form: the image of the three low bit planes as E2M1 nibbles
     gdca_buf rankws;              // device ranking: keys, values, histograms, the three output arrays
     // an enqueued ranked run (gdca_run_ranked_async): where its ranking will be, and whether enqueueing it worked
     bool rank_pending = false;
@@ -221,8 +222,8 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
     }
     if (!strcmp(k, "HAMMING_MODE")) {
         const char c = (char)tolower((unsigned char)value[0]);
-        t->hamming_mode = c == 'f' ? 0 : (c == 'b' ? 1 : -1);
-        return c == 'f' || c == 'b' || c == 'a' || c == 0;  // full | bound | auto
+        t->hamming_mode = c == 'f' ? 0 : (c == 'b' ? 1 : (c == 'm' ? 2 : -1));
+        return c == 'f' || c == 'b' || c == 'm' || c == 'a' || c == 0;  // full | bound | mfma | auto
     }
     if (!strcmp(k, "FORCE_FALLBACK")) {  // any value but "" and "0" switches it on (as DCAUTILS_FORCE_FALLBACK in the reference's tests)
         t->force_fallback = (*value && strcmp(value, "0") != 0) ? 1 : 0;
@@ -453,7 +454,7 @@ gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
     if (ctx->own_stream || ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     gdca_buf *bufs[] = {&ctx->Zt, &ctx->Zp, &ctx->hist, &ctx->Zb, &ctx->hcnt, &ctx->nk, &ctx->W, &ctx->Wfix, &ctx->Pifix,
                         &ctx->Pipc, &ctx->A, &ctx->G, &ctx->H, &ctx->P, &ctx->Sg, &ctx->Dblk, &ctx->Ld,
-                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd, &ctx->rankws, &ctx->hcand};
+                        &ctx->Tws, &ctx->colsum, &ctx->sc, &ctx->normws, &ctx->C2, &ctx->B0, &ctx->Rt, &ctx->Wd, &ctx->rankws, &ctx->hcand, &ctx->himg};
     for (gdca_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < N_SCRATCH; ++i)
@@ -583,6 +584,10 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     CHK(ensure(ctx, ctx->Zb, gdca_bitplane_bytes(N, M)));
     CHK(ensure(ctx, ctx->hcnt, (size_t)Mt * GDCA_HTILE * sizeof(int32_t)));
     if (!ctx->tune.force_fallback && ctx->tune.hamming_mode != 0) CHK(ensure(ctx, ctx->hcand, gdca_hamming_cand_cap(M) * 8));
+    // (the fp4 form's image of the three low bit planes: 1.5 N bytes per sequence)
+    // (only where the option asks for that form: the automatic choice never takes it -- k_hamming_fp4.hip says why)
+    const bool fp4 = !ctx->tune.force_fallback && ctx->tune.hamming_mode == 2;
+    if (fp4) CHK(ensure(ctx, ctx->himg, gdca_fp4_image_bytes(N, M)));
     CHK(ensure(ctx, ctx->nk, (size_t)M * sizeof(int32_t)));
     CHK(ensure(ctx, ctx->W, (size_t)M * sizeof(double)));
     CHK(ensure(ctx, ctx->Wfix, (size_t)M * sizeof(unsigned long long)));
@@ -593,7 +598,7 @@ static gdca_status weights_stage(gdca_ctx *ctx, const int8_t *Zd, int N, int M, 
     if (ctx->tune.force_fallback)
         gdca_launch_hamming_fallback(s, Zd, (int32_t *)ctx->hcnt.p, N, M, sc);
     else
-        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, Zd, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode, ctx->hcand.p);
+        gdca_launch_hamming(s, (const uint32_t *)ctx->Zb.p, Zd, (int32_t *)ctx->hcnt.p, N, M, sc, ctx->tune.hamming_mode, ctx->hcand.p, fp4 ? ctx->himg.p : nullptr);
     gdca_launch_weights(s, (const int32_t *)ctx->hcnt.p, M, gdca_fix_shift(M), (int32_t *)ctx->nk.p,
                         (double *)ctx->W.p, (unsigned long long *)ctx->Wfix.p);
     // (Meff: an exact integer sum by one workgroup, microseconds.  Rounds 1-4 summed left to right in f64 -- 0.3 ms of dependent adds at

@@ -20,7 +20,8 @@ struct gdca_dev_scalars {
     int info;
     int bad_symbol;  // bit 0: a byte of Z is outside 1..q; bit 1: a caller-given weight is outside [0, 1] (GDCA_EINVAL)
     int di_noconv;   // number of site pairs whose tridiagonal QL iteration did not converge (DI score)
-    int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement
+    int ham_mode;    // all-pairs Hamming kernel chosen for this family: 0 = exact distances, 1 = three-plane lower bound + refinement, 2 = the bit-count
+                     // lower bound on the fp4 matrix pipe + refinement (k_hamming_fp4.hip)
     int ham_cand;    // candidate pairs (bound below the threshold) in the sampled tiles of k_hamming_probe
     unsigned long long ham_ncand;  // pairs the bound form has put (or tried to put) into its candidate list: beyond the list's capacity the exact form counts
     unsigned long long sweep_cycles, sweep_ticks;  // k_sweep, summed over its workgroups: shader-clock cycles (s_memtime) and 100 MHz ticks they ran for
@@ -33,6 +34,8 @@ struct gdca_dev_scalars {
     // between them -- an event per member and stage was most of the host's work for a batch): slot = the index of the event a
     // launch of its own would have recorded (gdca_api.hip: EV_*)
     unsigned long long stamp[GDCA_STAMPS];
+    int ham_cand2;   // pairs of the sampled tiles the fp4 form would list (D < 3 thresh)
+    int pad_;
 };
 
 // Tuning switches of one context (gdca_ctx_set_option): initialised from the GDCA_* environment variables when the context is
@@ -51,7 +54,7 @@ struct gdca_tuning {
     int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected
     long sweep_timeout_ms;  // GDCA_SWEEP_TIMEOUT_MS: bound of one dependency wait; 0 = scaled with the problem (>= 4 s)
     int tally_tj;           // GDCA_TALLY_TJ: 32 = the wide pair-tally form
-    int hamming_mode;       // GDCA_HAMMING_MODE: -1 = probe, 0 = full (exact five-plane distances), 1 = bound (three planes + refinement)
+    int hamming_mode;       // GDCA_HAMMING_MODE: -1 = probe, 0 = full (exact five-plane distances), 1 = bound (three planes + refinement), 2 = mfma (bit counts on the fp4 matrix pipe + refinement)
     int force_fallback;     // GDCA_FORCE_FALLBACK: 1 = the independent byte-compare Hamming kernel
     int merge;              // GDCA_MERGE: families one merged sweep launch may carry in gdca_run_dev_phased (1 = never merge)
     int merge_blocks;       // GDCA_MERGE_BLOCKS: largest member of a merged launch, in 128-blocks
@@ -88,9 +91,13 @@ void gdca_launch_bitplane_pack(hipStream_t s, const int8_t *Z, uint32_t *Zb, int
                                gdca_dev_scalars *sc);
 // cnt: int32 [Mt*128], zeroed by the caller; adds #{l != k: d(k,l) < sc->thresh}
 // force: -1 = decide per family from a sample of tiles, 0 = the exact form, 1 = the lower bound with refinement
-size_t gdca_hamming_cand_cap(int M);  // pairs the bound form's candidate list holds (8 bytes each)
+size_t gdca_hamming_cand_cap(int M);  // pairs the bound forms' candidate list holds (8 bytes each)
+// ---- k_hamming_fp4.hip: the bit-count lower bound on the fp4 matrix pipe (sc->ham_mode == 2) ----
+size_t gdca_fp4_image_bytes(int N, int M);
+void gdca_launch_hamming_fp4_probe(hipStream_t s, const uint32_t *Zb, int N, int M, int nprobe, gdca_dev_scalars *sc);
+void gdca_launch_hamming_fp4(hipStream_t s, const uint32_t *Zb, void *img, int N, int M, gdca_dev_scalars *sc, void *cand_list, unsigned cap);
 void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force,
-                         void *cand_list);
+                         void *cand_list, void *fp4_img);
 // the same counts by an independent plain byte-compare kernel straight from Z (GDCA_FORCE_FALLBACK; overwrites cnt[0..M-1])
 void gdca_launch_hamming_fallback(hipStream_t s, const int8_t *Z, int32_t *cnt, int N, int M, const gdca_dev_scalars *sc);
 // n_out[k] = 1 + cnt[k]; W[k] = 1/n_k; Wfix[k] = rint(W[k] * 2^fix_shift)

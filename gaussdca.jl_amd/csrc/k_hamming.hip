@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_hamming_refine(const BatchArgs<k_hammin
     int N = a_.N;
     int32_t *__restrict__ cnt = a_.cnt;
     const gdca_dev_scalars *__restrict__ sc = a_.sc;
-    if (sc->ham_mode != 1) return;
+    if (sc->ham_mode == 0) return;  // (the exact form counts this family; 1, 2: one of the bound forms made the list)
     if (sc->ham_ncand > (unsigned long long)cap) return;  // the list overflowed: the exact form counts this family
     const unsigned total = (unsigned)sc->ham_ncand;
     const int thresh = sc->thresh;
@@ -474,10 +474,11 @@ struct k_hamming_decide_args {
     gdca_dev_scalars *sc;
     long long sampled_pairs;
     int force;
+    int fp4_ok;  // the fp4 form may be chosen (its image buffer exists)
 };
-static inline k_hamming_decide_args k_hamming_decide_mk(gdca_dev_scalars *sc, long long sampled_pairs, int force)
+static inline k_hamming_decide_args k_hamming_decide_mk(gdca_dev_scalars *sc, long long sampled_pairs, int force, int fp4_ok)
 {
-    return k_hamming_decide_args{sc, sampled_pairs, force};
+    return k_hamming_decide_args{sc, sampled_pairs, force, fp4_ok};
 }
 template <int CAP>
 __global__ void k_hamming_decide(const BatchArgs<k_hamming_decide_args, CAP> B_)
@@ -487,39 +488,47 @@ __global__ void k_hamming_decide(const BatchArgs<k_hamming_decide_args, CAP> B_)
     long long sampled_pairs = a_.sampled_pairs;
     int force = a_.force;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sc->ham_mode = force >= 0 ? force : ((double)sc->ham_cand < 1e-3 * (double)sampled_pairs ? 1 : 0);
+        // the bit-count bound on the fp4 matrix pipe (k_hamming_fp4.hip) where it would list fewer than 2 pairs in 1000 (its product is
+        // five times cheaper than the three-plane form's loop, its list about twice as long); else the three-plane form below 1 in 1000
+        // (a pair refined costs ~50 pairs skipped); else exact distances
+        const double pairs = (double)sampled_pairs;
+        sc->ham_mode = force >= 0 ? force : ((a_.fp4_ok && (double)sc->ham_cand2 < 2e-3 * pairs) ? 2 : ((double)sc->ham_cand < 1e-3 * pairs ? 1 : 0));
         sc->ham_ncand = 0u;
     }
 }
 
-// Z: the alignment's bytes ([M][N], what the bit planes were packed from); cand_list: gdca_hamming_cand_cap(M) pairs of scratch
+// Z: the alignment's bytes ([M][N], what the bit planes were packed from); cand_list: gdca_hamming_cand_cap(M) pairs of scratch;
+// fp4_img: gdca_fp4_image_bytes(N, M) of scratch for the fp4 form, or nullptr (that form is then never chosen)
 void gdca_launch_hamming(hipStream_t s, const uint32_t *Zb, const int8_t *Z, int32_t *cnt, int N, int M, gdca_dev_scalars *sc, int force,
-                         void *cand_list)
+                         void *cand_list, void *fp4_img)
 {
     const int Mt = (M + GDCA_HTILE - 1) / GDCA_HTILE, NW = (N + 31) / 32;
     const long long ntile = (long long)Mt * (Mt + 1) / 2;
     int2 *list = (int2 *)cand_list;
     const unsigned cap = (unsigned)gdca_hamming_cand_cap(M);
-    // the context option GDCA_HAMMING_MODE=full|bound forces a form (tests, measurements); default: decided per family from a
+    // the context option GDCA_HAMMING_MODE=full|bound|mfma forces a form (tests, measurements); default: decided per family from a
     // sample of tiles
     const int nprobe = (int)std::min<long long>(ntile, 192);
+    if (force == 2 && !fp4_img) force = 1;
     // (alignments of at most 64 columns -- two words per plane -- go to the exact form unprobed: the bound saves two instructions per
     // word and costs a list and a second kernel; N = 64, M = 20 000: 0.136 ms against 0.200, profiles/r05_option_probes.log)
     if (force < 0 && NW <= 2) force = 0;
     if (force < 0 && ntile >= 64) {
         (gdca_launch<k_hamming_args, k_hamming<1, HAM_BOUND_PLANES, true>, k_hamming<GDCA_MAXB, HAM_BOUND_PLANES, true>>(dim3((unsigned)nprobe), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
-        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1)));
+        if (fp4_img) gdca_launch_hamming_fp4_probe(s, Zb, N, M, nprobe, sc);
+        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, (long long)nprobe * GDCA_HTILE * GDCA_HTILE, -1, fp4_img ? 1 : 0)));
     } else {
-        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, 1ll, force < 0 ? 0 : force)));  // tiny families: the exact form
+        (gdca_launch<k_hamming_decide_args, k_hamming_decide<1>, k_hamming_decide<GDCA_MAXB>>(dim3(1), dim3(1), 0, s, k_hamming_decide_mk(sc, 1ll, force < 0 ? 0 : force, 0)));  // tiny families: the exact form
     }
-    // both forms are launched wherever the bound form may run: where the device decides between them, and behind a forced bound form,
-    // whose list may overflow (the form that has nothing to do exits on sc->ham_mode / sc->ham_ncand: Mt (Mt + 1) / 2 empty workgroups)
+    // every form that may run is launched: where the device decides between them, and behind a forced bound form, whose list may
+    // overflow (a form that has nothing to do exits on sc->ham_mode / sc->ham_ncand: empty workgroups)
     const bool decided = !(force < 0 && ntile >= 64);
     const int form = decided ? (force < 0 ? 0 : force) : -1;
-    if (form != 0) {
+    if (fp4_img && (form == 2 || form < 0)) gdca_launch_hamming_fp4(s, Zb, fp4_img, N, M, sc, list, cap);
+    if (form == 1 || form < 0)
         (gdca_launch<k_hamming_args, k_hamming<1, HAM_BOUND_PLANES, false>, k_hamming<GDCA_MAXB, HAM_BOUND_PLANES, false>>(dim3((unsigned)ntile), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
+    if (form != 0)
         (gdca_launch<k_hamming_refine_args, k_hamming_refine<1>, k_hamming_refine<GDCA_MAXB>>(dim3(2048), dim3(256), 0, s, k_hamming_refine_mk(Z, (const int2 *)list, cap, N, cnt, (const gdca_dev_scalars *)sc)));
-    }
     (gdca_launch<k_hamming_args, k_hamming<1, NPLANES, false>, k_hamming<GDCA_MAXB, NPLANES, false>>(dim3((unsigned)ntile), dim3(256), 0, s, k_hamming_mk(Zb, cnt, NW, M, Mt, sc, list, cap)));
 }
 

@@ -89,9 +89,10 @@ def test_second_hamming_implementation_against_the_same_goldens(g, ctx, o, refda
 
 
 def test_hamming_lower_bound_form_counts_exactly(g, ctx, o):
-    """The reweighting kernel has two forms (csrc/k_hamming.hip): exact distances on all five bit planes, and a two-plane
-    lower bound followed by exact refinement of the few pairs the bound does not rule out; a sample of tiles decides per family
-    (dense families keep the exact form).  All three settings -- forced exact, forced bound, automatic -- must give the same
+    """The reweighting kernel has three forms: exact distances on all five bit planes (csrc/k_hamming.hip), a three-plane
+    lower bound followed by exact refinement of the few pairs the bound does not rule out, and (round 6, csrc/k_hamming_fp4.hip)
+    a bit-count lower bound computed as a Gram matrix on the fp4 matrix pipe, refined the same way; a sample of tiles decides per family
+    (dense families keep the exact form).  All four settings -- forced exact, forced bound, forced mfma, automatic -- must give the same
     neighbour counts, bit for bit, as the oracle: on unrelated random sequences, on a clustered synthetic family (the
     benchmark's generator), on a DENSE family in which every pair is a neighbour (every pair a candidate: the worst case of the
     bound), on awkward sizes and at thresholds around the bound's blind spot."""
@@ -108,9 +109,16 @@ def test_hamming_lower_bound_form_counts_exactly(g, ctx, o):
     for name, Zo, thr in cases:
         Z = np.asfortranarray(Zo.T)
         want = o.neighbour_counts(Zo, thr)
-        for mode in ("full", "bound", "auto"):
+        for mode in ("full", "bound", "mfma", "auto"):
             ctx.set_option("HAMMING_MODE", mode)
             assert np.array_equal(g.neighbour_counts(Z, thr, ctx=ctx), want), (name, mode)
+    # sizes around the fp4 form's 256 x 256 tiles and 8-entry chunks (N = 32 k +- 1, M = 256 k +- 1), thresholds from 1 to N / 2
+    for M, N, thr in ((255, 31, 1), (256, 32, 10), (257, 33, 16), (511, 96, 48), (513, 161, 40), (1025, 257, 100), (700, 353, 176)):
+        Zo = synth.synth_family(N, M, 21, 0xF4 + M)
+        want = o.neighbour_counts(Zo, thr)
+        for mode in ("mfma", "auto"):
+            ctx.set_option("HAMMING_MODE", mode)
+            assert np.array_equal(g.neighbour_counts(np.asfortranarray(Zo.T), thr, ctx=ctx), want), (M, N, thr, mode)
     ctx.set_option("HAMMING_MODE", "auto")
 
 

@@ -24,7 +24,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++
 ALLOWED = {}
 
 
-@pytest.mark.parametrize("src", ["k_hamming.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
+@pytest.mark.parametrize("src", ["k_hamming.hip", "k_hamming_fp4.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
 def test_front_end_and_score_kernels_do_not_spill(src, tmp_path):
     if not os.path.exists(HIPCC) or shutil.which("c++filt") is None:
         pytest.skip("no hipcc")
@@ -97,7 +97,7 @@ def test_no_barrier_sits_inside_a_divergent_loop_of_the_sweep_kernels(inverse_as
     assert all(d == 1 or d == 2 for _, _, d, *_ in bad_late) and all(b >= 20 and m >= 1000 for _, _, _, b, m, _ in bad_late), bad_late
 
 
-@pytest.mark.parametrize("src", ["k_hamming.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
+@pytest.mark.parametrize("src", ["k_hamming.hip", "k_hamming_fp4.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
 def test_no_barrier_sits_inside_a_divergent_loop_elsewhere(src, tmp_path):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
