@@ -138,9 +138,9 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
  * execute their SPD-inverse stages one after the other (device-side event chain), so that with
  * gdca_run_dev_async the reweighting/tally stages of the next family overlap the inverse of the current
  * one.  All members of a pipeline are driven by one host thread.  Contexts that run on one GPU at the same time SHOULD be such
- * peers: the SPD inverse is a persistent kernel.  Launches of one family each that share the device without a gate take turns for
- * the compute units and both finish (tested: two non-peer contexts, two processes); a MERGED launch (gdca_run_dev_phased) beside
- * another sweep can be kept from its main lists until the watchdog ends it with GDCA_EHIP ("Sharing a device"). */
+ * peers: the SPD inverse is a persistent kernel, and two of them side by side only take turns for the compute units.  Sharing the device
+ * WITHOUT a gate is slower, not unsafe: launches of one family each and merged launches (gdca_run_dev_phased) beside another sweep -- two
+ * non-peer contexts driven by two threads, two processes -- all finish with the right inverses (tested: INTEGRATION.md, "Sharing a device"). */
 gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out);
 gdca_status gdca_ctx_destroy(gdca_ctx *ctx);
 gdca_status gdca_ctx_synchronize(gdca_ctx *ctx);

@@ -941,3 +941,9 @@ def test_two_ungated_sweeps_side_by_side():
                        env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="8000"), timeout=600)
     print(r.stdout[-800:])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    # ... and the same from TWO PROCESSES: merged launches of eight in one, n = 9100 sweeps in the other, twice over
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "side_by_side_probe.py"), "9100", "3", "merged_procs"], capture_output=True,
+                           text=True, env=dict(os.environ, GDCA_SWEEP_TIMEOUT_MS="8000"), timeout=600)
+        print(r.stdout[-600:])
+        assert r.returncode == 0 and "exit codes [0, 0]" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

@@ -1,6 +1,6 @@
 """Two sweep launches that are NOT gated against each other on one GPU: (a) two non-peer contexts of this process,
 each driven by a thread of its own, (b) two processes.  Every run must give the LAPACK inverse; how long they take side by side is printed.
-    python tools/side_by_side_probe.py [n] [rounds]            (child mode: ... child <tag>)"""
+    python tools/side_by_side_probe.py [n] [rounds] [merged | merged_procs]            (child mode: ... child <tag>)"""
 import os
 import subprocess
 import sys
@@ -54,11 +54,29 @@ if __name__ == "__main__":
 
     A = spd(n, 3 if not child else 4 + len(sys.argv[4]))
     Xr = np.linalg.inv(A)
+    if child and sys.argv[4] == "merged":
+        # (a process of its own that does nothing but merged launches of eight)
+        import torch
+
+        torch.zeros(1).cuda()
+        out = {}
+        merged_work(g, rounds, out)
+        print("child merged: worst rel %s, %s" % (out["merged"][0], out["merged"][1]), flush=True)
+        sys.exit(0 if out["merged"][0] <= 1e-10 else 1)
     if child:
         out = {}
         work(g, g.Context(0), A, Xr, rounds, "p", out)
         print("child %s: worst rel %.2e, %.2f s" % (sys.argv[4], out["p"][0], out["p"][1]), flush=True)
         sys.exit(0 if out["p"][0] <= 1e-10 else 1)
+    if len(sys.argv) > 3 and sys.argv[3] == "merged_procs":
+        # merged launches of eight in ONE process beside ungated single-family sweeps of n rows in ANOTHER: nothing orders
+        # the two processes' launches, not even a common runtime
+        t0 = time.time()
+        ps = [subprocess.Popen([sys.executable, __file__, str(n), str(rounds), "child", "big"]),
+              subprocess.Popen([sys.executable, __file__, str(n), str(8 * rounds), "child", "merged"])]
+        rcs = [p.wait() for p in ps]
+        print("merged launches of 8 in one process beside n=%d sweeps in another: exit codes %s, %.1f s" % (n, rcs, time.time() - t0), flush=True)
+        sys.exit(0 if rcs == [0, 0] else 1)
     if len(sys.argv) > 3 and sys.argv[3] == "merged":
         # a MERGED launch (eight members) beside an ungated single-family sweep of n rows: the case the batch driver once died of
         import torch
