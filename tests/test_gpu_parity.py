@@ -116,7 +116,7 @@ def test_hamming_lower_bound_form_counts_exactly(g, ctx, o):
     for M, N, thr in ((255, 31, 1), (256, 32, 10), (257, 33, 16), (511, 96, 48), (513, 161, 40), (1025, 257, 100), (700, 353, 176)):
         Zo = synth.synth_family(N, M, 21, 0xF4 + M)
         want = o.neighbour_counts(Zo, thr)
-        for mode in ("mfma", "auto"):
+        for mode in ("mfma", "bound", "auto"):
             ctx.set_option("HAMMING_MODE", mode)
             assert np.array_equal(g.neighbour_counts(np.asfortranarray(Zo.T), thr, ctx=ctx), want), (M, N, thr, mode)
     ctx.set_option("HAMMING_MODE", "auto")
