@@ -380,6 +380,9 @@ def main():
                     help="with --pipeline > 1: let the SPD-inverse stages of the families in flight take turns")
     ap.add_argument("--phased-one-set", action="store_true",
                     help="with --phased: one set of P contexts instead of two alternating ones (no batch is enqueued while another runs)")
+    ap.add_argument("--dump-families", default="",
+                    help="write the timed runs' per-family stage times (N, M, ms_*) to this JSON file (tools/fit_batch_model.py, "
+                         "tests/test_batch_sharding.py: the LPT cost model against measured times)")
     ap.add_argument("--phased", action="store_true",
                     help="with --pipeline K: batch the K families in flight BY PHASE on one stream (gdca_run_dev_phased): K front "
                          "ends, then K SPD inverses back to back, then K score stages -- the matrix pipes see one load step per "
@@ -454,6 +457,11 @@ def main():
 
     meas = measure(args, args.config, args.score, args.steps, args.warmup, rank, world, local, dev, dist)
     out = summarize(args, meas, world, dist, comm_fallback)  # (every rank: it holds the reductions)
+    if args.dump_families and rank == 0:
+        keys = ("N", "M", "n", "ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_score", "inverse_batch")
+        with open(args.dump_families, "w") as f:
+            json.dump({"workload": out["config"]["workload"], "schedule": out["config"]["schedule"],
+                       "families": [{k: s[k] for k in keys} for s in meas["stats"]]}, f, indent=0)
     if rank != 0:
         release(meas)
     else:
@@ -617,11 +625,28 @@ def measure(args, config, score_name, steps, warmup, rank, world, local, dev, di
                 stats=stats, dt=dt, steps=steps, warm=warm, P=P, phased=phased)
 
 
-def hbm_records(stats, q):
-    """`roofline` objects (bound "hbm") of the HBM-bound kernels of the timed runs: FN and the covariance write."""
+def pmc_kernel_traffic(N, M, score, prefix):
+    """HBM bytes per launch of the kernel whose name starts with `prefix`, from the committed counter passes (see pmc_traffic):
+    None unless the workload is the profiled one and the file holds that kernel."""
+    try:
+        with open(PROFILED_TRAFFIC) as f:
+            d = json.load(f)
+        w = d.get("workload", {})
+        if (w.get("N"), w.get("M"), w.get("score")) != (N, M, score):
+            return None
+        hit = [v["hbm_bytes_per_launch"] for k, v in d.get("per_kernel", {}).items() if k.startswith(prefix)]
+        return float(max(hit)) if hit else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def hbm_records(stats, q, traffic_of=None):
+    """`roofline` objects (bound "hbm") of the HBM-bound kernels of the timed runs: FN and the covariance write.
+    traffic_of(prefix): HBM bytes per launch of that kernel from the committed counter passes, or None."""
     import numpy as np
 
     out = []
+    traffic_of = traffic_of or (lambda prefix: None)
     s_dim = q - 1
     fn = [(8.0 * st["n"] * (st["n"] - s_dim) / 2.0, st["ms_fn"]) for st in stats if st.get("ms_fn", 0.0) > 0.0]
     if fn:
@@ -629,14 +654,14 @@ def hbm_records(stats, q):
         ach = by / (ms * 1e-3) / 1e9
         out.append({"kernel": "k_fn (compute_FN: one pass over the lower block triangle of the inverse)", "bound": "hbm", "achieved": ach,
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "bytes_per_launch": by / len(fn),
-                    "avg_launch_ms": ms / len(fn), "traffic": None})
+                    "avg_launch_ms": ms / len(fn), "traffic": traffic_of("k_fn")})
     pt = [(8.0 * st["n"] * st["n"], st["ms_pair_tally"]) for st in stats if st.get("ms_pair_tally", 0.0) > 0.0]
     if pt:
         by, ms = float(np.sum([b for b, _ in pt])), float(np.sum([m for _, m in pt]))
         ach = by / (ms * 1e-3) / 1e9
         out.append({"kernel": "k_pair_tally (pair tallies + pseudocount + covariance epilogue: C written once, 8 n^2 bytes; the kernel is "
                               "bound by its LDS atomics)", "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "bytes_per_launch": by / len(pt), "avg_launch_ms": ms / len(pt), "traffic": None})
+                    "frac": ach / PEAK_HBM_GBS, "bytes_per_launch": by / len(pt), "avg_launch_ms": ms / len(pt), "traffic": traffic_of("k_pair_tally")})
     return out
 
 
@@ -735,7 +760,7 @@ def summarize(args, meas, world, dist, comm_fallback):
         # stream, gdca_stats.ms_fn / ms_pair_tally) against the 8 TB/s HBM3E peak.  FN: one pass over the lower block triangle of
         # the inverse, 8 n (n - s) / 2 bytes.  The covariance build's compulsory write (8 n^2 bytes) is listed against the pair-tally
         # kernel that contains it -- a kernel bound by its LDS atomics, not by that write: the fraction says how far from HBM it is.
-        "roofline_hbm": hbm_records(stats, q),
+        "roofline_hbm": hbm_records(stats, q, (lambda pre: pmc_kernel_traffic(N0, M0, score_name, pre)) if config != "E" else None),
         "comm": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
                  "data_path_collectives": 0, "fallback_reason": comm_fallback},
     }

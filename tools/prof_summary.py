@@ -51,13 +51,17 @@ def cmd_pmc(args):
 def cmd_traffic(args):
     res = {}
     per_kernel = {}
+    launches_of = {}
     for d, cname in ((args.fetch, "FETCH_SIZE"), (args.write, "WRITE_SIZE")):
         vals, allk = [], defaultdict(float)
+        nl = defaultdict(int)
+        launches_of[cname] = nl
         for r in read_counters(d):
             if r["Counter_Name"] != cname:
                 continue
             k = short(r["Kernel_Name"])
             allk[k] += float(r["Counter_Value"])
+            nl[k] += 1
             if k.startswith("k_sweep"):
                 vals.append((float(r["Counter_Value"]), k))
         res[cname] = vals
@@ -74,6 +78,15 @@ def cmd_traffic(args):
         cal = json.load(open(args.calib))
         cf, cw = cal["k_mix"]["fetch_counter_over_bytes"], cal["k_mix"]["write_counter_over_bytes"]
         out["calibration"] = {"file": os.path.basename(args.calib), "fetch_counter_over_bytes": cf, "write_counter_over_bytes": cw}
+    # every kernel of the run, per launch, same corrections (bench.py fills the `traffic` of its roofline_hbm records from this)
+    pk = {}
+    for k in per_kernel["FETCH_SIZE_all_kernels_sum_kb"]:
+        nf, nw = launches_of["FETCH_SIZE"].get(k, 0), launches_of["WRITE_SIZE"].get(k, 0)
+        if nf and nw:
+            fb = per_kernel["FETCH_SIZE_all_kernels_sum_kb"][k] * 1024.0 / nf / cf
+            wb = per_kernel["WRITE_SIZE_all_kernels_sum_kb"].get(k, 0.0) * 1024.0 / nw / cw
+            pk[k] = {"launches": min(nf, nw), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+    out["per_kernel"] = pk
     out.update(launches=n, fetch_counter_bytes_per_launch=f, write_counter_bytes_per_launch=w,
                fetch_bytes_per_launch=f / cf, write_bytes_per_launch=w / cw, hbm_bytes_per_launch=f / cf + w / cw,
                kernels=sorted({k for _, k in res["FETCH_SIZE"]}), raw=per_kernel)
