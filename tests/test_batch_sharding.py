@@ -71,6 +71,36 @@ def test_lpt_balance_and_determinism():
         shard_families(sizes, 0)
 
 
+def test_lpt_model_against_measured_family_times():
+    """the LPT cost model (gaussdca.jl_amd/batch.py) against MEASURED per-family device times -- all 256 families of
+    BASELINE.json's batch configuration one after the other on one MI355X (profiles/r06_E_per_family.json, written by
+    `bench.py --config E --dump-families`): the makespan the model predicts for its own sharding is within 5 % of the makespan those
+    shards have by the measured times, at 2, 4 and 8 ranks; the measured makespan is within 3 % of the ideal (sum / world); and the
+    model's per-family totals are within 25 % of the measured ones for 95 % of the families."""
+    import json
+
+    import numpy as np
+
+    from gaussdca.jl_amd.batch import batch_sizes, family_cost, shard_families
+
+    with open(os.path.join(ROOT, "profiles", "r06_E_per_family.json")) as f:
+        fams = json.load(f)["families"]
+    assert len(fams) == 256
+    sizes = [(int(x["N"]), int(x["M"])) for x in fams]
+    assert sorted(sizes) == sorted(batch_sizes(256))  # (the bench processes them in LPT order: the same families)
+    tot = np.array([x["ms_total"] for x in fams]) * 1e-3
+    model = np.array([family_cost(n, m) for n, m in sizes])
+    ratio = model / tot
+    assert 0.75 < np.percentile(ratio, 2.5) and np.percentile(ratio, 97.5) < 1.25, np.percentile(ratio, [2.5, 50, 97.5])
+    assert abs(model.sum() / tot.sum() - 1.0) < 0.03
+    for world in (2, 4, 8):
+        sh = shard_families(sizes, world)
+        pred = max(sum(model[f] for f in s) for s in sh)
+        meas = max(sum(tot[f] for f in s) for s in sh)
+        assert abs(pred / meas - 1.0) < 0.05, (world, pred, meas)
+        assert meas / (tot.sum() / world) < 1.03, (world, meas, tot.sum() / world)
+
+
 def _run_bench(args, timeout=300):
     import json
     import subprocess

@@ -1,4 +1,4 @@
-"""Refit the LPT cost model of gaussdca.jl_amd/batch.py (seconds: max(ALPHA n^3, CHAIN blocks) + BETA M^2 N + GAMMA N^2 M) to measured per-family
+"""Refit the LPT cost model of gaussdca.jl_amd/batch.py (seconds: A3 n^3 + B1 b + B2 b^2 + H2 M^2 N + H1 M + T2 N^2 M + T1 N^2 + T0) to measured per-family
 stage times (bench.py --config E --dump-families FILE: one family after the other) and say how well the model's makespans agree with the measured ones.
     python tools/fit_batch_model.py profiles/r06_E_per_family.json"""
 import json
@@ -18,14 +18,12 @@ inv = np.array([f["ms_inverse"] for f in fams]) * 1e-3
 ham = np.array([f["ms_weights"] + f["ms_theta"] for f in fams]) * 1e-3
 cov = np.array([f["ms_covariance"] + f["ms_score"] for f in fams]) * 1e-3
 tot = np.array([f["ms_total"] for f in fams]) * 1e-3
-big = n >= 58 * 128
-alpha = float(np.sum(inv[big] * n[big] ** 3) / np.sum(n[big] ** 6))
 blocks = np.ceil(n / 128)
-small = blocks <= 30
-chain = float(np.sum(inv[small] * blocks[small]) / np.sum(blocks[small] ** 2))
-beta = float(np.sum(ham * M * M * N) / np.sum((M * M * N) ** 2))
-gamma = float(np.sum(cov * N * N * M) / np.sum((N * N * M) ** 2))
-print("fit: ALPHA %.3g  BETA %.3g  GAMMA %.3g  CHAIN %.3g   (batch.py: %.3g %.3g %.3g %.3g)" % (alpha, beta, gamma, chain, batch.ALPHA, batch.BETA, batch.GAMMA, batch.CHAIN))
+ci = np.linalg.lstsq(np.c_[n ** 3, blocks, blocks * blocks], inv, rcond=None)[0]
+ch = np.linalg.lstsq(np.c_[M * M * N, M], ham, rcond=None)[0]
+cc = np.linalg.lstsq(np.c_[N * N * M, N * N, np.ones_like(N)], cov, rcond=None)[0]
+print("fit: A3 %.4g B1 %.4g B2 %.4g | H2 %.4g H1 %.4g | T2 %.4g T1 %.4g T0 %.4g" % (*ci, *ch, *cc))
+print("batch.py: A3 %.4g B1 %.4g B2 %.4g | H2 %.4g H1 %.4g | T2 %.4g T1 %.4g T0 %.4g" % (batch.A3, batch.B1, batch.B2, batch.H2, batch.H1, batch.T2, batch.T1, batch.T0))
 model = np.array([batch.family_cost(int(a), int(b)) for a, b in zip(N, M)])
 print("batch.py's model against the measured per-family totals: sum %.3f s against %.3f s; per family ratio model / measured: median %.3f, 5 %% .. 95 %%: %.3f .. %.3f"
       % (model.sum(), tot.sum(), np.median(model / tot), *np.percentile(model / tot, [5, 95])))
