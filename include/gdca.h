@@ -152,10 +152,10 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * or without the GDCA_ prefix, any case; value = what the variable would hold.  Schedule of the SPD inverse: GROUP (1..4, -1 = the
  * measured rule), RAMP, RAGGED, REM_TAIL, PANEL_HALVES, SLAB, RING, MCUS, MCU_SOLO; SWEEP_TIMEOUT_MS (bound of one dependency wait inside
  * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
- * bound), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
+ * bound | mfma: the bit-count lower bound on the fp4 matrix pipe -- exact counts, never the automatic choice), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
  * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS, PHASED_FRONTS (1: the front ends of a phase batch run side by side on the
- * members' streams, 0: one after the other), PHASED_STREAMS (how many of those streams, the first members', they are spread over: default 4); REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
+ * members' streams, 0: one after the other), PHASED_STREAMS (how many of those streams, the first members', they are spread over: default 4), PHASED_GRIDS (the kernels of a phase batch as ONE grid per kernel kind carrying all members of a group: -1 = 1 group for small families, 4 for big ones [default], 1 .. 8 = that many groups side by side, 0 = a launch per member and kernel as PHASED_FRONTS describes); REFINE (auto | 0 | 1: one Newton-Schulz step on an inverse that looks
  * ill-conditioned / never / always) and REFINE_COND (the threshold of auto, default 1e6); CHOLESKY (0 | 1 | 2: the blocked
  * dpotrf + dpotri fallback never / where the sweep gave up [default] / for every inverse).  The schedule switches change results
  * at rounding level at most (another summation order); REFINE improves an ill-conditioned inverse.  GDCA_EINVAL: unknown key
