@@ -36,7 +36,7 @@ METRIC = "end-to-end gDCA sec + achieved Cholesky TFLOP/s, N=500 M=50k q=21"
 PEAK_F64_MFMA_TFLOPS = 78.6  # AMD MI355X spec, FP64 matrix (not listed in MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0  # HBM3E peak bandwidth (MI355X_MICROARCH.md)
 SPEC_SHADER_GHZ = 2.4  # the clock the spec peak is quoted at; the clock of the timed launches is measured by k_sweep itself
-PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r05_pmc_update_traffic.json")
+PROFILED_TRAFFIC = os.path.join(ROOT, "profiles", "r06_pmc_update_traffic.json")
 
 CONFIGS = {  # name -> (N, M, theta, seed); None sizes = the batch
     "B": dict(N=128, M=10000, theta=0.2, seed=0xB128, ref="BASELINE.json configs[1]"),
@@ -72,7 +72,7 @@ def pmc_traffic(N, M, score):
     """HBM bytes per launch of the dominant kernel.  NOT measured by this run (PMC counters need rocprofv3 passes of
     their own): the figure of the committed counter passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
     passes, corrected with the factor measured on a copy kernel with the update kernel's load mix:
-    profiles/r02_fetch_calibration.json), returned with its provenance; (None, None) unless the workload is the
+    profiles/r06_fetch_calibration.json), returned with its provenance; (None, None) unless the workload is the
     profiled one."""
     try:
         with open(PROFILED_TRAFFIC) as f:

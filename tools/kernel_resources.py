@@ -19,7 +19,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--sources", nargs="*", default=["k_inverse.hip", "k_hamming.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
+ap.add_argument("--sources", nargs="*", default=["k_inverse.hip", "k_hamming.hip", "k_hamming_fp4.hip", "k_tally.hip", "k_score.hip", "k_theta.hip", "k_elementwise.hip", "k_rank.hip"])
 ap.add_argument("--kernels", nargs="*", default=["k_sweep", "k_sweep_merged"], help="kernels whose basic blocks are listed (substring of the demangled name)")
 ap.add_argument("--min-mfma", type=int, default=32, help="list basic blocks with at least this many MFMAs")
 args = ap.parse_args()

@@ -62,7 +62,7 @@ def cmd_traffic(args):
             k = short(r["Kernel_Name"])
             allk[k] += float(r["Counter_Value"])
             nl[k] += 1
-            if k.startswith("k_sweep"):
+            if k.startswith("k_sweep") and "prep" not in k:
                 vals.append((float(r["Counter_Value"]), k))
         res[cname] = vals
         per_kernel[cname + "_all_kernels_sum_kb"] = dict(allk)
