@@ -6,6 +6,7 @@
 // end-to-end gDCA(filename) spends its time on the GPU, not in an interpreter loop.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -482,7 +483,11 @@ try {
     const size_t L = text.size();
     const int T = L < (1u << 20) ? 1 : fasta_threads();
 
-    // pass 1: header lines (first non-space character '>'), found per chunk of whole lines
+    // ONE team of T threads for both passes (round 6: as two parallel regions the 2 x 15 thread starts and joins were 0.5 ms of a
+    // 3.5-ms parse at 25 MB, and a thread now parses the records of the very bytes it has just scanned for headers):
+    //   phase A  header lines (first non-space character '>') of the thread's chunk of whole lines;
+    //   -- barrier; thread 0: the records' numbering, the first record's columns, the matrix --
+    //   phase B  the thread's own records: letter map + gap-fraction filter, every record into its own row.
     std::vector<size_t> cut((size_t)T + 1, L);
     cut[0] = 0;
     for (int t = 1; t < T; ++t) {
@@ -491,57 +496,111 @@ try {
         cut[(size_t)t] = nl ? (size_t)(nl - text.data()) + 1 : L;
     }
     std::vector<std::vector<Span>> found((size_t)T);
-    parallel(T, [&](int t) {
-        size_t pos = cut[(size_t)t];
-        const size_t end = cut[(size_t)t + 1];
-        auto &mine = found[(size_t)t];
-        while (pos < end) {
-            const char *nl = (const char *)memchr(text.data() + pos, '\n', L - pos);
-            const size_t eol = nl ? (size_t)(nl - text.data()) : L;
-            size_t a = pos;
-            while (a < eol && is_space(text[a])) ++a;
-            if (a < eol && text[a] == '>') mine.push_back({pos, eol});
-            pos = eol + 1;
-        }
-    });
-    const double t_p1 = trace ? tick() : 0.0;
-    std::vector<Span> headers;
-    for (auto &v : found) headers.insert(headers.end(), v.begin(), v.end());
-    const size_t R = headers.size();
-    if (R == 0) return GDCA_EINVAL;
-    auto body_of = [&](size_t r) { return Span{std::min(L, headers[r].b + 1), r + 1 < R ? headers[r + 1].a : L}; };
-
-    // the first sequence fixes the alignment columns: everything except '.' and lowercase letters
-    std::string scratch0;
-    const std::string first(body_sequence(text, body_of(0), scratch0));
+    std::vector<size_t> first_rec((size_t)T + 1, 0);  // number of the first record whose header thread t found
+    size_t R = 0;
+    std::string first;
     std::vector<uint32_t> cols;
-    for (size_t p = 0; p < first.size(); ++p) {
-        const char c = first[p];
-        if (c != '.' && !(c >= 'a' && c <= 'z')) cols.push_back((uint32_t)p);
-    }
-    const int32_t n = (int32_t)cols.size();
-    if (n <= 0) return GDCA_EINVAL;
-
-    std::unique_ptr<gdca_fasta> hold(new (std::nothrow) gdca_fasta());  // (freed on every way out but the last line, exceptions included)
-    gdca_fasta *h = hold.get();
-    if (!h) return GDCA_ENOMEM;
-    h->N = n;
-    h->Z = matbuf_get((size_t)n * R);
-    if (!h->Z.p) {
-        hold.reset();
-        return GDCA_ENOMEM;
-    }
-    std::vector<uint8_t> keep(R, 0);
+    int32_t n = 0;
+    bool all_match = false;
+    gdca_status serial_status = GDCA_OK;
+    std::unique_ptr<gdca_fasta> hold;
+    gdca_fasta *h = nullptr;
+    std::vector<uint8_t> keep;
     std::vector<int> qmax_t((size_t)T, 0);  // largest symbol among the rows each thread keeps
-    const double t_alloc = trace ? tick() : 0.0;
     std::atomic<bool> misaligned{false};
-    const bool all_match = cols.size() == first.size();  // the first record has no insert columns (the usual case)
-    // pass 2: records in parallel: letter map + gap-fraction filter, every record into its own row
-    parallel(T, [&](int t) {
+    double t_p1 = 0.0, t_alloc = 0.0;
+    // where record r's body ends: at the next header, which may be the next thread's first
+    auto header_of = [&](size_t r, int t_hint) -> const Span & {
+        int t = t_hint;
+        while (r >= first_rec[(size_t)t + 1]) ++t;
+        return found[(size_t)t][r - first_rec[(size_t)t]];
+    };
+    struct TeamBarrier {
+        std::mutex mu;
+        std::condition_variable cv;
+        int waiting = 0, phase = 0, T;
+        explicit TeamBarrier(int T_) : T(T_) {}
+        void arrive()
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            const int ph = phase;
+            if (++waiting == T) {
+                waiting = 0;
+                ++phase;
+                cv.notify_all();
+            } else {
+                cv.wait(lk, [&] { return phase != ph; });
+            }
+        }
+    } bar(T);
+    std::atomic<bool> team_failed{false};  // an exception inside a phase: the thread still meets the others at the barriers
+    auto team_body = [&](int t) {
+        try {
+            size_t pos = cut[(size_t)t];
+            const size_t end = cut[(size_t)t + 1];
+            auto &mine = found[(size_t)t];
+            while (pos < end) {
+                const char *nl = (const char *)memchr(text.data() + pos, '\n', L - pos);
+                const size_t eol = nl ? (size_t)(nl - text.data()) : L;
+                size_t a = pos;
+                while (a < eol && is_space(text[a])) ++a;
+                if (a < eol && text[a] == '>') mine.push_back({pos, eol});
+                pos = eol + 1;
+            }
+        } catch (...) {
+            team_failed = true;
+        }
+        bar.arrive();
+        if (t == 0) {
+            try {
+                t_p1 = trace ? tick() : 0.0;
+                for (int u = 0; u < T; ++u) first_rec[(size_t)u + 1] = first_rec[(size_t)u] + found[(size_t)u].size();
+                R = first_rec[(size_t)T];
+                if (R == 0 || team_failed) {
+                    serial_status = team_failed ? GDCA_ENOMEM : GDCA_EINVAL;
+                } else {
+                    // the first sequence fixes the alignment columns: everything except '.' and lowercase letters
+                    std::string scratch0;
+                    const Span h0 = header_of(0, 0);
+                    const size_t e0 = R > 1 ? header_of(1, 0).a : L;
+                    first = std::string(body_sequence(text, Span{std::min(L, h0.b + 1), e0}, scratch0));
+                    for (size_t p = 0; p < first.size(); ++p) {
+                        const char c = first[p];
+                        if (c != '.' && !(c >= 'a' && c <= 'z')) cols.push_back((uint32_t)p);
+                    }
+                    n = (int32_t)cols.size();
+                    if (n <= 0) {
+                        serial_status = GDCA_EINVAL;
+                    } else {
+                        hold.reset(new (std::nothrow) gdca_fasta());  // (freed on every way out but the last line, exceptions included)
+                        h = hold.get();
+                        if (h) {
+                            h->N = n;
+                            h->Z = matbuf_get((size_t)n * R);
+                        }
+                        if (!h || !h->Z.p) {
+                            hold.reset();
+                            h = nullptr;
+                            serial_status = GDCA_ENOMEM;
+                        } else {
+                            keep.assign(R, 0);
+                            all_match = cols.size() == first.size();  // the first record has no insert columns (the usual case)
+                        }
+                    }
+                }
+                t_alloc = trace ? tick() : 0.0;
+            } catch (...) {
+                serial_status = GDCA_ENOMEM;
+            }
+        }
+        bar.arrive();
+        if (serial_status != GDCA_OK) return;
         std::string scratch;
-        const size_t r0 = R * (size_t)t / (size_t)T, r1 = R * ((size_t)t + 1) / (size_t)T;
+        const size_t r0 = first_rec[(size_t)t], r1 = first_rec[(size_t)t + 1];
         for (size_t r = r0; r < r1 && !misaligned.load(std::memory_order_relaxed); ++r) {
-            const std::string_view sq = body_sequence(text, body_of(r), scratch);
+            const Span hd = found[(size_t)t][r - r0];
+            const size_t body_end = r + 1 < R ? (r + 1 < r1 ? found[(size_t)t][r + 1 - r0].a : header_of(r + 1, t).a) : L;
+            const std::string_view sq = body_sequence(text, Span{std::min(L, hd.b + 1), body_end}, scratch);
             if (sq.size() != first.size()) {
                 misaligned = true;  // "inputs are not aligned"
                 return;
@@ -590,7 +649,40 @@ try {
             if (keep[r])
                 for (int32_t i = 0; i < n; ++i) qmax_t[(size_t)t] = std::max(qmax_t[(size_t)t], (int)row[i]);
         }
-    });
+    };
+    {
+        // (nothing may leave a worker thread, and a thread that could not be started must not leave the others waiting at a barrier:
+        // the team is as large as the number of threads that did start, and a team that is not complete fails the parse)
+        std::vector<std::thread> th;
+        auto guarded = [&](int t) {
+            try {
+                team_body(t);
+            } catch (...) {
+                team_failed = true;
+            }
+        };
+        int started = 1;
+        try {
+            th.reserve((size_t)T - 1);
+            for (int t = 1; t < T; ++t) {
+                th.emplace_back(guarded, t);
+                ++started;
+            }
+        } catch (...) {
+            team_failed = true;
+        }
+        {
+            std::lock_guard<std::mutex> lk(bar.mu);
+            bar.T = started;  // (thread 0 has not arrived yet: nobody can be past the first barrier)
+        }
+        guarded(0);
+        for (auto &x : th) x.join();
+    }
+    if (team_failed) {
+        hold.reset();
+        return GDCA_ENOMEM;
+    }
+    if (serial_status != GDCA_OK) return serial_status;
     const double t_p2 = trace ? tick() : 0.0;
     if (misaligned) {
         hold.reset();
