@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GDCA_LIB") or os.path.join(_HERE, "libgdca.so")
 
 GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV = 0, 1, 2, 3, 4, 5
 SCORE_FROB, SCORE_DI = 0, 1
-ABI_VERSION = 5  # GDCA_VERSION_MAJOR * 1000 + GDCA_VERSION_MINOR of the header this binding mirrors
+ABI_VERSION = 6  # GDCA_VERSION_MAJOR * 1000 + GDCA_VERSION_MINOR of the header this binding mirrors
 
 
 class GdcaError(RuntimeError):
@@ -55,7 +55,7 @@ class Stats(C.Structure):
         ("ms_covariance", C.c_double), ("ms_inverse", C.c_double), ("ms_inverse_update", C.c_double),
         ("ms_score", C.c_double), ("inverse_flops", C.c_double), ("update_flops", C.c_double),
         ("sweep_ghz", C.c_double), ("inverse_norm1", C.c_double), ("matrix_norm1", C.c_double), ("cond_bound", C.c_double),
-        ("ms_fn", C.c_double), ("ms_pair_tally", C.c_double),   # (new fields go to the END: an older build of the library fills a prefix)
+        ("ms_fn", C.c_double), ("ms_pair_tally", C.c_double), ("sweep_retries", C.c_int32), ("reserved0", C.c_int32),   # (new fields go to the END: an older build of the library fills a prefix)
     ]
 
     def as_dict(self):

@@ -80,6 +80,8 @@ struct gdca_ctx {
     double *pend_S;
     gdca_params pend_p;
     int pend_refined;
+    int pend_attempt;          // attempts the enqueued run's inverse has had so far (0: the first is enqueued); its watchdog may end a launch (k_inverse.hip, spin_until)
+    bool pend_rescored;        // ... and it was run again at collect time: the scores (and a ranking) are those of the last attempt
     hipEvent_t pend_upd_ev[2]; // the two events around that launch (this context's own, also for a merged launch)
     double pend_upd_flops;
 };
@@ -234,7 +236,7 @@ bool gdca_tuning_set(gdca_tuning *t, const char *key, const char *value)
     struct { const char *name; int *field; long lo, hi; } ints[] = {
         {"GROUP", &t->group, -1, 4},        {"RAMP", &t->ramp, 0, 1},          {"RAGGED", &t->ragged, 0, 1},
         {"REM_TAIL", &t->rem_tail, -1, 1 << 20}, {"PANEL_HALVES", &t->panel_halves, -1, 1}, {"SLAB", &t->slab, 0, 1},
-        {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 32},        {"MCU_SOLO", &t->mcu_solo, -1, 1},       {"SWEEP_DEBUG", &t->sweep_debug, 0, 31},
+        {"RING", &t->ring, 2, 8},           {"MCUS", &t->mcus, -1, 32},        {"MCU_SOLO", &t->mcu_solo, -1, 1},       {"SWEEP_DEBUG", &t->sweep_debug, 0, 63}, {"SWEEP_RETRIES", &t->sweep_retries, 0, 5},
         {"TALLY_TJ", &t->tally_tj, 0, 32},  {"MERGE", &t->merge, 1, 8},        {"MERGE_BLOCKS", &t->merge_blocks, 1, 64},
         {"MERGE_MCUS", &t->merge_mcus, -1, 16},  {"MERGE_GROUP", &t->merge_group, -1, 4}, {"MERGE_TILES", &t->merge_tiles, 1, 1 << 20},
         {"CHOLESKY", &t->cholesky, 0, 2},  {"PHASED_FRONTS", &t->phased_fronts, 0, 1}, {"PHASED_GRIDS", &t->phased_grids, -1, 8}, {"PHASED_STREAMS", &t->phased_streams, 1, 64},
@@ -280,6 +282,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->ring = 8;
     t->mcus = -1;
     t->mcu_solo = -1;
+    t->sweep_retries = 2;
     t->hamming_mode = -1;
     t->merge = 8;
     t->merge_blocks = 57;
@@ -293,7 +296,7 @@ void gdca_tuning_from_env(gdca_tuning *t)
     t->refine_cond = 1e6;
     t->cholesky = 1;
     static const char *const names[] = {"GDCA_GROUP", "GDCA_RAMP", "GDCA_RAGGED", "GDCA_REM_TAIL", "GDCA_PANEL_HALVES", "GDCA_SLAB",
-                                        "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_TALLY_TJ",
+                                        "GDCA_RING", "GDCA_MCUS", "GDCA_SWEEP_DEBUG", "GDCA_SWEEP_TIMEOUT_MS", "GDCA_SWEEP_RETRIES", "GDCA_TALLY_TJ",
                                         "GDCA_HAMMING_MODE", "GDCA_FORCE_FALLBACK", "GDCA_MERGE", "GDCA_MERGE_BLOCKS",
                                         "GDCA_MERGE_MCUS", "GDCA_MERGE_GROUP", "GDCA_MERGE_TILES", "GDCA_REFINE", "GDCA_REFINE_COND", "GDCA_CHOLESKY", "GDCA_SWEEP_TRACE", "GDCA_PHASED_FRONTS", "GDCA_PHASED_GRIDS", "GDCA_PHASED_STREAMS", "GDCA_MCU_SOLO"};
     for (const char *nm : names)
@@ -407,6 +410,27 @@ gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_
     return GDCA_OK;
 }
 
+// A stream's hardware queue comes into being with the stream's FIRST command, not with the stream -- and the driver maps a new queue
+// by taking every queue of the device off the hardware and putting them back: the waves of all running kernels are saved and restored
+// (a standstill of ~1.7 ms, measured from inside the sweep kernel; the waves come back on other compute units).  Restored beside the
+// kernels of other streams, a persistent sweep need not get all its workgroups back at once -- and those it did get back wait for
+// the items the others hold, keeping the compute units those would need: the launch stands still until its watchdog ends it.
+// Round 6's batch driver ran into exactly that, in 1 to 8 of 100 runs: the contexts of its phase batches were made when the first
+// small family showed up, their streams started beside a slot's running sweep (tools/rounds/r06/gpu_r6q.sh, gpu_r6s.sh; made before
+// any work: 0 of 200).  So the queue is made HERE, with the context -- one small fill and a synchronisation; the context's scalars
+// are allocated on the way -- and callers make their contexts before they enqueue work (include/gdca.h).  What a caller cannot
+// rule out (another process starting on the same GPU) is what the sweep's watchdog and gdca_run_collect's second attempt are for.
+static gdca_status warm_stream(gdca_ctx *ctx, hipStream_t s)
+{
+    CHK(ensure(ctx, ctx->sc, sizeof(gdca_dev_scalars)));
+    gdca_fill_async(s, ctx->sc.p, 0, sizeof(gdca_dev_scalars));
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GDCA_EHIP, "the context's stream could not be started%s%s", "", "");
+    }
+    return GDCA_OK;
+}
+
 gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
 {
     gdca_status st = gdca_ctx_create_on_stream(device_id, nullptr, out);
@@ -422,7 +446,12 @@ gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out)
         return GDCA_EHIP;
     }
     ctx->own_stream = true;
-    return GDCA_OK;
+    st = warm_stream(ctx, ctx->stream);
+    if (st != GDCA_OK) {
+        gdca_ctx_destroy(ctx);
+        *out = nullptr;
+    }
+    return st;
 }
 
 gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
@@ -440,11 +469,19 @@ gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
         if (hipStreamCreateWithPriority(&g->batch_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) g->batch_stream = nullptr;
         leader->gate = g;
     }
+    const bool new_gate = leader->gate->refs == 1;
     gdca_status st = gdca_ctx_create(leader->device, out);
     if (st != GDCA_OK) return st;
     (*out)->gate = leader->gate;
     leader->gate->refs += 1;
-    return GDCA_OK;
+    if (new_gate && leader->gate->batch_stream) {  // (the pipeline's own stream too)
+        st = warm_stream(*out, leader->gate->batch_stream);
+        if (st != GDCA_OK) {
+            gdca_ctx_destroy(*out);
+            *out = nullptr;
+        }
+    }
+    return st;
 }
 
 gdca_status gdca_ctx_destroy(gdca_ctx *ctx)
@@ -685,6 +722,7 @@ static gdca_status inverse_job(gdca_ctx *ctx, int n, int n_pad, gdca_inverse_job
     job->n_real = n;
     job->sc = (gdca_dev_scalars *)ctx->sc.p;
     job->tune = &ctx->tune;
+    job->doomed = (ctx->tune.sweep_debug & 32) != 0 && ctx->pend_attempt == 0;
     return GDCA_OK;
 }
 
@@ -835,8 +873,12 @@ static gdca_status begin(gdca_ctx *ctx)
     HIPCHK(hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->sc, sizeof(gdca_dev_scalars)));
     gdca_fill_async(ctx->stream, ctx->sc.p, 0, sizeof(gdca_dev_scalars));
+    ctx->pend_attempt = 0;
+    ctx->pend_rescored = false;
     return GDCA_OK;
 }
+
+static gdca_status run_inverse(gdca_ctx *ctx);
 
 extern "C" {
 
@@ -853,6 +895,24 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else {
         CHK(fetch_scalars(ctx));
+    }
+    while (ctx->sc_host->info == INT32_MIN && !ctx->sc_host->bad_symbol && ctx->pend_attempt < ctx->tune.sweep_retries) {
+        // The sweep's watchdog ended the launch (k_inverse.hip, spin_until: in practice a launch that did not get all its workgroups
+        // back after the driver had taken the device's queues off the hardware).  Nothing is wrong with the matrix: the covariance
+        // once more from the tallies -- the sweep works in place --, the inverse again as a launch of its own behind the pipeline's
+        // gate, the scores again.  A launch that fails option SWEEP_RETRIES times in a row (default 2) is reported as GDCA_EHIP.
+        gdca_dev_scalars *sc = (gdca_dev_scalars *)ctx->sc.p;
+        const int N = ctx->pend_N, M = ctx->pend_M, q = ctx->pend_q, n_pad = ctx->pend_npad, n = ctx->pend_n;
+        ++ctx->pend_attempt;
+        CHK(tally_stage(ctx, ctx->pend_Z, N, M, q, &sc->Meff, ctx->pend_p.pseudocount, 1, nullptr, (double *)ctx->A.p, (size_t)n_pad));
+        gdca_launch_pad_identity(ctx->stream, (double *)ctx->A.p, n, n_pad);
+        HIPCHK(hipMemsetAsync(&sc->info, 0, sizeof(int), ctx->stream));
+        HIPCHK(hipMemsetAsync(&sc->di_noconv, 0, sizeof(int), ctx->stream));
+        CHK(run_inverse(ctx));
+        CHK(score_stage(ctx, N, q - 1, n_pad, ctx->pend_p.score, ctx->pend_p.apc, ctx->pend_S));
+        if (ctx->pend_timed && !ctx->pend_stamped) CHK(mark(ctx, 5));
+        CHK(fetch_scalars(ctx));
+        ctx->pend_rescored = true;
     }
     if (ctx->tune.refine != 0 && ctx->sc_host->info == 0 && !ctx->sc_host->bad_symbol &&
         (ctx->tune.refine == 1 || cond_bound(*ctx->sc_host, ctx->pend_p.pseudocount, ctx->pend_q, ctx->pend_N) > ctx->tune.refine_cond)) {
@@ -915,6 +975,7 @@ gdca_status gdca_run_collect(gdca_ctx *ctx, gdca_stats *st)
         st->update_launches = ctx->pend_nupd;
         st->inverse_batch = ctx->pend_batch;
         st->refined = ctx->pend_refined;
+        st->sweep_retries = ctx->pend_attempt;
         st->inverse_norm1 = h.inv_norm1;
         st->matrix_norm1 = h.mat_norm1;
         st->cond_bound = ctx->tune.refine != 0 ? cond_bound(h, ctx->pend_p.pseudocount, ctx->pend_q, ctx->pend_N) : 0.0;
@@ -1569,8 +1630,8 @@ gdca_status gdca_run_ranked_collect(gdca_ctx *ctx, int32_t *i_out, int32_t *j_ou
     const long long len = ctx->rank_len;
     if (len == 0) return GDCA_OK;
     if (!i_out || !j_out || !score_out) return fail(ctx, GDCA_EINVAL, "null pointer%s%s", "", "");
-    // (a run whose inverse was refined or recomputed at collect time has new scores: rank those)
-    if (ctx->pend_refined != 0)
+    // (a run whose inverse was refined, recomputed or run again at collect time has new scores: rank those)
+    if (ctx->pend_refined != 0 || ctx->pend_rescored)
         CHK(ranking_stage(ctx, ctx->pend_S, ctx->pend_N, ctx->rank_sep, len, &ctx->rank_i, &ctx->rank_j, &ctx->rank_s));
     return ranking_to_host(ctx, len, ctx->rank_i, ctx->rank_j, ctx->rank_s, i_out, j_out, score_out);
 }
@@ -1782,21 +1843,42 @@ static gdca_status operator_fallback(gdca_ctx *ctx, const double *A_dev, int n, 
     return fetch_scalars(ctx);
 }
 
-gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
+// the operator-level inverse of the caller's matrix (still intact: the sweep works on a copy), start to finish on the context's stream;
+// the context's scalars are in sc_host afterwards
+static gdca_status operator_inverse_once(gdca_ctx *ctx, double *A_dev, int n, int n_pad)
 {
-    if (!ctx || !A_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
-    CHK(begin(ctx));
     hipStream_t s = ctx->stream;
-    const int n_pad = round_up(n, GDCA_TILE);
     CHK(ensure(ctx, ctx->A, (size_t)n_pad * n_pad * sizeof(double)));
     gdca_launch_copy_in(s, A_dev, n, (double *)ctx->A.p, n_pad);
     int n_upd = 0;
     CHK(inverse_stage(ctx, n, n_pad, false, &n_upd, nullptr));
     CHK(operator_norms_and_refine(ctx, A_dev, n, n_pad));
     CHK(operator_fallback(ctx, A_dev, n, n_pad));
+    if (ctx->sc_host->info == INT32_MIN) return GDCA_OK;  // (the watchdog: the caller's matrix stays as it is)
     gdca_launch_copy_out_neg_sym(s, (const double *)ctx->A.p, n_pad, A_dev, n);
     CHK(check_launch(ctx, "copy_out"));
     HIPCHK(hipStreamSynchronize(s));
+    return GDCA_OK;
+}
+
+// ... once more after a launch the watchdog ended (gdca_run_collect has the why), up to option SWEEP_RETRIES times
+static gdca_status operator_inverse_retry(gdca_ctx *ctx, double *A_dev, int n, int n_pad)
+{
+    while (ctx->sc_host->info == INT32_MIN && ctx->pend_attempt < ctx->tune.sweep_retries) {
+        ++ctx->pend_attempt;
+        HIPCHK(hipMemsetAsync(&((gdca_dev_scalars *)ctx->sc.p)->info, 0, sizeof(int), ctx->stream));
+        CHK(operator_inverse_once(ctx, A_dev, n, n_pad));
+    }
+    return GDCA_OK;
+}
+
+gdca_status gdca_spd_inverse_dev(gdca_ctx *ctx, double *A_dev, int32_t n, int32_t *info)
+{
+    if (!ctx || !A_dev || n < 1 || n > GDCA_MAX_N) return GDCA_EINVAL;
+    CHK(begin(ctx));
+    const int n_pad = round_up(n, GDCA_TILE);
+    CHK(operator_inverse_once(ctx, A_dev, n, n_pad));
+    CHK(operator_inverse_retry(ctx, A_dev, n, n_pad));
     if (ctx->sc_host->info == INT32_MIN) {
         if (info) *info = 0;
         return fail(ctx, GDCA_EHIP, "SPD inverse aborted: a dependency wait inside the sweep kernel timed out%s%s", "", "");
@@ -1849,11 +1931,16 @@ gdca_status gdca_spd_inverse_batch_dev(gdca_ctx *const *ctxs, int32_t K, double 
     for (int k = 0; k < K && st == GDCA_OK; ++k) st = member_error(lead, ctxs[k], k, operator_norms_and_refine(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad));
     for (int k = 0; k < K && st == GDCA_OK; ++k) st = member_error(lead, ctxs[k], k, operator_fallback(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad));
     for (int k = 0; k < K && st == GDCA_OK; ++k) {
+        if (ctxs[k]->sc_host->info == INT32_MIN) continue;  // (the watchdog ended this member's launch: see below)
         gdca_launch_copy_out_neg_sym(lead->stream, (const double *)ctxs[k]->A.p, ctxs[k]->pend_npad, A_dev[k], n[k]);
         st = check_launch(lead, "copy_out");
     }
     (void)hipStreamSynchronize(lead->stream);
     for (int k = 0; k < K; ++k) ctxs[k]->stream = own[k];
+    if (st != GDCA_OK) return st;
+    // members whose launch the watchdog ended (all members of a merged launch share that fate): once more, one by one
+    for (int k = 0; k < K && st == GDCA_OK; ++k)
+        if (ctxs[k]->sc_host->info == INT32_MIN) st = member_error(lead, ctxs[k], k, operator_inverse_retry(ctxs[k], A_dev[k], n[k], ctxs[k]->pend_npad));
     if (st != GDCA_OK) return st;
     gdca_status worst = GDCA_OK;
     for (int k = 0; k < K; ++k) {

@@ -39,7 +39,8 @@ struct Options {
     int score = GDCA_SCORE_FROB, min_separation = 5;
     bool remove_dups = false;
     std::string batch_dir, out_dir;
-    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1, merge = 1 /* families per phase batch (--merge K, up to 32); 1 = off: see the worker */, merge_blocks = 24 /* largest covariance of a "small" family, in 128-blocks */;
+    bool merge_given = false;  // --merge on the command line (then the library's own pivot grouping; by default single-block groups: the same bits as unmerged runs)
+    int gpus = 0, parsers = 0 /* 0 = hardware threads / 8, between 4 and 32 */, inflight = 2, passes = 1, merge = 8 /* families per phase batch (--merge K, up to 32); 1 = off: see the worker */, merge_blocks = 24 /* largest covariance of a "small" family, in 128-blocks */;
     bool parse_only = false;
     std::vector<std::string> positional;
 };
@@ -399,6 +400,7 @@ int run_batch(const Options &o)
     const double t0 = now();
     std::vector<double> busy((size_t)G, 0.0);
     std::vector<int> count((size_t)G, 0);
+    std::atomic<int> merged_batches{0};
     std::vector<double> done_at;  // completion time of every family, in order (steady-state rate: start-up -- process start, HIP initialisation,
                                   // the first parses, the first batch -- excluded)
     int completed = 0;
@@ -454,8 +456,9 @@ int run_batch(const Options &o)
                 ++failures;
                 return;
             }
-            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs\n", devs[(size_t)g],
-                    sl.res.name.c_str(), sl.N, sl.M, sl.q, st.theta, st.Meff, sl.parse_s, st.ms_total, now() - sl.t_start);
+            fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs%s\n", devs[(size_t)g],
+                    sl.res.name.c_str(), sl.N, sl.M, sl.q, st.theta, st.Meff, sl.parse_s, st.ms_total, now() - sl.t_start,
+                    st.sweep_retries > 0 ? "  (SPD inverse run again: its first launch was ended by the watchdog)" : "");
             {
                 std::lock_guard<std::mutex> lk(omu);
                 outq.push_back(std::move(sl.res));
@@ -468,18 +471,15 @@ int run_batch(const Options &o)
         // uploaded and enqueued while the previous one computes; they are created when the first small family shows up -- as peers
         // of the pipeline's leader: ONE gate orders every SPD inverse of this GPU, single or merged (two persistent sweep launches
         // that become resident side by side can wait for each other's workgroups until the watchdog ends them).
-        // OFF by default (--merge 1): a member of a merged launch sweeps in larger pivot groups than a launch of its own, so its
-        // scores agree with the one-by-one path to rounding (1e-13), not bit for bit.  Measured on one MI355X, round 5
-        // (profiles/r05_cli_merge.log): 96 families of config B's size run at 661-665 families/s in steady state through the slots'
-        // pipeline and at **1231-1243 through merged batches of eight** (round 4: 630-650 against 650-660 -- until the contexts
-        // lost their side streams and the collects their blit kernels, DESIGN.md section 5, the worker thread's launches and collects
-        // bound both); creating the sixteen extra contexts costs ~0.1 s once.  On the mixed batch of configuration E merged batches
-        // neither gain nor lose (72.4-72.8 against 72.8 families/s).  --merge 8 is the setting for batches of small families.
-        // Round 6 (the batch's kernels as batched grids, every family of a mixed directory through phase batches: --merge 16
-        // --merge-blocks 100000; profiles/r06_cli_batch.log): all 256 families of configuration E, files to files, 3.73-3.81 s
-        // against 3.66-3.75 s through the slots' pipeline with three contexts (device-resident: 3.29 s phase-batched, 3.43 s on two
-        // streams) -- the 4 % the phase batches win on the device are lost again to the first batch (sixteen parses before anything
-        // runs) and to the worker's sixteen uploads and collects per batch: the pipeline stays the default for mixed directories.
+        // ON by default for families of up to 24 blocks (N <= 153 at q = 21), eight to a batch, with the members' pivot groups those of
+        // single launches (MERGE_GROUP=1: every ranking file byte for byte what `--merge 1` writes; tests/test_gpu_configs.py).  `--merge K`
+        // on the command line selects the library's own grouping of merged members (larger pivot groups: scores equal to rounding,
+        // 1e-13, and ~7 % faster at config B's size), `--merge-blocks B` which families count as small, `--merge 1` switches it off.
+        // Measured on one MI355X (profiles/r06_cli_batch.log, r05_cli_merge.log): 96 families of config B's size 661-665 families/s through
+        // the slots' pipeline, 1231-1243 through merged batches of eight; on the mixed batch of configuration E batches of its small
+        // families neither gain nor lose (round 5: 72.4-72.8 against 72.8), and phase batches of EVERYTHING (--merge 16 --merge-blocks
+        // 100000: all 256 families, files to files, 3.73-3.81 s against 3.66-3.75 s) lose at the process level what they win on the
+        // device: the first batch waits for sixteen parses, and the worker uploads and collects sixteen families at a time.
         const int SMALL_BLOCKS = o.merge_blocks;
         struct Set {
             std::vector<Slot> mem;
@@ -488,7 +488,23 @@ int run_batch(const Options &o)
         Set sets[2];
         int cur_set = 0;
         bool sets_ok = true;
-        auto is_small = [&](const Family &f) { return o.merge > 1 && ((long long)f.N * (f.q - 1) + 127) / 128 <= SMALL_BLOCKS; };
+        // (by default only in directories of 128 files and more: the two sets' sixteen extra contexts cost ~40 ms once, a fifth of a
+        // 96-file run of config B's size -- 0.25-0.28 s against 0.22 s -- and nothing of a long one)
+        const char *min_files = getenv("GDCA_CLI_MERGE_MIN_FILES");  // (tests: the default batches in a small directory)
+        const bool merging = o.merge > 1 && (o.merge_given || jobs.size() >= (size_t)(min_files ? std::max(1, atoi(min_files)) : 128));
+        // the sets' contexts are made NOW, before anything runs on the GPU: a context's stream brings a hardware queue to life, and
+        // the driver takes all running kernels off the device and back for that (gdca_api.hip, warm_stream)
+        if (merging && !getenv("GDCA_CLI_LAZY_SETS"))
+            for (Set &st : sets)
+                while (sets_ok && (int)st.mem.size() < o.merge) {
+                    Slot sl;
+                    if (gdca_ctx_create_peer(slots[0].ctx, &sl.ctx) != GDCA_OK) sets_ok = false;
+                    else {
+                        if (!o.merge_given && !getenv("GDCA_MERGE_GROUP")) (void)gdca_ctx_set_option(sl.ctx, "MERGE_GROUP", "1");
+                        st.mem.push_back(std::move(sl));
+                    }
+                }
+        auto is_small = [&](const Family &f) { return merging && ((long long)f.N * (f.q - 1) + 127) / 128 <= SMALL_BLOCKS; };
         auto finish_set = [&](Set &st) {
             for (int m = 0; m < st.used; ++m)
                 if (st.mem[(size_t)m].busy) finish(st.mem[(size_t)m]);
@@ -560,7 +576,12 @@ int run_batch(const Options &o)
                 while (sets_ok && st.mem.size() < grp.size()) {
                     Slot sl;
                     if (gdca_ctx_create_peer(slots[0].ctx, &sl.ctx) != GDCA_OK) sets_ok = false;
-                    else st.mem.push_back(std::move(sl));
+                    else {
+                        // (the default batches keep the pivot grouping of single launches: every ranking file is byte for byte what the
+                        // unmerged driver writes; --merge K asks for the library's faster grouping of merged members, equal to rounding)
+                        if (!o.merge_given && !getenv("GDCA_MERGE_GROUP")) (void)gdca_ctx_set_option(sl.ctx, "MERGE_GROUP", "1");
+                        st.mem.push_back(std::move(sl));
+                    }
                 }
                 bool started = false;
                 if (sets_ok) {
@@ -582,6 +603,7 @@ int run_batch(const Options &o)
                     if (rc == GDCA_OK) {
                         for (int m = 0; m < G2; ++m) st.mem[(size_t)m].busy = true;
                         st.used = G2;
+                        ++merged_batches;
                         cur_set ^= 1;
                         started = true;
                     } else {
@@ -653,11 +675,10 @@ int run_batch(const Options &o)
         // the families that completed after the first `skip` did (one pipeline's worth: the contexts in flight, or the first phase batch --
         // its members all complete at once, which as "first to last" would count fifteen families at no time at all)
         const size_t skip = (size_t)std::max(1, o.inflight) * (size_t)G;
-        if (o.merge > 1)
-            fprintf(stderr, "  (phase batches complete %d families at a time, the biggest families first: no steady-state figure -- compare whole runs)\n", o.merge);
-        else if (done_at.size() > skip + 1 && done_at.back() > done_at[skip - 1])
-            fprintf(stderr, "  steady state (after the first %zu completed families; process start, HIP initialisation and the first parses excluded): %.2f families/s\n",
-                    skip, (double)(done_at.size() - skip) / (done_at.back() - done_at[skip - 1]));
+        if (done_at.size() > skip + 1 && done_at.back() > done_at[skip - 1])
+            fprintf(stderr, "  steady state (after the first %zu completed families; process start, HIP initialisation and the first parses excluded): %.2f families/s%s\n",
+                    skip, (double)(done_at.size() - skip) / (done_at.back() - done_at[skip - 1]),
+                    merged_batches.load() > 0 ? "  (small families completed in phase batches, several at a time)" : "");
     }
     for (int g = 0; g < G; ++g) fprintf(stderr, "  gpu %d: %d families, busy %.3f s\n", devs[(size_t)g], count[(size_t)g], busy[(size_t)g]);
     return failures.load() ? 1 : 0;
@@ -692,7 +713,10 @@ int main(int argc, char **argv)
         else if (s == "--gpus") o.gpus = atoi(val());
         else if (s == "--parsers") o.parsers = atoi(val());
         else if (s == "--inflight") o.inflight = atoi(val());
-        else if (s == "--merge") o.merge = std::min(32, std::max(1, atoi(val())));
+        else if (s == "--merge") {
+            o.merge = std::min(32, std::max(1, atoi(val())));
+            o.merge_given = true;
+        }
         else if (s == "--merge-blocks") o.merge_blocks = std::min(1 << 20, std::max(1, atoi(val())));  // (0 or less: 1; "all": any number beyond the largest family)
         else if (s == "--parse-only") o.parse_only = true;
         else if (s == "--passes") o.passes = atoi(val());

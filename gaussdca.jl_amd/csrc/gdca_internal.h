@@ -51,8 +51,9 @@ struct gdca_tuning {
     int ring;               // GDCA_RING: panel / Pg slots between single blocks (2..8)
     int mcus;               // GDCA_MCUS: compute units elected for the pivot chain (1..16)
     int mcu_solo;           // GDCA_MCU_SOLO: 1 = one chain worker per elected compute unit (its second workgroup leaves; MCUS then counts up to 32), 0 = two, -1 = the measured rule (groups of two and three)
-    int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected
+    int sweep_debug;        // GDCA_SWEEP_DEBUG (tests): bit 0 = XCC 0 stays out of the election, bit 1 = nobody is elected, bit 5 = the watchdog ends the first attempt of every inverse
     long sweep_timeout_ms;  // GDCA_SWEEP_TIMEOUT_MS: bound of one dependency wait; 0 = scaled with the problem (>= 4 s)
+    int sweep_retries;      // GDCA_SWEEP_RETRIES: attempts an inverse gets after its launch was ended by the watchdog (default 2; 0 = none: GDCA_EHIP at once)
     int tally_tj;           // GDCA_TALLY_TJ: 32 = the wide pair-tally form
     int hamming_mode;       // GDCA_HAMMING_MODE: -1 = probe, 0 = full (exact five-plane distances), 1 = bound (three planes + refinement), 2 = mfma (bit counts on the fp4 matrix pipe + refinement)
     int force_fallback;     // GDCA_FORCE_FALLBACK: 1 = the independent byte-compare Hamming kernel
@@ -170,6 +171,7 @@ struct gdca_inverse_job {
     gdca_inverse_ws ws;
     gdca_dev_scalars *sc;
     const gdca_tuning *tune;
+    bool doomed;  // tests (option SWEEP_DEBUG bit 5): this launch's watchdog fires at its first unsatisfied wait
 };
 size_t gdca_inverse_flag_bytes(int n_pad);
 // ONE persistent launch on stream s; upd_ev (optional, 2 events) are recorded around the launch.

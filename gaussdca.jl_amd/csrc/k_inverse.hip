@@ -951,6 +951,7 @@ struct SweepDesc {
     unsigned *arrived;     // workgroups of the launch that have shown up so far (the first member's counter serves a merged launch)
     unsigned *abort;       // set by a workgroup whose dependency wait ran out of time: everybody leaves (watchdog)
     unsigned long long timeout_ticks;  // bound of a single dependency wait, 100 MHz ticks
+    unsigned long long hole_timeout_ticks;  // ... of what is left of a wait once its wave has been off the hardware (spin_until)
     int debug;             // GDCA_SWEEP_DEBUG bits (tests): 1 = workgroups on XCC 0 stay out of the election; 2 = nobody is elected
     const int *gs;         // [ng + 1]: first block of group p (groups need not have the same size: a short ramp 1, 2, .. opens
                            // the sweep so that the first chains are short while there is little update work to hide them behind)
@@ -984,6 +985,7 @@ struct SweepShared {
     unsigned long long stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
     int item, next, ready, fam, live, fnext, pnext;
     int p[8];                     // merged launch: per family, the group this workgroup's last item belonged to
+    unsigned hw_home;             // HW_ID of thread 0's wave when it last looked (spin_until: a wave that has moved was saved and restored)
 };
 __shared__ SweepShared sw;
 #define sw_item sw.item
@@ -1106,8 +1108,22 @@ __device__ __forceinline__ void publish_wt_begin()
 // bug in the item order, a workgroup of the launch that was never scheduled, a device fault elsewhere -- would hang the whole
 // GPU behind a C-ABI that promises to return a status.  So a wait is bounded (D.timeout_ticks of the 100 MHz wall clock, seconds:
 // a healthy wait is microseconds): the workgroup that runs out of time sets the device-wide abort word and sc->info = INT_MIN,
-// every poll loop also looks at that word, and everybody leaves; the host maps it to GDCA_EHIP.  The fast path (flags already
-// set) costs nothing; a poll iteration costs one more load.
+// every poll loop also looks at that word, and everybody leaves; the host runs the inverse once more (gdca_run_collect) and maps
+// a second failure to GDCA_EHIP.  The fast path (flags already set) costs nothing; a poll iteration costs one more load.
+//
+// The one way a healthy launch gets there, found in round 6 (gdca_api.hip, warm_stream): the driver takes the queues of the device
+// off the hardware and back whenever it maps a new one -- a stream's first command in this process, another process starting --
+// and saves and restores the waves of every running kernel for that.  Measured from in here: all waves of the launch miss ~1.7 ms
+// and wake up on other compute units.  Alone on the device the launch then carries on.  Beside kernels of other queues it may
+// get only part of its workgroups back (416 of 512 in every case seen: the second workgroup of three compute units per shader
+// engine stays out, frozen in the middle of whatever item it was working on), the restored ones poll for the items the others hold
+// and keep the compute units those need: a standstill to the end of the bound, although nothing is wrong with the launch.  A
+// polling wave SEES the event -- two polls are microseconds apart, a hole of SWEEP_HOLE_TICKS between them means the wave was off
+// the hardware; a wave that finds itself on another compute unit than at its last wait was off it inside an item (2 of 11 disturbed
+// launches of tools/rounds/r06/gpu_r6s.sh had no workgroup polling at that moment and ran into the full bound) -- and gives its wait only
+// D.hole_timeout_ticks more: the launch ends after tens of milliseconds instead of seconds,
+// and the second attempt has the device to itself like any other launch.
+#define SWEEP_HOLE_TICKS 30000ull  // 0.3 ms of the 100 MHz clock
 __device__ __forceinline__ int *abort_lds()
 {
     __shared__ int w;  // this workgroup has seen the abort (written by thread 0 before a barrier, read by all after it)
@@ -1116,22 +1132,42 @@ __device__ __forceinline__ int *abort_lds()
 
 // `ready` loads the flags of the wait and says whether they are all set; the abort word travels in the same round trip.
 // Returns false when the wait was abandoned.  (Thread 0 only.)
+// where thread 0's wave runs: compute unit, SIMD, wave slot, queue (a wave never moves -- unless it is saved and restored)
+__device__ __forceinline__ unsigned sweep_hw_id()
+{
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return hw;
+}
+
 template <class F>
 __device__ __forceinline__ bool spin_until(const SweepDesc &D, F ready)
 {
-    unsigned long long t0 = 0ull;
+    unsigned long long t0 = 0ull, prev = 0ull, limit = D.timeout_ticks;
     for (unsigned it = 0;; ++it) {
         const unsigned ab = flag_load(D.abort);
         const bool r = ready();
         if (ab != 0u) return false;
         if (r) return true;
-        if (it == 0)
-            t0 = wall_clock64();
-        else if (wall_clock64() - t0 > D.timeout_ticks) {
-            __hip_atomic_store(D.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&D.sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
+        const unsigned long long now = wall_clock64();
+        if (it == 0) {
+            t0 = now;
+            // ... or it sits on another compute unit than the last time it looked: the hole was in an item, not in a wait
+            const unsigned hw = sweep_hw_id();
+            if (hw != sw.hw_home) {
+                sw.hw_home = hw;
+                if (D.hole_timeout_ticks < limit) limit = D.hole_timeout_ticks;
+            }
+        } else {
+            // a hole between two polls: this wave was off the hardware (see above) -- from here on the wait gets the short bound
+            if (now - prev > SWEEP_HOLE_TICKS && now - t0 + D.hole_timeout_ticks < limit) limit = now - t0 + D.hole_timeout_ticks;
+            if (now - t0 > limit) {
+                __hip_atomic_store(D.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&D.sc->info, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
         }
+        prev = now;
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -2222,6 +2258,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
     if (threadIdx.x == 0) {
         launch_desc_init();
         *abort_lds() = 0;
+        sw.hw_home = sweep_hw_id();
         sw_item = sweep_elect(1);
     }
     __syncthreads();
@@ -2340,6 +2377,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep_merged(const SweepBatch Barg)
     if (threadIdx.x == 0) {
         launch_desc_init();
         *abort_lds() = 0;
+        sw.hw_home = sweep_hw_id();
         sw_item = sweep_elect(K);
         for (int f = 0; f < SWEEP_MAX_MERGE; ++f) sw_p[f] = 0;
     }
@@ -2609,6 +2647,10 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     const double model_ms = 8.0 * members * ((double)n_pad * n_pad * n_pad / 50e12 * 1e3);
     const long timeout_ms = tu.sweep_timeout_ms > 0 ? tu.sweep_timeout_ms : std::max(4000L, (long)model_ms);
     D.timeout_ticks = (unsigned long long)std::max(1L, timeout_ms) * 100000ull;
+    // ... and once a polling wave has been off the hardware (spin_until): 50 ms or that modelled duration -- a launch that merely shares
+    // the device goes on within that; one that did not get all its workgroups back never does
+    D.hole_timeout_ticks = std::min(D.timeout_ticks, (unsigned long long)std::max(50L, (long)model_ms) * 100000ull);
+    if (job.doomed) D.timeout_ticks = D.hole_timeout_ticks = 1ull;  // (tests: the first wait that has to poll twice gives up)
     D.debug = tu.sweep_debug;
     D.item0 = ws.item0_dev;
     D.mitem0 = ws.item0_dev + (ng + 1);

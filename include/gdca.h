@@ -43,7 +43,7 @@ extern "C" {
 #define GDCA_MAX_N 60000
 
 #define GDCA_VERSION_MAJOR 0
-#define GDCA_VERSION_MINOR 5
+#define GDCA_VERSION_MINOR 6
 
 typedef enum gdca_status {
     GDCA_OK = 0,
@@ -113,7 +113,7 @@ typedef struct gdca_stats {
                                    no gap).  Every run whose bound is below REFINE_COND is KNOWN to be well enough conditioned
                                    for the sweep and pays nothing for the screen; +inf at pseudocount 0; 0 with option REFINE=0 */
     /* Fields are only ever added at the END, and every addition bumps GDCA_VERSION_MINOR (0.5: the five fields from
-     * matrix_norm1 on).  The LIBRARY fills sizeof(gdca_stats) as IT was built: a binding built against a newer header than
+     * matrix_norm1 on; 0.6: sweep_retries).  The LIBRARY fills sizeof(gdca_stats) as IT was built: a binding built against a newer header than
      * the library reads a valid prefix (the rest stays as the caller initialised it), but a binding built against an OLDER,
      * shorter struct would be overrun -- so a binding compares gdca_stats_bytes() with its own struct size (and
      * gdca_version() with the minor it was written for) once at load time and refuses to run on a mismatch, as the Python
@@ -122,6 +122,10 @@ typedef struct gdca_stats {
                                    8 n (n - s) / 2 bytes); 0 for the DI score and for a run refined at collect time */
     double ms_pair_tally;       /* the pair-tally kernel alone, with its pseudocount + covariance epilogue (its one
                                    compulsory HBM write: 8 n^2 bytes); 0 with option REFINE=0                      */
+    int32_t sweep_retries;      /* 0.6: times this run's SPD inverse was run AGAIN because the sweep kernel's watchdog had ended
+                                   its launch (normally 0; see "Contexts and the device's queues" below).  The result is that
+                                   of the last attempt, the ms_* of the inverse and of the score stage are the last attempt's */
+    int32_t reserved0;          /* (keeps the struct a multiple of 8 bytes; 0) */
 } gdca_stats;
 
 /* ---- library / context ---------------------------------------------------------------- */

@@ -39,6 +39,7 @@ mutable struct GdcaStats
     inverse_flops::Cdouble; update_flops::Cdouble
     sweep_ghz::Cdouble; inverse_norm1::Cdouble; matrix_norm1::Cdouble; cond_bound::Cdouble
     ms_fn::Cdouble; ms_pair_tally::Cdouble
+    sweep_retries::Int32; reserved0::Int32
     GdcaStats() = new()
 end
 
@@ -53,8 +54,8 @@ function ctx()
         ver = ccall((:gdca_version, libgdca), Int32, ())
         sb = ccall((:gdca_stats_bytes, libgdca), Int32, ())
         pb = ccall((:gdca_params_bytes, libgdca), Int32, ())
-        (ver == 5 && sb == sizeof(GdcaStats) && pb == sizeof(GdcaParams)) ||
-            error("libgdca is version $ver with gdca_stats of $sb bytes; this binding mirrors version 5 with $(sizeof(GdcaStats)) bytes")
+        (ver == 6 && sb == sizeof(GdcaStats) && pb == sizeof(GdcaParams)) ||
+            error("libgdca is version $ver with gdca_stats of $sb bytes; this binding mirrors version 6 with $(sizeof(GdcaStats)) bytes")
     end
     return CTX[]
 end

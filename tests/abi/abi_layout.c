@@ -44,6 +44,8 @@ int main(void)
     F(gdca_stats, cond_bound);
     F(gdca_stats, ms_fn);
     F(gdca_stats, ms_pair_tally);
+    F(gdca_stats, sweep_retries);
+    F(gdca_stats, reserved0);
     printf("status GDCA_OK %d 0\nstatus GDCA_EINVAL %d 0\nstatus GDCA_ENOTPD %d 0\nstatus GDCA_EHIP %d 0\n"
            "status GDCA_ENOMEM %d 0\nstatus GDCA_ENOCONV %d 0\n",
            GDCA_OK, GDCA_EINVAL, GDCA_ENOTPD, GDCA_EHIP, GDCA_ENOMEM, GDCA_ENOCONV);

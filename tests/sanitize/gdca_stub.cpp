@@ -117,6 +117,11 @@ gdca_status gdca_ctx_create_peer(gdca_ctx *leader, gdca_ctx **out)
     return leader ? gdca_ctx_create(leader->device, out) : GDCA_EINVAL;
 }
 
+gdca_status gdca_ctx_set_option(gdca_ctx *ctx, const char *key, const char *value)
+{
+    return (ctx && key && value) ? GDCA_OK : GDCA_EINVAL;  // (the batch driver sets MERGE_GROUP on its batch contexts)
+}
+
 gdca_status gdca_run_ranked_async(gdca_ctx *ctx, const int8_t *Z, int32_t N, int32_t M, int32_t q, const gdca_params *p, int32_t min_separation)
 {
     if (!ctx || ctx->pending || N < 1 || min_separation < 1) return GDCA_EINVAL;

@@ -41,9 +41,9 @@ def test_python_binding_covers_the_header(lib_path):
 
     assert sorted(_lib.SYMBOLS) == _declared_symbols()
     lib = _lib.load()
-    assert lib.gdca_version() == 5 == _lib.ABI_VERSION
+    assert lib.gdca_version() == 6 == _lib.ABI_VERSION
     assert lib.gdca_stats_bytes() == ctypes.sizeof(_lib.Stats) and lib.gdca_params_bytes() == ctypes.sizeof(_lib.Params)
-    assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 10 + 8 * 15  # ten int32, fifteen more doubles
+    assert ctypes.sizeof(_lib.Stats) == 8 * 3 + 4 * 10 + 8 * 15 + 4 * 2  # ten int32, fifteen more doubles, two int32
     assert ctypes.sizeof(_lib.Params) == 24
 
 

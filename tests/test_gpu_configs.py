@@ -354,8 +354,12 @@ def test_batch_driver_merges_small_families(g, ctx, tmp_path):
     for f, (N, M) in enumerate(sizes):
         synth.write_fasta(str(indir / ("fam%03d.fasta" % f)), synth.synth_family(N, M, 21, 0xABC0 + f))
     outs = {}
-    wide = ["--merge", "8", "--merge-blocks", "57"]    # (merged batches are an option of the driver, off by default; 24 blocks by default)
-    for name, args, env in (("unmerged", ["--merge", "1"], {}), ("merged_g1", wide, {"GDCA_MERGE_GROUP": "1"}), ("merged", wide, {})):
+    wide = ["--merge", "8", "--merge-blocks", "57"]
+    # (round 6: by DEFAULT -- no --merge on the command line, a directory of 128 files or more [here: GDCA_CLI_MERGE_MIN_FILES] -- families of up
+    # to 24 blocks go eight to a batch with the pivot groups of single launches: byte-identical files; `--merge K` selects the library's own
+    # grouping of merged members)
+    for name, args, env in (("unmerged", ["--merge", "1"], {}), ("merged_g1", wide, {"GDCA_MERGE_GROUP": "1"}), ("merged", wide, {}),
+                            ("default", [], {"GDCA_CLI_MERGE_MIN_FILES": "1"}), ("default_wide", ["--merge-blocks", "57"], {"GDCA_CLI_MERGE_MIN_FILES": "1"})):
         out = tmp_path / name
         r = subprocess.run([CLI, "--batch", str(indir), "--out", str(out), "--parsers", "4", *args], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, **env))
@@ -365,6 +369,7 @@ def test_batch_driver_merges_small_families(g, ctx, tmp_path):
         fn = "fam%03d.rank.txt" % f
         ref = (outs["unmerged"] / fn).read_bytes()
         assert (outs["merged_g1"] / fn).read_bytes() == ref, (f, sizes[f])
+        assert (outs["default"] / fn).read_bytes() == ref and (outs["default_wide"] / fn).read_bytes() == ref, (f, sizes[f])
         i0, j0, s0 = _read_rank(outs["unmerged"] / fn)
         i1, j1, s1 = _read_rank(outs["merged"] / fn)
         assert len(i0) == len(i1) and sorted(zip(i0.tolist(), j0.tolist())) == sorted(zip(i1.tolist(), j1.tolist()))

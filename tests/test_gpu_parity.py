@@ -685,6 +685,72 @@ def test_merged_inverses_equal_single_launches(g, ctx):
             c.close()
 
 
+def test_a_launch_the_watchdog_ended_gets_a_second_attempt(g):
+    """The sweep's watchdog is not the end of a run (round 6): a healthy launch can lose part of its workgroups when the driver takes the
+    device's queues off the hardware and back (a new stream's first command, another process starting), stands still and is ended
+    by its bounded waits -- gdca_run_collect then builds the covariance again and runs the inverse once more.  SWEEP_DEBUG bit 5 lets
+    the watchdog end the FIRST attempt of every inverse: every entry must return what it returns without it, bit for bit, and say so
+    in gdca_stats.sweep_retries; with SWEEP_RETRIES=0 the first failure is final (GDCA_EHIP, as before round 6)."""
+    import torch
+
+    rng = np.random.default_rng(606)
+    fams = [random_msa(rng, M, N) for M, N in ((500, 60), (800, 45), (400, 150), (600, 90))]       # (M, N), rows = sequences
+    Zf = [np.asfortranarray(Zo.T) for Zo in fams]
+    ref = g.Context(0)
+    cs = [g.Context(0)]
+    cs += [cs[0].peer() for _ in range(3)]
+    try:
+        ref.set_options(MERGE_GROUP=1)
+        want = [ref.run(Z, 21, 0.8, -1.0, 0) for Z in Zf]
+        want_r = [ref.run_ranked_ptr(Z.ctypes.data, Z.shape[0], Z.shape[1], 21, 0.8, -1.0, 0, 5) for Z in Zf]
+        assert all(st["sweep_retries"] == 0 for _, st in want)
+        for c in cs:
+            c.set_options(SWEEP_DEBUG=32)
+        # the fused run and its ranked form
+        for k, Z in enumerate(Zf[:2]):
+            S, st = cs[0].run(Z, 21, 0.8, -1.0, 0)
+            assert st["sweep_retries"] == 1 and st["info"] == 0
+            assert np.array_equal(S, want[k][0])
+            ii, jj, sc, st2 = cs[0].run_ranked_ptr(Z.ctypes.data, Z.shape[0], Z.shape[1], 21, 0.8, -1.0, 0, 5)
+            assert st2["sweep_retries"] == 1
+            assert np.array_equal(ii, want_r[k][0]) and np.array_equal(jj, want_r[k][1]) and np.array_equal(sc, want_r[k][2])
+        # a phase batch: its merged launch is ended, every member runs again on its own (MERGE_GROUP=1: the grouping of single launches)
+        cs[0].set_options(MERGE_GROUP=1)
+        dZ = [torch.from_numpy(Zo).cuda() for Zo in fams]
+        dS = [torch.zeros((Zo.shape[1], Zo.shape[1]), dtype=torch.float64, device="cuda") for Zo in fams]
+        g.run_dev_phased(cs, [z.data_ptr() for z in dZ], [Zo.shape[1] for Zo in fams], [Zo.shape[0] for Zo in fams], [21] * 4, 0.8, -1.0, 0,
+                         [x.data_ptr() for x in dS])
+        sts = [c.collect() for c in cs]
+        for k in range(4):
+            assert sts[k]["sweep_retries"] == 1 and sts[k]["info"] == 0, (k, sts[k])
+            assert np.array_equal(dS[k].cpu().numpy(), want[k][0]), k
+        # ... and ranked, from host matrices
+        g.run_ranked_phased_async(cs, [Z.ctypes.data for Z in Zf], [Z.shape[0] for Z in Zf], [Z.shape[1] for Z in Zf], [21] * 4, 0.8, -1.0, 0, 5)
+        for k, c in enumerate(cs):
+            ii, jj, sc, st2 = c.run_ranked_collect()
+            assert st2["sweep_retries"] == 1
+            assert np.array_equal(ii, want_r[k][0]) and np.array_equal(jj, want_r[k][1]) and np.array_equal(sc, want_r[k][2]), k
+        # the operator-level inverse
+        n = 1500
+        B = rng.standard_normal((n, 32))
+        A = (B @ B.T) / 32 + np.diag(0.5 + rng.random(n))
+        d = torch.from_numpy(A).cuda()
+        assert g.spd_inverse_batch_dev(cs[:1], [d.data_ptr()], [n]) == [0]
+        assert np.max(np.abs(d.cpu().numpy() - np.linalg.inv(A))) < 1e-9
+        # no second attempt: the first failure is the run's
+        cs[0].set_options(SWEEP_RETRIES=0)
+        with pytest.raises(g.GdcaError) as ei:
+            cs[0].run(Zf[0], 21, 0.8, -1.0, 0)
+        assert "timed out" in str(ei.value)
+        cs[0].set_options(SWEEP_RETRIES=2, SWEEP_DEBUG=0)
+        S, st = cs[0].run(Zf[0], 21, 0.8, -1.0, 0)
+        assert st["sweep_retries"] == 0 and np.array_equal(S, want[0][0])
+    finally:
+        for c in reversed(cs):
+            c.close()
+        ref.close()
+
+
 def test_merged_sweep_watchdog(g):
     """The merged launch keeps the promise of the single one: when a member's chain never runs (SWEEP_DEBUG bit 1: nobody is
     elected) the bounded waits end the launch, EVERY member of it is reported as aborted (no member's result can be trusted
