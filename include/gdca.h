@@ -135,6 +135,18 @@ int32_t gdca_stats_bytes(void);
 int32_t gdca_params_bytes(void);
 int32_t gdca_device_count(void);
 
+/* Contexts and the device's queues.  A context owns a stream, and a stream's hardware queue comes into being with its first command;
+ * the driver maps a new queue by taking EVERY queue of the device off the hardware and back -- the waves of all running kernels are
+ * saved and restored (~1.7 ms).  A persistent sweep restored beside the kernels of other queues may not get all its workgroups back
+ * and then stands still until its watchdog ends it (round 6; gdca_api.hip, warm_stream; k_inverse.hip, spin_until).  Therefore:
+ *   - gdca_ctx_create / _create_peer make the stream's queue at once (a small fill and a synchronisation: ~0.2 ms more per context);
+ *   - make the contexts a program needs BEFORE it enqueues work, as the batch driver and bench.py do.  A context on a caller's stream
+ *     (gdca_ctx_create_on_stream) is the caller's business: run something on that stream first;
+ *   - what a program cannot rule out (another process starting on the GPU, a library of its own that makes a stream) is survived: the
+ *     sweep notices that its waves were off the hardware and ends a launch that no longer moves after ~0.1 s instead of seconds, and
+ *     gdca_run_collect / gdca_spd_inverse_dev run that inverse again -- up to option SWEEP_RETRIES (default 2) times, reported in
+ *     gdca_stats.sweep_retries; the results are those of an undisturbed run, bit for bit.  Only an inverse that fails every attempt
+ *     is GDCA_EHIP ("a dependency wait inside the sweep kernel timed out"). */
 gdca_status gdca_ctx_create(int32_t device_id, gdca_ctx **out);
 /* same, but enqueue on an existing hipStream_t (passed as void*); NULL = the null stream */
 gdca_status gdca_ctx_create_on_stream(int32_t device_id, void *hip_stream, gdca_ctx **out);
@@ -155,7 +167,7 @@ gdca_status gdca_ctx_set_timing(gdca_ctx *ctx, int32_t enabled);
  * created; afterwards only this call changes them, and two contexts of one process may differ).  key = the variable's name with
  * or without the GDCA_ prefix, any case; value = what the variable would hold.  Schedule of the SPD inverse: GROUP (1..4, -1 = the
  * measured rule), RAMP, RAGGED, REM_TAIL, PANEL_HALVES, SLAB, RING, MCUS, MCU_SOLO; SWEEP_TIMEOUT_MS (bound of one dependency wait inside
- * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
+ * the sweep kernel; 0 = scaled with the problem, at least 4 s), SWEEP_RETRIES (0..5: further attempts of an inverse whose launch the watchdog ended), SWEEP_DEBUG, SWEEP_TRACE (file); HAMMING_MODE (auto | full |
  * bound | mfma: the bit-count lower bound on the fp4 matrix pipe -- exact counts, never the automatic choice), FORCE_FALLBACK (the independent byte-compare Hamming kernel, cf. DCAUTILS_FORCE_FALLBACK in test/runtests.jl:78-86),
  * TALLY_TJ; MERGE (families per merged SPD-inverse launch in gdca_run_dev_phased, 1 = off), MERGE_BLOCKS (largest member, in
  * 128-blocks), MERGE_TILES, MERGE_GROUP, MERGE_MCUS, PHASED_FRONTS (1: the front ends of a phase batch run side by side on the
