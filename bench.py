@@ -737,6 +737,8 @@ def summarize(args, meas, world, dist, comm_fallback):
         "stage_ms": {k: float(np.mean([s[k] for s in stats])) for k in
                      ("ms_total", "ms_theta", "ms_weights", "ms_covariance", "ms_inverse", "ms_inverse_update",
                       "ms_score")},
+        # inverses of the timed region that were run AGAIN because the sweep's watchdog had ended their launch (normally 0: DESIGN.md 3.1a)
+        "sweep_retries": int(np.sum([s.get("sweep_retries", 0) for s in stats])),
         "roofline": {
             "kernel": kernel,
             "bound": "mfma",

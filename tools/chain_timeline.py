@@ -24,7 +24,7 @@ def grp(q, kind):   # kind: 'slab', 'xslab', 'slab2' of step q -> list of (ready
             return [items.get((q, base + i)) for i in range(8)]
         base = 1 if kind == 'xslab' else 9
         return [items.get((q + 1, base + i)) for i in range(8)]
-    base = {'slab': 1, 'xslab': 9, 'slab2': 17}[kind]
+    base = {'slab': 1, 'xslab': 9, 'slab2': 17, 'slab3': 25}[kind]
     return [items.get((q, base + i)) for i in range(8)]
 def span(v):
     v = [x for x in v if x]
@@ -34,7 +34,7 @@ prev = None
 for q in range(lo, min(hi, ng - 1) + 1):
     pv = items[(q, 0)]
     s = "%3d | %7.1f .. %7.1f" % (q, pv[0], pv[1])
-    for k in ('slab', 'xslab', 'slab2'):
+    for k in ('slab', 'xslab', 'slab2') + (('slab3',) if (q, 25) in items else ()):
         a, b = span(grp(q, k))
         s += " | %7.1f .. %7.1f" % (a, b)
     s += " ||"
