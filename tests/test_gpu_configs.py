@@ -378,6 +378,38 @@ def test_batch_driver_merges_small_families(g, ctx, tmp_path):
         assert dev <= 2e-6, (f, sizes[f], dev)          # (%e keeps seven digits: one unit of the last is 1e-6 relative)
 
 
+def test_batch_driver_survives_hardware_queues_made_beside_running_sweeps(g, ctx, tmp_path):
+    """Round 6's standstill, kept as a test (tools/rounds/r06/gpu_r6q.sh, gpu_r6s.sh): with GDCA_CLI_LAZY_SETS=1 the driver makes the
+    contexts of its phase batches when the first small family shows up -- their streams' hardware queues come to life beside the slots'
+    running sweeps, the driver maps them by taking every queue off the device and back, and now and then (1 to 8 runs of 100) a sweep does
+    not get all its workgroups back.  The sweep notices (a hole between two polls, a wave on another compute unit), gives up early, and the
+    collect runs the inverse again: no run may fail, every ranking file must be the undisturbed driver's, byte for byte."""
+    from gaussdca.jl_amd import synth
+
+    rng = np.random.default_rng(8)
+    indir = tmp_path / "in"
+    indir.mkdir()
+    sizes = [(min(int(n), 281), int(m)) for n, m in zip(rng.integers(6, 288, size=20), rng.integers(300, 4000, size=20))] + [(420, 3000), (380, 2500)]
+    for f, (N, M) in enumerate(sizes):
+        synth.write_fasta(str(indir / ("fam%03d.fasta" % f)), synth.synth_family(N, M, 21, 0xABC0 + f))
+    wide = ["--merge", "8", "--merge-blocks", "57"]
+    ref = tmp_path / "ref"
+    r = subprocess.run([CLI, "--batch", str(indir), "--out", str(ref), "--parsers", "4", *wide], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GDCA_MERGE_GROUP="1"))
+    assert r.returncode == 0 and "(0 failed)" in r.stderr, r.stderr[-3000:]
+    again = 0
+    for rep in range(30):
+        out = tmp_path / ("lazy%02d" % rep)
+        r = subprocess.run([CLI, "--batch", str(indir), "--out", str(out), "--parsers", "4", *wide], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, GDCA_MERGE_GROUP="1", GDCA_CLI_LAZY_SETS="1"))
+        assert r.returncode == 0 and "22 families" in r.stderr and "(0 failed)" in r.stderr, (rep, r.stderr[-3000:])
+        again += r.stderr.count("run again")
+        for f in range(len(sizes)):
+            fn = "fam%03d.rank.txt" % f
+            assert (out / fn).read_bytes() == (ref / fn).read_bytes(), (rep, f, sizes[f])
+    print("inverses run again in 30 runs:", again)
+
+
 @pytest.mark.parametrize("which", ["smallest", "largest", "mid_a", "mid_b"])
 def test_config_E_families_match_oracle(g, ctx, o, which):
     """Four of the 16 sampled batch families at their real sizes against the oracle's whole pipeline (the batch test
