@@ -1132,12 +1132,12 @@ __device__ __forceinline__ int *abort_lds()
 
 // `ready` loads the flags of the wait and says whether they are all set; the abort word travels in the same round trip.
 // Returns false when the wait was abandoned.  (Thread 0 only.)
-// where thread 0's wave runs: compute unit, SIMD, wave slot, queue (a wave never moves -- unless it is saved and restored)
+// where thread 0's wave runs: compute unit, SIMD, wave slot (a wave never moves -- unless it is saved and restored)
 __device__ __forceinline__ unsigned sweep_hw_id()
 {
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    return hw;
+    return hw & 0x000fff3fu;  // wave slot, SIMD, compute unit, shader array, shader engine, workgroup slot (not the queue / state fields)
 }
 
 template <class F>
