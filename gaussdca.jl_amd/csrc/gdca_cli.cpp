@@ -456,9 +456,10 @@ int run_batch(const Options &o)
                 ++failures;
                 return;
             }
+            char again[96] = "";
+            if (st.sweep_retries > 0) snprintf(again, sizeof(again), "  (SPD inverse run again, %d time(s): the watchdog had ended its launch)", st.sweep_retries);
             fprintf(stderr, "gpu %d  %-24s N=%d M=%d q=%d theta=%.6f Meff=%.4f  parse %.3fs  device %.1f ms  total %.3fs%s\n", devs[(size_t)g],
-                    sl.res.name.c_str(), sl.N, sl.M, sl.q, st.theta, st.Meff, sl.parse_s, st.ms_total, now() - sl.t_start,
-                    st.sweep_retries > 0 ? "  (SPD inverse run again: its first launch was ended by the watchdog)" : "");
+                    sl.res.name.c_str(), sl.N, sl.M, sl.q, st.theta, st.Meff, sl.parse_s, st.ms_total, now() - sl.t_start, again);
             {
                 std::lock_guard<std::mutex> lk(omu);
                 outq.push_back(std::move(sl.res));

@@ -33,6 +33,6 @@ PY
   done
   echo "$name: $bad failures of $runs; runs with an inverse run again: $again; runs of a second and more: $slow"
 }
-try early_sets 100
-try lazy_sets 300 GDCA_CLI_LAZY_SETS=1
+try early_sets 30
+try lazy_sets 200 GDCA_CLI_LAZY_SETS=1
 grep -h "run again" $out/again_*.log | awk '{print $4, $5}' | sort | uniq -c | sort -rn | head
