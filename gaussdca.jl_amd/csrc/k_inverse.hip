@@ -971,6 +971,7 @@ struct SweepDesc {
     gdca_dev_scalars *sc;
     unsigned long long *dbg;  // optional (GDCA_SWEEP_TRACE): 100 MHz wall-clock stamps, (start, end) per M-list item
     unsigned long long *dbg_main;  // optional: [0] ticks tile items waited, [1] panel items waited, [2..] ticks / counts by kind
+    unsigned long long *dbg_items; // optional: per main-list item (kind, p, a, b, workgroup), taken, end of its wait, done (100 MHz stamps)
 };
 
 // LDS of the sweep kernels, at file scope so that the out-of-line item functions (below) address it as LDS without having it
@@ -985,6 +986,7 @@ struct SweepShared {
     unsigned long long stamp[2];  // trace: start of the current main-list item (wall clock, shader clock)
     int item, next, ready, fam, live, fnext, pnext;
     int p[8];                     // merged launch: per family, the group this workgroup's last item belonged to
+    int cur;                      // trace: the main-list item this workgroup is working on (-1: an item of the chain)
     unsigned hw_home;             // HW_ID of thread 0's wave when it last looked (spin_until: a wave that has moved was saved and restored)
 };
 __shared__ SweepShared sw;
@@ -1599,6 +1601,7 @@ __device__ __forceinline__ void sweep_panel_item(const SweepDesc &D, int p, int 
             return (f0 >= nmi) & (f1 >= (unsigned)p) & (f2 >= (unsigned)p) & (f3 >= (unsigned)p) & (f4 >= (unsigned)p) & (f5 >= want);
         });
         if (D.dbg) {
+            if (sw.cur >= 0) D.dbg_items[4 * (size_t)sw.cur + 2] = wall_clock64();
             atomicAdd(D.dbg_main + 1, wall_clock64() - t0);
             if (D.slab && i == b0 + 3) atomicMax(D.dbg_main + 8 + 1024 + 3 * D.ng + 16 * p + 9, wall_clock64());  // trace: last half ready
         }
@@ -1828,6 +1831,7 @@ __device__ __forceinline__ bool tile_item_wait(const SweepDesc &D, int p, int I,
             return (f1 >= need1) & (f2 >= need) & (f3 >= (unsigned)p);
         });
         if (D.dbg) {
+            if (sw.cur >= 0) D.dbg_items[4 * (size_t)sw.cur + 2] = wall_clock64();
             atomicAdd(D.dbg_main + 0, wall_clock64() - t0);
             const int r3 = g_start(D, p) + 3;
             if (D.slab && I == r3 && J >= r3 - 2) D.dbg_main[8 + 1024 + 3 * D.ng + 16 * p + 10 + (J - (r3 - 2))] = wall_clock64();  // trace: ready
@@ -2036,6 +2040,7 @@ __device__ __forceinline__ void sweep_wb_item(const SweepDesc &D, int p, int e, 
         });
     }
     if (!acquire_end(ok)) return;
+    if (D.dbg && tid == 0 && sw.cur >= 0) D.dbg_items[4 * (size_t)sw.cur + 2] = wall_clock64();
     panel_writeback_tile(D.A, D.ld, k, i, D.H0 + (ring_panel(D, p) + w) * D.pstride, D.ld, Gs[0]);
     publish_begin();
     if (tid == 0) {
@@ -2272,6 +2277,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
         sw_probe[1] = wall_clock64();
     }
     __syncthreads();
+    if (threadIdx.x == 0) sw.cur = -1;
     if (m_worker) sweep_chain_worker<MULTI>(0);
     int p = 0;  // group whose sequence the last item belonged to (items come in ascending order)
     // the NEXT item is requested while the current one is being worked on (the returning atomic takes a microsecond or two
@@ -2304,7 +2310,14 @@ __global__ __launch_bounds__(256, 2) void k_sweep(const SweepDesc Darg)
             }
         }
         const NextTake nt{nxt, 1, 0};
+        if (D.dbg && threadIdx.x == 0) {
+            sw.cur = item;
+            D.dbg_items[4 * (size_t)item] = ((unsigned long long)(unsigned)it.kind << 56) | ((unsigned long long)(unsigned)it.p << 44) | ((unsigned long long)(unsigned)it.a << 32) |
+                                            ((unsigned long long)(unsigned)it.b << 20) | (unsigned long long)blockIdx.x;
+            D.dbg_items[4 * (size_t)item + 1] = sw_stamp[0];
+        }
         const bool published = sweep_main_item<MULTI>(D, 0, it, rdy, nt);
+        if (D.dbg && threadIdx.x == 0) D.dbg_items[4 * (size_t)item + 3] = wall_clock64();
         if (D.dbg && threadIdx.x == 0) {
             const unsigned long long t_item = sw_stamp[0], c_item = sw_stamp[1];
             const int xslot = D.slab ? sweep_trace_xslot(D, it) : -1;
@@ -2685,6 +2698,7 @@ static SweepPlan plan_sweep(hipStream_t s0, const gdca_inverse_job &job, bool me
     D.sc = job.sc;
     D.dbg = nullptr;
     D.dbg_main = nullptr;
+    D.dbg_items = nullptr;
     P.g = g;
     P.mpos = mpos;
     P.chunks = chunks;
@@ -2712,11 +2726,13 @@ void gdca_launch_spd_inverse(hipStream_t s0, const gdca_inverse_job &job, hipEve
     const char *trace_path = job.tune->sweep_trace[0] ? job.tune->sweep_trace : nullptr;
     unsigned long long *dbg = nullptr;
     if (trace_path) {
-        (void)hipMalloc(&dbg, (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) * sizeof(unsigned long long));
-        (void)hipMemsetAsync(dbg, 0, (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) * sizeof(unsigned long long), s0);
+        const size_t words = (size_t)(2 * (mpos + 1) + 8 + 1024 + 19 * ng) + 4 * ((size_t)D.total + 1);
+        (void)hipMalloc(&dbg, words * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dbg, 0, words * sizeof(unsigned long long), s0);
     }
     D.dbg = dbg;
     D.dbg_main = dbg ? dbg + 2 * (mpos + 1) : nullptr;
+    D.dbg_items = dbg ? dbg + 2 * (mpos + 1) + 8 + 1024 + 19 * (size_t)ng : nullptr;
     const unsigned grid = (unsigned)(2 * job.ws.update_cus);  // two 256-VGPR workgroups per CU: every register file full
     const bool tm = upd_ev && max_upd_ev >= 2;
     if (tm) (void)hipEventRecord(upd_ev[0], s0);
@@ -2819,6 +2835,15 @@ static void write_sweep_trace(const char *trace_path, const SweepPlan &P, unsign
             for (long long x = 0; x < mpos; ++x) {
                 while (x >= mit[q + 1]) ++q;
                 fprintf(fp, "%d %lld %.2f %.2f\n", q, x - mit[q], (double)(h[2 * x] - t0) / 100.0, (double)(h[2 * x + 1] - t0) / 100.0);
+            }
+            // every main-list item: kind p a b workgroup | taken, end of its wait (= taken where it did not have to poll), done
+            std::vector<unsigned long long> hi((size_t)4 * P.D.total);
+            (void)hipMemcpy(hi.data(), dbg + 2 * (mpos + 1) + 8 + 1024 + 19 * (size_t)ng, hi.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            for (int x = 0; x < P.D.total; ++x) {
+                const unsigned long long w = hi[4 * (size_t)x], tk = hi[4 * (size_t)x + 1], rd = hi[4 * (size_t)x + 2], dn = hi[4 * (size_t)x + 3];
+                if (!tk) continue;  // (an empty slot)
+                fprintf(fp, "m %d %llu %llu %llu %llu %llu %.2f %.2f %.2f\n", x, w >> 56, (w >> 44) & 0xfff, (w >> 32) & 0xfff, (w >> 20) & 0xfff, w & 0xfffff,
+                        (double)(long long)(tk - t0) / 100.0, (double)(long long)((rd ? rd : tk) - t0) / 100.0, (double)(long long)(dn - t0) / 100.0);
             }
             fclose(fp);
         }

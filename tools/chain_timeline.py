@@ -13,7 +13,7 @@ for l in open(path):
         import re
         f = re.findall(r"(-?[\d.]+) \(ready\s+(-?[\d.]+)\) \.\.\s+(-?[\d.]+)", l)
         xs[p] = [tuple(float(v) for v in t) for t in f]
-    elif not l.startswith("#"):
+    elif not l.startswith("#") and not l.startswith("m "):
         q, e, a, b = l.split()
         items[(int(q), int(e))] = (float(a), float(b))
 ng = max(q for q, _ in items) + 1

@@ -14,7 +14,7 @@ for rep in range(2):   # second call: warm
         X = g.inv_cholesky(A, ctx=ctx)
     except g.PosDefException as e:   # timing experiments with deliberately wrong arithmetic end up here
         print("not positive definite:", e)
-rows = [l.split() for l in open(TRACE) if not l.startswith("#")]
+rows = [l.split() for l in open(TRACE) if not l.startswith("#") and not l.startswith("m ")]
 for l in open(TRACE):
     if l.startswith("#"): print(l.strip())
 gsel = {int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["10", "11"])}
