@@ -820,7 +820,10 @@ def test_sweep_trace_lists_every_chain_item(tmp_path, group, items):
     assert json.loads(r.stdout.strip().splitlines()[-1])["rel"] <= 1e-10
     lines = trace.read_text().splitlines()
     head = [l for l in lines if l.startswith("#")]
-    rows = [l.split() for l in lines if not l.startswith("#")]
+    rows = [l.split() for l in lines if not l.startswith("#") and not l.startswith("m ")]
+    # (round 6: every main-list item too -- "m index kind p a b workgroup taken ready done", what tools/critical_path.py walks)
+    mains = [l.split() for l in lines if l.startswith("m ")]
+    assert len(mains) > 100 and all(float(m[9]) >= float(m[8]) >= float(m[7]) - 1e-9 for m in mains if int(m[2]) != 3)
     assert head[0].startswith("# nblk 12 g %s" % group)
     assert any(l.startswith("# pivot items: 12;") for l in head)
     if items is not None:
